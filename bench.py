@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X state-vector evolution core.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): n=30 (+log2 N) qubit random
+circuit, depth 40 = 20 x (Haar U(2) on every qubit + Haar U(4) on a random perfect
+matching), complex64, NO gate fusion -> 900 gate applications at n=30, k in {1,2}.
+One "step" = one pass of that circuit over the resident state vector.  The state is
+already in HBM when the timed region starts; matrices (<= 128 B each) cross the C ABI
+as host pointers exactly like in the reference (simulation.py:637-644).
+
+Prints ONE JSON line (rank 0):  value = amplitude updates per second of the whole job
+(= gate-applications/s x 2^n), plus gate_apps_per_s, a `roofline` object for the
+dominant kernel measured live with HIP events on the library's stream, and (N=1) a
+`cpu_baseline` object: the reference's own C++ core (oracle/_ref, "reference") or this
+repo's C restatement ("port") timed on the host cores on a bounded sample of the same
+circuit.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--qubits', type=int, default=None, help='qubits per GPU shard + log2(gpus); default 30 per GPU')
+    ap.add_argument('--depth', type=int, default=40)
+    ap.add_argument('--workload', default='rqc_1q2q', choices=['rqc_1q2q', 'dense_k34'])
+    ap.add_argument('--dtype', default='complex64', choices=['complex64', 'complex128'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-events', action='store_true', help='skip per-gate HIP events in the timed region')
+    return ap.parse_args()
+
+
+def kernel_class(pos, vb):
+    """Name of the kernel instantiation a call dispatches to (see csrc/hq_hip.hip)."""
+    k = len(pos)
+    vmask = sum(1 << p for p in pos if p < vb)
+    if k <= 3:
+        return f'apply_direct<k={k},vmask={vmask}>'
+    return f'apply_generic<k={k}>'
+
+
+def cpu_baseline(gates, n, seconds, complex_type):
+    """Time the reference C++ core (or the port) on a bounded prefix of the same circuit."""
+    import oracle
+    from oracle.binding import aligned_empty
+    try:
+        lib = oracle.load_ref()
+    except Exception:
+        lib = oracle.load_port()
+    ft = np.float32 if complex_type == 'complex64' else np.float64
+    try:
+        avail = os.sysconf('SC_AVPHYS_PAGES') * os.sysconf('SC_PAGE_SIZE')
+    except (ValueError, OSError):
+        avail = 16 << 30
+    n_cpu = n
+    while n_cpu > 20 and 2 * (1 << n_cpu) * np.dtype(ft).itemsize * 1.5 > avail:
+        n_cpu -= 1
+    if n_cpu != n:  # same generator, fewer qubits (host RAM too small for the full state)
+        from hybridq_amd.circuits import rqc_1q2q
+        gates = rqc_1q2q(n_cpu, depth=40, seed=n)
+    planes = aligned_empty((2, 1 << n_cpu), ft)
+    planes[:] = 0
+    planes[0, 0] = 1
+    warm = min(8, max(0, len(gates) - 2))
+    _, info = oracle.evolve_reference_protocol(lib, gates, n_cpu, complex_type=complex_type, planes=planes,
+                                               warmup_gates=warm, max_seconds=seconds, to_complex=False)
+    gps = info['n_gates'] / info['runtime (s)']
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    threads = int(os.environ.get('OMP_NUM_THREADS', cores))
+    return {
+        'value': gps * (1 << n_cpu),
+        'unit': 'amplitudes/s',
+        'gate_apps_per_s': gps,
+        'cores': threads,
+        'kind': lib.kind,
+        'sample': (f'first {info["n_gates"]} gate applications (after {warm} warm-up) of the same n={n_cpu} '
+                   f'depth-40 circuit through the reference driver protocol (swap policy + apply_U), '
+                   f'{info["runtime (s)"]:.1f} s, OpenMP threads={threads}'),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from hybridq_amd import core
+    from hybridq_amd.circuits import rqc_1q2q, dense_kq
+
+    g = int(np.log2(world))
+    assert 1 << g == world, 'number of GPUs must be a power of two'
+    n_local = 30 if args.qubits is None else args.qubits - g
+    n = n_local + g
+    if args.workload == 'rqc_1q2q':
+        gates = rqc_1q2q(n, depth=args.depth, seed=n)
+    else:
+        gates = dense_kq(n, n_gates=200, seed=34)
+    ft = np.dtype('float32') if args.dtype == 'complex64' else np.dtype('float64')
+    vb = 2 if ft == np.dtype('float32') else 1
+    bytes_per_gate = 2 * (1 << n_local) * 2 * ft.itemsize  # read+write both planes (per GPU)
+
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    if world == 1:
+        from hybridq_amd.simulation import EvolutionState
+        state = EvolutionState(list(range(n)), complex_type=args.dtype, initial_state='0' * n)
+        plan = [(U, qs, [state.map[q] for q in reversed(qs)]) for U, qs in gates]
+
+        def run_step(events=None):
+            for i, (U, qs, pos) in enumerate(plan):
+                if events is not None:
+                    events[i][0].record()
+                core.apply_U(state.planes[0], state.planes[1], U, pos, n)
+                if events is not None:
+                    events[i][1].record()
+
+        n_exchanges = 0
+    else:
+        from hybridq_amd.dist import ShardedEvolution
+        sharded = ShardedEvolution(n, complex_type=args.dtype, initial_state='0' * n)
+        schedule = sharded.plan(gates)
+        n_exchanges = sum(1 for op in schedule if op[0] == 'X')
+
+        def run_step(events=None):
+            sharded.run(schedule)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step()
+    barrier()
+    events = None
+    if world == 1 and not args.no_events:
+        events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                   for _ in gates] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        run_step(events[s] if events is not None else None)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    gate_apps = args.steps * len(gates)
+    gps = gate_apps / elapsed
+    result = {
+        'metric': 'amplitude updates/s (gate-applications/s x 2^n), n-qubit random circuit, state-vector evolution',
+        'value': gps * float(1 << n),
+        'unit': 'amplitudes/s',
+        'gate_apps_per_s': gps,
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'ms_per_gate': 1e3 * elapsed / gate_apps,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32' if ft == np.dtype('float32') else 'f64',
+        'data': 'synthetic',
+        'config': {
+            'workload': (f'n={n} random circuit, depth {args.depth}, Haar 1q/2q gates, {args.dtype}, no fusion'
+                         if args.workload == 'rqc_1q2q' else f'n={n}, 200 Haar 3q/4q dense gates, {args.dtype}'),
+            'n_qubits': n,
+            'gate_applications_per_step': len(gates),
+            'state_bytes_per_gpu': 2 * (1 << n_local) * ft.itemsize,
+            'parallelism': f'high-qubit shard x{world}' if world > 1 else 'single GPU',
+            'exchanges_per_step': n_exchanges,
+        },
+    }
+
+    if rank == 0 and events is not None:
+        per_class = {}
+        for s in range(args.steps):
+            for (U, qs, pos), (e0, e1) in zip(plan, events[s]):
+                per_class.setdefault(kernel_class(pos, vb), []).append(e0.elapsed_time(e1))
+        total = {c: float(np.sum(v)) for c, v in per_class.items()}
+        dom = max(total, key=total.get)
+        avg_ms = float(np.mean(per_class[dom]))
+        achieved = bytes_per_gate / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom)
+            except Exception:
+                traffic = None
+        result['roofline'] = {
+            'bound': 'hbm',
+            'kernel': dom,
+            'achieved': achieved,
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS,
+            'traffic': traffic,
+            'algorithmic_bytes_per_launch': bytes_per_gate,
+            'avg_launch_ms': avg_ms,
+            'launches': len(per_class[dom]),
+            'per_kernel_avg_ms': {c: float(np.mean(v)) for c, v in sorted(per_class.items())},
+            'per_kernel_launches': {c: len(v) for c, v in sorted(per_class.items())},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result['cpu_baseline'] = cpu_baseline(gates, n, args.cpu_seconds, args.dtype)
+        except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
+            result['cpu_baseline'] = {'value': None, 'unit': 'amplitudes/s', 'cores': 0, 'kind': 'port',
+                                      'sample': f'failed: {e!r}'}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

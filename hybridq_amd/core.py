@@ -1,0 +1,218 @@
+"""ctypes binding of libhq_hip.so -- the counterpart of the reference's L2 layer
+(hybridq/utils/dot.py:26-71, hybridq/utils/transpose.py:25-58 and the loader
+hybridq/utils/utils.py:534-553).
+
+The module-level names mirror the reference so that code written against it reads the
+same: ``_log2_pack_size``, ``_dot_core[float dtype]``, ``_to_complex_core[complex
+dtype]``, ``_swap_core[dtype]``.  Unlike the reference there is NO silent fallback: if
+the HIP library cannot be loaded, importing this module raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'csrc', 'libhq_hip.so')
+
+
+def load_library(path=None):
+    """Load libhq_hip.so.  Search order mirrors hybridq/utils/utils.py:534-553 (bare
+    name first so LD_LIBRARY_PATH wins) after the in-tree build."""
+    cands = [path] if path else [os.environ.get('HQ_HIP_LIBRARY'), _LIB_PATH, 'libhq_hip.so']
+    errors = []
+    for c in cands:
+        if not c:
+            continue
+        try:
+            return ctypes.CDLL(c)
+        except OSError as e:  # keep looking
+            errors.append(f'{c}: {e}')
+    raise ImportError('hybridq_amd: cannot load the HIP core libhq_hip.so (build it with '
+                      '`python -m hybridq_amd.build`). Tried:\n  ' + '\n  '.join(errors))
+
+
+def _define_function(lib, fname, restype, *argtypes):
+    func = getattr(lib, fname)
+    func.argtypes = argtypes
+    func.restype = restype
+    return func
+
+
+_lib = load_library()
+
+_c_types_map = {
+    np.dtype('float32'): ctypes.c_float,
+    np.dtype('float64'): ctypes.c_double,
+    np.dtype('int32'): ctypes.c_int32,
+    np.dtype('int64'): ctypes.c_int64,
+    np.dtype('uint32'): ctypes.c_uint32,
+    np.dtype('uint64'): ctypes.c_uint64,
+}
+
+# --- reference boundary (same shapes as dot.py:49-71 / transpose.py:52-58) ----------
+_get_log2_pack_size = _define_function(_lib, 'get_log2_pack_size', ctypes.c_uint32)
+
+_dot_core = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'apply_U_float{b}', ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint,
+                                            ctypes.c_uint) for b in (32, 64)
+}
+
+_to_complex_core = {
+    np.dtype(f'complex{2 * b}'): _define_function(_lib, f'hq_to_complex{2 * b}', ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_uint64) for b in (32, 64)
+}
+
+_swap_core = {
+    dt: _define_function(_lib, f'swap_{dt.name}', ctypes.c_int, ctypes.c_void_p,
+                         ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint, ctypes.c_uint)
+    for dt in _c_types_map
+}
+
+# --- extensions ------------------------------------------------------------------
+_set_stream = _define_function(_lib, 'hq_set_stream', ctypes.c_int, ctypes.c_void_p)
+_sync = _define_function(_lib, 'hq_sync', ctypes.c_int)
+_last_error = _define_function(_lib, 'hq_last_error', ctypes.c_char_p)
+_last_kernel = _define_function(_lib, 'hq_last_kernel', ctypes.c_char_p)
+_device_count = _define_function(_lib, 'hq_device_count', ctypes.c_int)
+_set_apply_mode = _define_function(_lib, 'hq_set_apply_mode', ctypes.c_int, ctypes.c_char_p)
+_set_log2_pack_size = _define_function(_lib, 'hq_set_log2_pack_size', ctypes.c_int, ctypes.c_uint)
+_init_state = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_init_state_float{b}', ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint,
+                                            ctypes.c_int, ctypes.c_uint64) for b in (32, 64)
+}
+_norm2 = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_norm2_float{b}', ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_uint64,
+                                            ctypes.POINTER(ctypes.c_double)) for b in (32, 64)
+}
+
+#: symbols the C header include/hq_hip.h declares (checked by tests/test_abi.py)
+EXPORTED = [
+    'get_log2_pack_size', 'apply_U_float32', 'apply_U_float64', 'to_complex64', 'to_complex128',
+    'swap_float32', 'swap_float64', 'swap_int32', 'swap_int64', 'swap_uint32', 'swap_uint64',
+    'hq_set_stream', 'hq_sync', 'hq_set_log2_pack_size', 'hq_last_error', 'hq_device_count',
+    'hq_set_apply_mode', 'hq_last_kernel', 'hq_to_complex64', 'hq_to_complex128',
+    'hq_init_state_float32', 'hq_init_state_float64', 'hq_norm2_float32', 'hq_norm2_float64',
+]
+
+
+class HQError(RuntimeError):
+    pass
+
+
+def last_error():
+    return (_last_error() or b'').decode()
+
+
+def last_kernel():
+    return (_last_kernel() or b'').decode()
+
+
+def _check(rc, what):
+    if rc:
+        raise HQError(f'{what} failed: {last_error()}')
+
+
+def log2_pack_size():
+    return int(_get_log2_pack_size())
+
+
+_log2_pack_size = log2_pack_size()
+
+
+def device_count():
+    return int(_device_count())
+
+
+def set_stream(stream_handle):
+    """`stream_handle`: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+    _check(_set_stream(ctypes.c_void_p(int(stream_handle))), 'hq_set_stream')
+
+
+def sync():
+    _check(_sync(), 'hq_sync')
+
+
+def set_apply_mode(name):
+    _check(_set_apply_mode(name.encode()), 'hq_set_apply_mode')
+
+
+def _ptr(x):
+    """Raw address of a numpy array, a torch tensor or an int."""
+    if isinstance(x, int):
+        return x
+    if hasattr(x, 'data_ptr'):
+        return x.data_ptr()
+    if hasattr(x, 'ctypes'):
+        return x.ctypes.data
+    raise TypeError(f'cannot take the address of {type(x)}')
+
+
+def _float_dtype(x):
+    if hasattr(x, 'data_ptr'):  # torch tensor
+        return np.dtype(str(x.dtype).replace('torch.', ''))
+    return np.dtype(x.dtype)
+
+
+def _n_qubits(x):
+    size = x.numel() if hasattr(x, 'numel') else x.size
+    n = int(size).bit_length() - 1
+    if 1 << n != size:
+        raise ValueError('plane size is not a power of two')
+    return n
+
+
+def apply_U(psi_re, psi_im, U, pos, n_qubits=None):
+    """In-place ``apply_U_float{32,64}`` (include/hq_hip.h) on device tensors (torch) or
+    host arrays (numpy).  `U`: 2^k x 2^k complex (row-major), `pos`: k positions with
+    pos[0] <-> LSB of U's index (simulation.py:633)."""
+    ft = _float_dtype(psi_re)
+    ctype = np.dtype('complex64') if ft == np.dtype('float32') else np.dtype('complex128')
+    U = np.ascontiguousarray(U, dtype=ctype)
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    n = _n_qubits(psi_re) if n_qubits is None else int(n_qubits)
+    if U.size != 4**len(pos):
+        raise ValueError("'U' and 'pos' are incompatible")
+    rc = _dot_core[ft](_ptr(psi_re), _ptr(psi_im), U.ctypes.data,
+                       pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n, len(pos))
+    _check(rc, 'apply_U')
+
+
+def swap(array, pos, n_qubits=None):
+    """In-place ``swap_<dtype>``: new[x] = old[(x & ~(2^s-1)) | sum_i x_i << pos[i]]."""
+    dt = _float_dtype(array)
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    n = _n_qubits(array) if n_qubits is None else int(n_qubits)
+    rc = _swap_core[dt](_ptr(array), pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n, len(pos))
+    _check(rc, 'swap')
+
+
+def to_complex(psi_re, psi_im, out):
+    """out[2i] = re[i], out[2i+1] = im[i]; `out` is a complex tensor/array of the same size."""
+    ft = _float_dtype(psi_re)
+    ctype = np.dtype('complex64') if ft == np.dtype('float32') else np.dtype('complex128')
+    size = psi_re.numel() if hasattr(psi_re, 'numel') else psi_re.size
+    rc = _to_complex_core[ctype](_ptr(psi_re), _ptr(psi_im), _ptr(out), size)
+    _check(rc, 'to_complex')
+    return out
+
+
+def init_state(psi_re, psi_im, kind='basis', basis=0):
+    ft = _float_dtype(psi_re)
+    n = _n_qubits(psi_re)
+    rc = _init_state[ft](_ptr(psi_re), _ptr(psi_im), n, {'basis': 0, 'plus': 1}[kind], int(basis))
+    _check(rc, 'init_state')
+
+
+def norm2(psi_re, psi_im):
+    ft = _float_dtype(psi_re)
+    size = psi_re.numel() if hasattr(psi_re, 'numel') else psi_re.size
+    out = ctypes.c_double(0.0)
+    rc = _norm2[ft](_ptr(psi_re), _ptr(psi_im), size, ctypes.byref(out))
+    _check(rc, 'norm2')
+    return out.value

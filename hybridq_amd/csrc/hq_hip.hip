@@ -1,0 +1,617 @@
+// hq_hip.hip -- host side of libhq_hip.so: argument checking, kernel dispatch and the
+// C ABI declared in include/hq_hip.h (the reference boundary of
+// /root/reference/include/python_U.cpp:127-154 and python_swap.cpp:68-99).
+#include "hq_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hq_hip.h"
+
+namespace hq {
+
+// ---------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------
+enum class Mode { Auto, Direct, Generic, Naive };
+
+struct Context {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  unsigned log2_pack = 1;
+  Mode mode = Mode::Auto;
+  bool nontemporal = false;
+  std::string last_error = "";
+  const char* last_kernel = "none";
+  // arena for matrices that do not fit kernel arguments (generic / naive kernels)
+  unsigned char* arena_host = nullptr;  // pinned
+  unsigned char* arena_dev = nullptr;
+  size_t arena_size = 0, arena_used = 0;
+  // scratch (host staging of planes, naive / swap_gather temporaries, norm2)
+  void* scratch[3] = {nullptr, nullptr, nullptr};
+  size_t scratch_size[3] = {0, 0, 0};
+  bool attr_set = false;
+  bool env_read = false;
+};
+
+static Context& ctx() {
+  static Context c;
+  return c;
+}
+
+static int fail(const std::string& msg) {
+  ctx().last_error = msg;
+  return 1;
+}
+
+#define HQ_HIP_CHECK(expr)                                                             \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+  } while (0)
+
+static void read_env(Context& c) {
+  if (c.env_read) return;
+  c.env_read = true;
+  if (const char* e = getenv("HQ_LOG2_PACK_SIZE")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 5) c.log2_pack = (unsigned)v;
+  }
+  if (const char* e = getenv("HQ_APPLY_MODE")) {
+    std::string s(e);
+    if (s == "direct") c.mode = Mode::Direct;
+    else if (s == "generic") c.mode = Mode::Generic;
+    else if (s == "naive") c.mode = Mode::Naive;
+  }
+  if (const char* e = getenv("HQ_NONTEMPORAL")) c.nontemporal = atoi(e) != 0;
+}
+
+static int get_scratch(Context& c, int slot, size_t bytes, void** out) {
+  if (c.scratch_size[slot] < bytes) {
+    if (c.scratch[slot]) {
+      HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+      HQ_HIP_CHECK(hipFree(c.scratch[slot]));
+      c.scratch[slot] = nullptr;
+      c.scratch_size[slot] = 0;
+    }
+    HQ_HIP_CHECK(hipMalloc(&c.scratch[slot], bytes));
+    c.scratch_size[slot] = bytes;
+  }
+  *out = c.scratch[slot];
+  return 0;
+}
+
+// Copy `bytes` of host data into the arena; returns the device address in *dev.  The
+// host copy is taken immediately (the caller's buffer may be a temporary), the H2D
+// transfer is asynchronous on the stream.
+static int arena_upload(Context& c, const void* host, size_t bytes, void** dev) {
+  const size_t kArena = 64u << 20;
+  if (!c.arena_host) {
+    HQ_HIP_CHECK(hipHostMalloc((void**)&c.arena_host, kArena, hipHostMallocDefault));
+    HQ_HIP_CHECK(hipMalloc((void**)&c.arena_dev, kArena));
+    c.arena_size = kArena;
+  }
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (need > c.arena_size) return fail("matrix too large for the upload arena");
+  if (c.arena_used + need > c.arena_size) {
+    HQ_HIP_CHECK(hipStreamSynchronize(c.stream));  // wrap: wait for in-flight users
+    c.arena_used = 0;
+  }
+  memcpy(c.arena_host + c.arena_used, host, bytes);
+  HQ_HIP_CHECK(hipMemcpyAsync(c.arena_dev + c.arena_used, c.arena_host + c.arena_used, bytes,
+                              hipMemcpyHostToDevice, c.stream));
+  *dev = c.arena_dev + c.arena_used;
+  c.arena_used += need;
+  return 0;
+}
+
+// true if `p` can be dereferenced by a kernel
+static bool is_device_pointer(const void* p) {
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // unregistered host memory
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged ||
+         attr.type == hipMemoryTypeUnified;
+}
+
+static int check_positions(const unsigned* pos, unsigned n, unsigned k) {
+  if (k > n || n > 62) return 1;
+  uint64_t seen = 0;
+  for (unsigned i = 0; i < k; ++i) {
+    if (pos[i] >= n) return 1;
+    if (seen & (1ull << pos[i])) return 1;
+    seen |= 1ull << pos[i];
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// apply_U dispatch (device pointers)
+// ---------------------------------------------------------------------------------
+template <typename T, int K, int VMASK>
+static int launch_direct_kv(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n) {
+  constexpr int VB = Vec<T>::VB;
+  constexpr int KV = popc_c(VMASK), KR = K - KV, R = 1 << KR, D = 1 << K;
+  constexpr int ILP = R >= 4 ? 1 : (R == 2 ? 2 : 4);
+  // sort positions ascending, remember which original matrix bit each one is
+  unsigned order[K];
+  for (int j = 0; j < K; ++j) order[j] = j;
+  std::sort(order, order + K, [&](unsigned a, unsigned b) { return pos[a] < pos[b]; });
+  GateArg<T, K> g;
+  for (int t = 0; t < D; ++t) {
+    int to = 0;
+    for (int j = 0; j < K; ++j) to |= ((t >> j) & 1) << order[j];
+    for (int s = 0; s < D; ++s) {
+      int so = 0;
+      for (int j = 0; j < K; ++j) so |= ((s >> j) & 1) << order[j];
+      g.re[t * D + s] = U[2 * (to * D + so)];
+      g.im[t * D + s] = U[2 * (to * D + so) + 1];
+    }
+  }
+  RegPos rp = {{0, 0, 0, 0}};
+  for (int j = 0; j < KR; ++j) rp.p[j] = pos[order[KV + j]] - VB;
+  const uint64_t nslots = 1ull << (n - VB - KR);
+  const uint64_t nblocks = nslots / (ILP * kBlock);
+  if (nblocks == 0 || nblocks > 0x7fffffffull) return fail("direct: grid out of range");
+  if (c.nontemporal)
+    hipLaunchKernelGGL((apply_direct_kernel<T, K, VMASK, ILP, true>), dim3((unsigned)nblocks),
+                       dim3(kBlock), 0, c.stream, re, im, g, rp);
+  else
+    hipLaunchKernelGGL((apply_direct_kernel<T, K, VMASK, ILP, false>), dim3((unsigned)nblocks),
+                       dim3(kBlock), 0, c.stream, re, im, g, rp);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "direct";
+  return 0;
+}
+
+template <typename T, int K>
+static int launch_direct_k(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                           int vmask) {
+  constexpr int VB = Vec<T>::VB;
+  switch (vmask) {
+    case 0: return launch_direct_kv<T, K, 0>(c, re, im, U, pos, n);
+    case 1: return launch_direct_kv<T, K, 1>(c, re, im, U, pos, n);
+    case 2:
+      if constexpr (VB >= 2) return launch_direct_kv<T, K, 2>(c, re, im, U, pos, n);
+      break;
+    case 3:
+      if constexpr (VB >= 2 && K >= 2) return launch_direct_kv<T, K, 3>(c, re, im, U, pos, n);
+      break;
+  }
+  return fail("direct: bad vmask");
+}
+
+// can the direct kernel run this call?
+template <typename T>
+static bool direct_ok(unsigned n, unsigned k, const unsigned* pos) {
+  constexpr int VB = Vec<T>::VB;
+  if (k < 1 || k > 3) return false;
+  unsigned kv = 0;
+  for (unsigned j = 0; j < k; ++j) kv += pos[j] < (unsigned)VB;
+  const unsigned kr = k - kv;
+  const unsigned R = 1u << kr;
+  const unsigned ilp = R >= 4 ? 1 : (R == 2 ? 2 : 4);
+  if (n < VB + kr) return false;
+  const uint64_t nslots = 1ull << (n - VB - kr);
+  return nslots >= (uint64_t)ilp * kBlock;
+}
+
+template <typename T>
+static int launch_direct(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                         unsigned k) {
+  constexpr int VB = Vec<T>::VB;
+  int vmask = 0;
+  for (unsigned j = 0; j < k; ++j)
+    if (pos[j] < (unsigned)VB) vmask |= 1 << pos[j];
+  switch (k) {
+    case 1: return launch_direct_k<T, 1>(c, re, im, U, pos, n, vmask);
+    case 2: return launch_direct_k<T, 2>(c, re, im, U, pos, n, vmask);
+    case 3: return launch_direct_k<T, 3>(c, re, im, U, pos, n, vmask);
+  }
+  return fail("direct: k out of range");
+}
+
+template <typename T>
+static int launch_generic(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                          unsigned k) {
+  GenArg a;
+  memset(&a, 0, sizeof(a));
+  a.k = k;
+  a.c = std::min<unsigned>(n - k, kTileBits - k);
+  uint64_t tmask = 0;
+  for (unsigned j = 0; j < k; ++j) {
+    a.tpos[j] = pos[j];
+    tmask |= 1ull << pos[j];
+  }
+  unsigned nc = 0;
+  for (unsigned p = 0; p < n && nc < a.c; ++p)
+    if (!((tmask >> p) & 1)) a.cpos[nc++] = p;
+  std::vector<unsigned> all(a.tpos, a.tpos + k);
+  all.insert(all.end(), a.cpos, a.cpos + a.c);
+  std::sort(all.begin(), all.end());
+  for (unsigned j = 0; j < k + a.c; ++j) a.apos[j] = all[j];
+  a.vec_ok = (a.cpos[0] == 0 && a.cpos[1] == 1) ? 1u : 0u;
+  const size_t D = (size_t)1 << k, C = (size_t)1 << a.c;
+  void* dU = nullptr;
+  if (arena_upload(c, U, 2 * D * D * sizeof(T), &dU)) return 1;
+  const size_t lds = D * 8 + C * 4 + 2 * D * C * sizeof(T);
+  if (!c.attr_set) {
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_generic_kernel<float>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_generic_kernel<double>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    c.attr_set = true;
+  }
+  const uint64_t nblocks = 1ull << (n - k - a.c);
+  const unsigned grid = (unsigned)std::min<uint64_t>(nblocks, 256 * 16);
+  hipLaunchKernelGGL((apply_generic_kernel<T>), dim3(grid), dim3(kBlock), lds, c.stream, re, im,
+                     (const T*)dU, a, nblocks);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "generic";
+  return 0;
+}
+
+template <typename T>
+static int launch_naive(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                        unsigned k) {
+  NaiveArg a;
+  memset(&a, 0, sizeof(a));
+  a.k = k;
+  for (unsigned j = 0; j < k; ++j) a.tpos[j] = pos[j];
+  const uint64_t size = 1ull << n;
+  const size_t D = (size_t)1 << k;
+  void* dU = nullptr;
+  if (arena_upload(c, U, 2 * D * D * sizeof(T), &dU)) return 1;
+  void* tmp = nullptr;
+  if (get_scratch(c, 2, 2 * size * sizeof(T), &tmp)) return 1;
+  T* tre = (T*)tmp;
+  T* tim = tre + size;
+  HQ_HIP_CHECK(hipMemcpyAsync(tre, re, size * sizeof(T), hipMemcpyDeviceToDevice, c.stream));
+  HQ_HIP_CHECK(hipMemcpyAsync(tim, im, size * sizeof(T), hipMemcpyDeviceToDevice, c.stream));
+  const uint64_t nblocks = (size + kBlock - 1) / kBlock;
+  if (nblocks > 0x7fffffffull) return fail("naive: state too large");
+  hipLaunchKernelGGL((apply_naive_kernel<T>), dim3((unsigned)nblocks), dim3(kBlock), 0, c.stream,
+                     (const T*)tre, (const T*)tim, re, im, (const T*)dU, a, size);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "naive";
+  return 0;
+}
+
+template <typename T>
+static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                        unsigned k) {
+  const bool can_direct = direct_ok<T>(n, k, pos);
+  const bool can_generic = (n - k) >= 2 && k <= kMaxK;
+  switch (c.mode) {
+    case Mode::Direct:
+      if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
+      break;
+    case Mode::Generic:
+      if (can_generic) return launch_generic<T>(c, re, im, U, pos, n, k);
+      break;
+    case Mode::Naive:
+      return launch_naive<T>(c, re, im, U, pos, n, k);
+    case Mode::Auto:
+      break;
+  }
+  if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
+  if (can_generic) return launch_generic<T>(c, re, im, U, pos, n, k);
+  return launch_naive<T>(c, re, im, U, pos, n, k);
+}
+
+template <typename T>
+static int apply_U_entry(T* re, T* im, const T* U, const unsigned* pos, unsigned n, unsigned k) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (k == 0) return 0;  // python_U.cpp:38-39
+  if (!re || !im || !U || !pos) return fail("apply_U: null pointer");
+  if (k > kMaxK) return fail("apply_U: n_pos > 10 is not supported");
+  if (check_positions(pos, n, k)) return fail("apply_U: invalid positions");
+  if ((reinterpret_cast<uintptr_t>(re) % 32) || (reinterpret_cast<uintptr_t>(im) % 32))
+    return fail("apply_U: planes must be 32-byte aligned");  // U.h:34-36
+  const bool dre = is_device_pointer(re), dim_ = is_device_pointer(im);
+  if (dre != dim_) return fail("apply_U: psi_re/psi_im must both be device or both host");
+  if (dre) return apply_device<T>(c, re, im, U, pos, n, k);
+  // host compatibility path: stage -> kernel -> copy back -> sync
+  const size_t bytes = ((size_t)1 << n) * sizeof(T);
+  void* s0 = nullptr;
+  if (get_scratch(c, 0, 2 * bytes, &s0)) return 1;
+  T* dr = (T*)s0;
+  T* di = (T*)((unsigned char*)s0 + bytes);
+  HQ_HIP_CHECK(hipMemcpyAsync(dr, re, bytes, hipMemcpyHostToDevice, c.stream));
+  HQ_HIP_CHECK(hipMemcpyAsync(di, im, bytes, hipMemcpyHostToDevice, c.stream));
+  if (apply_device<T>(c, dr, di, U, pos, n, k)) return 1;
+  HQ_HIP_CHECK(hipMemcpyAsync(re, dr, bytes, hipMemcpyDeviceToHost, c.stream));
+  HQ_HIP_CHECK(hipMemcpyAsync(im, di, bytes, hipMemcpyDeviceToHost, c.stream));
+  HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// swap
+// ---------------------------------------------------------------------------------
+template <typename E>
+static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsigned s) {
+  SwapArg sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.s = s;
+  bool identity = true;
+  for (unsigned i = 0; i < s; ++i) {
+    sa.pos[i] = pos[i];
+    identity &= pos[i] == i;
+  }
+  if (identity) return 0;
+  const unsigned max_lds_bits = sizeof(E) == 4 ? 13 : 12;  // 32 KiB of elements
+  if (s <= max_lds_bits) {
+    const unsigned tile_bits = std::min<unsigned>(n, std::max<unsigned>(s, 11));
+    const uint64_t ntiles = 1ull << (n - tile_bits);
+    const size_t lds = ((((size_t)1 << s) * 2 + 15) & ~(size_t)15) + ((size_t)1 << tile_bits) * sizeof(E);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
+    hipLaunchKernelGGL((swap_lds_kernel<E>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
+                       tile_bits, ntiles);
+    HQ_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  const uint64_t size = 1ull << n;
+  void* tmp = nullptr;
+  if (get_scratch(c, 2, size * sizeof(E), &tmp)) return 1;
+  const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
+  hipLaunchKernelGGL((swap_gather_kernel<E>), dim3(grid), dim3(kBlock), 0, c.stream,
+                     (const E*)a, (E*)tmp, sa, size);
+  HQ_HIP_CHECK(hipGetLastError());
+  HQ_HIP_CHECK(hipMemcpyAsync(a, tmp, size * sizeof(E), hipMemcpyDeviceToDevice, c.stream));
+  return 0;
+}
+
+template <typename E>
+static int swap_entry(E* a, const unsigned* pos, unsigned n, unsigned s) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (s == 0) return 0;  // python_swap.cpp:35-36
+  if (!a || !pos) return fail("swap: null pointer");
+  if (s > n || s > 30 || n > 62) return fail("swap: invalid sizes");
+  uint64_t seen = 0;
+  for (unsigned i = 0; i < s; ++i) {
+    if (pos[i] >= s || (seen >> pos[i]) & 1) return fail("swap: pos is not a permutation of 0..s-1");
+    seen |= 1ull << pos[i];
+  }
+  if (is_device_pointer(a)) return swap_device<E>(c, a, pos, n, s);
+  const size_t bytes = ((size_t)1 << n) * sizeof(E);
+  void* s0 = nullptr;
+  if (get_scratch(c, 0, bytes, &s0)) return 1;
+  HQ_HIP_CHECK(hipMemcpyAsync(s0, a, bytes, hipMemcpyHostToDevice, c.stream));
+  if (swap_device<E>(c, (E*)s0, pos, n, s)) return 1;
+  HQ_HIP_CHECK(hipMemcpyAsync(a, s0, bytes, hipMemcpyDeviceToHost, c.stream));
+  HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// to_complex
+// ---------------------------------------------------------------------------------
+template <typename T>
+static int interleave_device(Context& c, const T* re, const T* im, T* out, uint64_t size) {
+  if (size == 0) return 0;
+  const bool vec = size % 4 == 0 && reinterpret_cast<uintptr_t>(re) % 32 == 0 &&
+                   reinterpret_cast<uintptr_t>(im) % 32 == 0 &&
+                   reinterpret_cast<uintptr_t>(out) % 32 == 0;
+  if (vec) {
+    const uint64_t nq = size / 4;
+    const unsigned grid = (unsigned)std::min<uint64_t>((nq + kBlock - 1) / kBlock, 256 * 32);
+    hipLaunchKernelGGL((interleave4_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, out,
+                       nq);
+  } else {
+    const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
+    hipLaunchKernelGGL((interleave_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, out,
+                       size);
+  }
+  HQ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+static int to_complex_entry(T* re, T* im, T* out, uint64_t size) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (size == 0) return 0;
+  if (!re || !im || !out) return fail("to_complex: null pointer");
+  const bool d_in = is_device_pointer(re);
+  if (d_in != is_device_pointer(im)) return fail("to_complex: mixed host/device planes");
+  const bool d_out = is_device_pointer(out);
+  const size_t bytes = size * sizeof(T);
+  if (d_in && d_out) return interleave_device<T>(c, re, im, out, size);
+  // stage whatever lives on the host
+  const T *sre = re, *sim = im;
+  T* sout = out;
+  if (!d_in) {
+    void* s0 = nullptr;
+    if (get_scratch(c, 0, 2 * bytes, &s0)) return 1;
+    HQ_HIP_CHECK(hipMemcpyAsync(s0, re, bytes, hipMemcpyHostToDevice, c.stream));
+    HQ_HIP_CHECK(hipMemcpyAsync((unsigned char*)s0 + bytes, im, bytes, hipMemcpyHostToDevice, c.stream));
+    sre = (const T*)s0;
+    sim = (const T*)((unsigned char*)s0 + bytes);
+  }
+  if (!d_out) {
+    void* s1 = nullptr;
+    if (get_scratch(c, 1, 2 * bytes, &s1)) return 1;
+    sout = (T*)s1;
+  }
+  if (interleave_device<T>(c, sre, sim, sout, size)) return 1;
+  if (!d_out) {
+    HQ_HIP_CHECK(hipMemcpyAsync(out, sout, 2 * bytes, hipMemcpyDeviceToHost, c.stream));
+    HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+  }
+  return 0;
+}
+
+template <typename T>
+static int init_state_entry(T* re, T* im, unsigned n, int kind, uint64_t basis) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!re || !im || n > 62) return fail("init_state: bad arguments");
+  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("init_state: device pointers only");
+  const uint64_t size = 1ull << n;
+  if (kind == 0 && basis >= size) return fail("init_state: basis out of range");
+  if (kind != 0 && kind != 1) return fail("init_state: unknown kind");
+  const T amp = (T)std::pow(2.0, -0.5 * (double)n);
+  const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
+  hipLaunchKernelGGL((init_state_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, size,
+                     kind, basis, amp);
+  HQ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+static int norm2_entry(const T* re, const T* im, uint64_t size, double* out) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!re || !im || !out) return fail("norm2: null pointer");
+  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("norm2: device pointers only");
+  void* s1 = nullptr;
+  if (get_scratch(c, 1, 256, &s1)) return 1;
+  HQ_HIP_CHECK(hipMemsetAsync(s1, 0, sizeof(double), c.stream));
+  const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 16);
+  hipLaunchKernelGGL((norm2_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, size,
+                     (double*)s1);
+  HQ_HIP_CHECK(hipGetLastError());
+  HQ_HIP_CHECK(hipMemcpyAsync(out, s1, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+}  // namespace hq
+
+// -----------------------------------------------------------------------------------
+// C ABI
+// -----------------------------------------------------------------------------------
+extern "C" {
+
+unsigned int get_log2_pack_size(void) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::read_env(c);
+  return c.log2_pack;
+}
+
+int apply_U_float32(float* psi_re, float* psi_im, const float* U, const unsigned int* pos,
+                    unsigned int n_qubits, unsigned int n_pos) {
+  return hq::apply_U_entry<float>(psi_re, psi_im, U, pos, n_qubits, n_pos);
+}
+int apply_U_float64(double* psi_re, double* psi_im, const double* U, const unsigned int* pos,
+                    unsigned int n_qubits, unsigned int n_pos) {
+  return hq::apply_U_entry<double>(psi_re, psi_im, U, pos, n_qubits, n_pos);
+}
+
+int to_complex64(float* psi_re, float* psi_im, float* psi_out, unsigned int size) {
+  return hq::to_complex_entry<float>(psi_re, psi_im, psi_out, size);
+}
+int to_complex128(double* psi_re, double* psi_im, double* psi_out, unsigned int size) {
+  return hq::to_complex_entry<double>(psi_re, psi_im, psi_out, size);
+}
+int hq_to_complex64(float* psi_re, float* psi_im, float* psi_out, uint64_t size) {
+  return hq::to_complex_entry<float>(psi_re, psi_im, psi_out, size);
+}
+int hq_to_complex128(double* psi_re, double* psi_im, double* psi_out, uint64_t size) {
+  return hq::to_complex_entry<double>(psi_re, psi_im, psi_out, size);
+}
+
+int swap_float32(float* a, const unsigned int* pos, unsigned int n, unsigned int s) {
+  return hq::swap_entry<uint32_t>(reinterpret_cast<uint32_t*>(a), pos, n, s);
+}
+int swap_float64(double* a, const unsigned int* pos, unsigned int n, unsigned int s) {
+  return hq::swap_entry<uint64_t>(reinterpret_cast<uint64_t*>(a), pos, n, s);
+}
+int swap_int32(int* a, const unsigned int* pos, unsigned int n, unsigned int s) {
+  return hq::swap_entry<uint32_t>(reinterpret_cast<uint32_t*>(a), pos, n, s);
+}
+int swap_int64(long* a, const unsigned int* pos, unsigned int n, unsigned int s) {
+  return hq::swap_entry<uint64_t>(reinterpret_cast<uint64_t*>(a), pos, n, s);
+}
+int swap_uint32(unsigned int* a, const unsigned int* pos, unsigned int n, unsigned int s) {
+  return hq::swap_entry<uint32_t>(reinterpret_cast<uint32_t*>(a), pos, n, s);
+}
+int swap_uint64(unsigned long* a, const unsigned int* pos, unsigned int n, unsigned int s) {
+  return hq::swap_entry<uint64_t>(reinterpret_cast<uint64_t*>(a), pos, n, s);
+}
+
+int hq_set_stream(void* hip_stream) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  c.stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return 0;
+}
+
+int hq_sync(void) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hipError_t e = hipStreamSynchronize(c.stream);
+  if (e != hipSuccess) return hq::fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int hq_set_log2_pack_size(unsigned int v) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::read_env(c);
+  if (v < 1 || v > 5) return hq::fail("log2_pack_size must be in 1..5");
+  c.log2_pack = v;
+  return 0;
+}
+
+const char* hq_last_error(void) { return hq::ctx().last_error.c_str(); }
+
+int hq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int hq_set_apply_mode(const char* name) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::read_env(c);
+  std::string s(name ? name : "");
+  if (s == "auto") c.mode = hq::Mode::Auto;
+  else if (s == "direct") c.mode = hq::Mode::Direct;
+  else if (s == "generic") c.mode = hq::Mode::Generic;
+  else if (s == "naive") c.mode = hq::Mode::Naive;
+  else if (s == "nt=1") c.nontemporal = true;
+  else if (s == "nt=0") c.nontemporal = false;
+  else return hq::fail("unknown apply mode: " + s);
+  return 0;
+}
+
+const char* hq_last_kernel(void) { return hq::ctx().last_kernel; }
+
+int hq_init_state_float32(float* re, float* im, unsigned int n, int kind, uint64_t basis) {
+  return hq::init_state_entry<float>(re, im, n, kind, basis);
+}
+int hq_init_state_float64(double* re, double* im, unsigned int n, int kind, uint64_t basis) {
+  return hq::init_state_entry<double>(re, im, n, kind, basis);
+}
+int hq_norm2_float32(const float* re, const float* im, uint64_t size, double* out) {
+  return hq::norm2_entry<float>(re, im, size, out);
+}
+int hq_norm2_float64(const double* re, const double* im, uint64_t size, double* out) {
+  return hq::norm2_entry<double>(re, im, size, out);
+}
+
+}  // extern "C"

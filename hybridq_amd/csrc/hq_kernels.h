@@ -1,0 +1,390 @@
+// hq_kernels.h -- device kernels of the MI355X (gfx950) state-vector evolution core.
+//
+// Semantics implemented (reference: /root/reference/include/U.h:28-102,123-202,
+// include/swap.h:28-95, include/python_U.cpp:114-123), written from the index
+// formula, CDNA4-first:
+//
+//   * apply_direct   k <= 3: pure HBM streaming.  Each lane owns 16-byte vectors
+//                    (index bits 0..1 for f32, bit 0 for f64) and ALL 2^k partner
+//                    vectors of its tile, so the butterfly is register-local: no
+//                    LDS, no cross-lane traffic.  The lane -> address map skips the
+//                    target bits, i.e. a wave's loads are contiguous 1 KiB runs
+//                    whenever the targets sit at positions >= 8, and degrade to
+//                    interleaved 16/32/64-byte pieces of the same cache lines (both
+//                    halves issued back to back by the same wave) for lower targets.
+//                    U lives in SGPRs / the scalar cache (kernel argument).
+//   * apply_generic  any k <= 10: workgroup tile of 2^(k+c) amplitudes staged
+//                    through LDS (c lowest non-target bits = contiguous columns),
+//                    dense complex mat-mat on the tile, results streamed back.
+//   * apply_naive    out-of-place one-thread-per-amplitude fallback for tiny states.
+//   * swap_lds / swap_gather, interleave (to_complex), init_state, norm2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  using type = f32x4;   // 16-byte lane vector
+  using quad = f32x4;   // 4 consecutive elements
+  static constexpr int VB = 2;
+};
+template <> struct Vec<double> {
+  using type = f64x2;
+  using quad = f64x4;
+  static constexpr int VB = 1;
+};
+
+__host__ __device__ constexpr int popc_c(int x) { return x == 0 ? 0 : (x & 1) + popc_c(x >> 1); }
+// gather the bits of v selected by mask into a compact integer
+__host__ __device__ constexpr int pext_c(int v, int mask) {
+  int out = 0, o = 0;
+  for (int b = 0; b < 8; ++b)
+    if ((mask >> b) & 1) { out |= ((v >> b) & 1) << o; ++o; }
+  return out;
+}
+// scatter the low bits of v to the positions selected by mask
+__host__ __device__ constexpr int pdep_c(int v, int mask) {
+  int out = 0, o = 0;
+  for (int b = 0; b < 8; ++b)
+    if ((mask >> b) & 1) { out |= ((v >> o) & 1) << b; ++o; }
+  return out;
+}
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------
+// apply_direct
+// ---------------------------------------------------------------------------------
+template <typename T, int K> struct GateArg {
+  T re[1 << (2 * K)];  // row-major, matrix index bits in ASCENDING position order
+  T im[1 << (2 * K)];
+};
+struct RegPos { unsigned p[4]; };  // register-target positions minus VB, ascending
+
+template <typename T, int K, int VMASK, int ILP, bool NT>
+__global__ void __launch_bounds__(kBlock)
+apply_direct_kernel(T* __restrict__ re, T* __restrict__ im, const GateArg<T, K> U,
+                    const RegPos rp) {
+  using V = typename Vec<T>::type;
+  constexpr int VB = Vec<T>::VB, VE = 1 << VB;
+  constexpr int KV = popc_c(VMASK), KR = K - KV, R = 1 << KR, D = 1 << K;
+  V* __restrict__ vre = reinterpret_cast<V*>(re);
+  V* __restrict__ vim = reinterpret_cast<V*>(im);
+
+  uint64_t off[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int j = 0; j < KR; ++j) o |= (uint64_t)((r >> j) & 1) << rp.p[j];
+    off[r] = o;
+  }
+
+  const uint64_t g0 = (uint64_t)blockIdx.x * (ILP * kBlock) + threadIdx.x;
+  uint64_t vb[ILP];
+  V xr[ILP][R], xi[ILP][R];
+#pragma unroll
+  for (int i = 0; i < ILP; ++i) {
+    uint64_t v = g0 + (uint64_t)i * kBlock;
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+      const uint64_t lo = (1ull << rp.p[j]) - 1;
+      v = ((v & ~lo) << 1) | (v & lo);
+    }
+    vb[i] = v;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (NT) {
+        xr[i][r] = __builtin_nontemporal_load(&vre[v | off[r]]);
+        xi[i][r] = __builtin_nontemporal_load(&vim[v | off[r]]);
+      } else {
+        xr[i][r] = vre[v | off[r]];
+        xi[i][r] = vim[v | off[r]];
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < ILP; ++i) {
+#pragma unroll
+    for (int ro = 0; ro < R; ++ro) {
+      V yr, yi;
+#pragma unroll
+      for (int co = 0; co < VE; ++co) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int to = pext_c(co, VMASK) | (ro << KV);
+        const int cfree = co & ~VMASK;
+        T ar = 0, ai = 0;
+#pragma unroll
+        for (int ti = 0; ti < D; ++ti) {
+          const int ci = pdep_c(ti & ((1 << KV) - 1), VMASK) | cfree;
+          const int ri = ti >> KV;
+          const T ur = U.re[to * D + ti], ui = U.im[to * D + ti];
+          const T pr = xr[i][ri][ci], pi = xi[i][ri][ci];
+          ar = __builtin_fma(ur, pr, ar);
+          ar = __builtin_fma(-ui, pi, ar);
+          ai = __builtin_fma(ur, pi, ai);
+          ai = __builtin_fma(ui, pr, ai);
+        }
+        yr[co] = ar;
+        yi[co] = ai;
+      }
+      if (NT) {
+        __builtin_nontemporal_store(yr, &vre[vb[i] | off[ro]]);
+        __builtin_nontemporal_store(yi, &vim[vb[i] | off[ro]]);
+      } else {
+        vre[vb[i] | off[ro]] = yr;
+        vim[vb[i] | off[ro]] = yi;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// apply_generic (LDS tile)
+// ---------------------------------------------------------------------------------
+constexpr int kMaxK = 10;
+constexpr int kTileBits = 12;
+
+struct GenArg {
+  unsigned k, c;                 // target bits, column bits (c >= 2)
+  unsigned tpos[kMaxK];          // target positions, ORIGINAL order (bit j of matrix index)
+  unsigned cpos[kTileBits];      // column positions ascending (lowest non-target bits)
+  unsigned apos[kTileBits + kMaxK];  // all tile positions ascending
+  unsigned vec_ok;               // cpos[0]==0 && cpos[1]==1: quads contiguous in memory
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+apply_generic_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ U,
+                     const GenArg a, const uint64_t nblocks) {
+  using Q = typename Vec<T>::quad;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned D = 1u << a.k, C = 1u << a.c, CQ = C >> 2;
+  uint64_t* toff = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* coff = reinterpret_cast<uint32_t*>(toff + D);
+  T* xr = reinterpret_cast<T*>(coff + C);
+  T* xi = xr + (size_t)D * C;
+  const unsigned tid = threadIdx.x;
+
+  for (unsigned i = tid; i < D; i += kBlock) {
+    uint64_t o = 0;
+    for (unsigned j = 0; j < a.k; ++j) o |= (uint64_t)((i >> j) & 1u) << a.tpos[j];
+    toff[i] = o;
+  }
+  for (unsigned i = tid; i < C; i += kBlock) {
+    uint32_t o = 0;
+    for (unsigned j = 0; j < a.c; ++j) o |= ((i >> j) & 1u) << a.cpos[j];
+    coff[i] = o;
+  }
+  __syncthreads();
+
+  const unsigned nitems = D * CQ;
+  for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    uint64_t base = b;
+    for (unsigned j = 0; j < a.k + a.c; ++j) {
+      const uint64_t lo = (1ull << a.apos[j]) - 1;
+      base = ((base & ~lo) << 1) | (base & lo);
+    }
+    // stage the tile
+    for (unsigned e = tid; e < nitems; e += kBlock) {
+      const unsigned t = e / CQ, q = e % CQ;
+      const uint64_t idx = base | toff[t];
+      Q vr, vi;
+      if (a.vec_ok) {
+        vr = *reinterpret_cast<const Q*>(re + (idx | coff[4 * q]));
+        vi = *reinterpret_cast<const Q*>(im + (idx | coff[4 * q]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vr[j] = re[idx | coff[4 * q + j]];
+          vi[j] = im[idx | coff[4 * q + j]];
+        }
+      }
+      *reinterpret_cast<Q*>(xr + (size_t)t * C + 4 * q) = vr;
+      *reinterpret_cast<Q*>(xi + (size_t)t * C + 4 * q) = vi;
+    }
+    __syncthreads();
+    // dense complex (D x D) . (D x C)
+    for (unsigned e = tid; e < nitems; e += kBlock) {
+      const unsigned t = e / CQ, q = e % CQ;
+      const T* __restrict__ Urow = U + (size_t)2 * D * t;
+      Q ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+      for (unsigned s = 0; s < D; ++s) {
+        const T ur = Urow[2 * s], ui = Urow[2 * s + 1];
+        const Q pr = *reinterpret_cast<const Q*>(xr + (size_t)s * C + 4 * q);
+        const Q pi = *reinterpret_cast<const Q*>(xi + (size_t)s * C + 4 * q);
+        ar += ur * pr - ui * pi;
+        ai += ur * pi + ui * pr;
+      }
+      const uint64_t idx = base | toff[t];
+      if (a.vec_ok) {
+        *reinterpret_cast<Q*>(re + (idx | coff[4 * q])) = ar;
+        *reinterpret_cast<Q*>(im + (idx | coff[4 * q])) = ai;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          re[idx | coff[4 * q + j]] = ar[j];
+          im[idx | coff[4 * q + j]] = ai[j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// apply_naive: out-of-place, one thread per output amplitude (tiny states only)
+// ---------------------------------------------------------------------------------
+struct NaiveArg {
+  unsigned k;
+  unsigned tpos[kMaxK];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+apply_naive_kernel(const T* __restrict__ in_re, const T* __restrict__ in_im,
+                   T* __restrict__ out_re, T* __restrict__ out_im, const T* __restrict__ U,
+                   const NaiveArg a, const uint64_t size) {
+  const uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (x >= size) return;
+  const unsigned D = 1u << a.k;
+  unsigned t = 0;
+  uint64_t mask = 0;
+  for (unsigned j = 0; j < a.k; ++j) {
+    t |= (unsigned)((x >> a.tpos[j]) & 1u) << j;
+    mask |= 1ull << a.tpos[j];
+  }
+  const uint64_t b = x & ~mask;
+  T ar = 0, ai = 0;
+  for (unsigned s = 0; s < D; ++s) {
+    uint64_t idx = b;
+    for (unsigned j = 0; j < a.k; ++j) idx |= (uint64_t)((s >> j) & 1u) << a.tpos[j];
+    const T ur = U[2 * ((size_t)t * D + s)], ui = U[2 * ((size_t)t * D + s) + 1];
+    const T pr = in_re[idx], pi = in_im[idx];
+    ar += ur * pr - ui * pi;
+    ai += ur * pi + ui * pr;
+  }
+  out_re[x] = ar;
+  out_im[x] = ai;
+}
+
+// ---------------------------------------------------------------------------------
+// swap (low-bit permutation)
+// ---------------------------------------------------------------------------------
+struct SwapArg {
+  unsigned s;
+  unsigned pos[32];
+};
+
+// One workgroup permutes 2^tile_bits contiguous elements (>= one 2^s chunk) through LDS.
+template <typename E>
+__global__ void __launch_bounds__(kBlock)
+swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
+                const uint64_t ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned S = 1u << sa.s, TILE = 1u << tile_bits;
+  uint16_t* src = reinterpret_cast<uint16_t*>(smem);          // S entries
+  E* buf = reinterpret_cast<E*>(smem + (((size_t)S * 2 + 15) & ~(size_t)15));
+  const unsigned tid = threadIdx.x;
+  for (unsigned x = tid; x < S; x += kBlock) {
+    unsigned y = 0;
+    for (unsigned i = 0; i < sa.s; ++i) y |= ((x >> i) & 1u) << sa.pos[i];
+    src[x] = (uint16_t)y;
+  }
+  for (uint64_t tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
+    E* g = a + tb * TILE;
+    __syncthreads();
+    for (unsigned x = tid; x < TILE; x += kBlock) buf[x] = g[x];
+    __syncthreads();
+    for (unsigned x = tid; x < TILE; x += kBlock)
+      g[x] = buf[(x & ~(S - 1)) | src[x & (S - 1)]];
+  }
+}
+
+// Out-of-place gather for large s: out[x] = in[(x & ~(S-1)) | perm(x & (S-1))].
+template <typename E>
+__global__ void __launch_bounds__(kBlock)
+swap_gather_kernel(const E* __restrict__ in, E* __restrict__ out, const SwapArg sa,
+                   const uint64_t size) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const uint64_t S = 1ull << sa.s;
+  for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < size; x += stride) {
+    uint64_t y = x & ~(S - 1);
+    for (unsigned i = 0; i < sa.s; ++i) y |= ((x >> i) & 1ull) << sa.pos[i];
+    out[x] = in[y];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// to_complex, init_state, norm2
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+interleave_kernel(const T* __restrict__ re, const T* __restrict__ im, T* __restrict__ out,
+                  const uint64_t size) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
+    out[2 * i] = re[i];
+    out[2 * i + 1] = im[i];
+  }
+}
+
+// 4 elements per thread, 16-byte accesses; size must be a multiple of 4 and pointers
+// 16/32-byte aligned (checked by the host).
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+interleave4_kernel(const T* __restrict__ re, const T* __restrict__ im, T* __restrict__ out,
+                   const uint64_t nquads) {
+  using Q = typename Vec<T>::quad;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nquads; i += stride) {
+    const Q r = reinterpret_cast<const Q*>(re)[i];
+    const Q m = reinterpret_cast<const Q*>(im)[i];
+    Q o0 = {r[0], m[0], r[1], m[1]};
+    Q o1 = {r[2], m[2], r[3], m[3]};
+    reinterpret_cast<Q*>(out)[2 * i] = o0;
+    reinterpret_cast<Q*>(out)[2 * i + 1] = o1;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+init_state_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t size, const int kind,
+                  const uint64_t basis, const T amp) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
+    re[i] = kind == 1 ? amp : (i == basis ? (T)1 : (T)0);
+    im[i] = 0;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+norm2_kernel(const T* __restrict__ re, const T* __restrict__ im, const uint64_t size,
+             double* __restrict__ out) {
+  __shared__ double part[kBlock / 64];
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  double acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
+    const double r = re[i], m = im[i];
+    acc += r * r + m * m;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int w = 0; w < kBlock / 64; ++w) s += part[w];
+    atomicAdd(out, s);
+  }
+}
+
+}  // namespace hq

@@ -1,0 +1,118 @@
+/*
+ * hq_hip.h -- C ABI of libhq_hip.so, the MI355X (gfx950) state-vector evolution core.
+ *
+ * Part 1 is the drop-in boundary: exactly the symbols the reference's ctypes
+ * bindings look up in hybridq.so / hybridq_swap.so, with the same argument
+ * meaning, in-place semantics and "int, 0 = ok" error convention.
+ * Part 2 are extensions the reference has no counterpart for (stream control,
+ * 64-bit counts, device-side state helpers).
+ *
+ * Pointer kinds.  `psi_re/psi_im/array/psi_out` may be DEVICE pointers (the
+ * normal case: the state lives in HBM; the call enqueues kernels on the
+ * library's stream and returns without synchronising) or HOST pointers
+ * (compatibility path for the unmodified reference Python: the planes are
+ * staged H2D, processed and copied back before the call returns).  The kind is
+ * detected with hipPointerGetAttributes.  `U` and `pos` are always HOST
+ * pointers and are only read during the call (they are Python temporaries in
+ * the reference: hybridq/circuit/simulation/simulation.py:633-644).
+ */
+#ifndef HQ_HIP_H
+#define HQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Part 1 -- reference boundary                                               */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces get_log2_pack_size(), /root/reference/include/python_U.cpp:129
+ * (bound at hybridq/utils/dot.py:49-50).  The caller promises every target
+ * position >= this value (simulation.py:559, dot.py:217-221) and treats 0 as
+ * "library missing" (simulation.py:393-397).  The GPU kernels accept ANY
+ * position, so this returns 1 by default (env HQ_LOG2_PACK_SIZE or
+ * hq_set_log2_pack_size() override it, e.g. 3 to reproduce the reference's
+ * exact call sequence). */
+unsigned int get_log2_pack_size(void);
+
+/* Replace apply_U_float32/64, python_U.cpp:131-143 (bound at dot.py:53-62;
+ * called at simulation.py:640-646 and dot.py:305).  Semantics of
+ * include/U.h:28-102,123-202: for every base index b with all target bits
+ * clear and every row t,  out[b | dep(t)] = sum_s U[t][s] * in[b | dep(s)],
+ * dep(t) = sum_j ((t>>j)&1) << pos[j].  U: row-major 2^k x 2^k, interleaved
+ * (re,im).  pos: k distinct positions < n_qubits in any order.  In place.
+ * Returns 0 on success, 1 on invalid arguments (U.h:34-36,48-54) or a HIP
+ * error.  n_pos == 0 is a no-op returning 0 (python_U.cpp:38-39).  Limits:
+ * n_pos <= 10 (what dot.py:236 allows). */
+int apply_U_float32(float *psi_re, float *psi_im, const float *U, const unsigned int *pos,
+                    unsigned int n_qubits, unsigned int n_pos);
+int apply_U_float64(double *psi_re, double *psi_im, const double *U, const unsigned int *pos,
+                    unsigned int n_qubits, unsigned int n_pos);
+
+/* Replace to_complex64/128, python_U.cpp:145-153 (bound at dot.py:64-71;
+ * called at simulation.py:671-674, dot.py:111): out[2i]=re[i], out[2i+1]=im[i]. */
+int to_complex64(float *psi_re, float *psi_im, float *psi_out, unsigned int size);
+int to_complex128(double *psi_re, double *psi_im, double *psi_out, unsigned int size);
+
+/* Replace swap_{float,int,uint}{32,64}, /root/reference/include/python_swap.cpp:70-98
+ * (bound at hybridq/utils/transpose.py:52-58; called at simulation.py:623-630,
+ * 658-663, dot.py:291-317, transpose.py:148).  Semantics of include/swap.h:28-95:
+ * new[x] = old[(x & ~(2^s-1)) | sum_i ((x>>i)&1) << pos[i]], s = n_pos; pos must
+ * be a permutation of 0..s-1 (the reference does not check; we return 1). */
+int swap_float32(float *array, const unsigned int *pos, unsigned int n_qubits, unsigned int n_pos);
+int swap_float64(double *array, const unsigned int *pos, unsigned int n_qubits, unsigned int n_pos);
+int swap_int32(int *array, const unsigned int *pos, unsigned int n_qubits, unsigned int n_pos);
+int swap_int64(long *array, const unsigned int *pos, unsigned int n_qubits, unsigned int n_pos);
+int swap_uint32(unsigned int *array, const unsigned int *pos, unsigned int n_qubits,
+                unsigned int n_pos);
+int swap_uint64(unsigned long *array, const unsigned int *pos, unsigned int n_qubits,
+                unsigned int n_pos);
+
+/* ------------------------------------------------------------------------- */
+/* Part 2 -- extensions (no reference counterpart)                            */
+/* ------------------------------------------------------------------------- */
+
+/* HIP stream (hipStream_t as void*) that device-pointer calls enqueue on.
+ * Default: the null stream.  Pass torch.cuda.current_stream().cuda_stream to
+ * order the kernels with torch / RCCL work. */
+int hq_set_stream(void *hip_stream);
+/* hipStreamSynchronize on the library's stream. */
+int hq_sync(void);
+/* What get_log2_pack_size() reports (must be >= 1). */
+int hq_set_log2_pack_size(unsigned int v);
+/* Last error message of this library (never NULL). */
+const char *hq_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime failure). */
+int hq_device_count(void);
+/* Kernel variant selection for A/B measurements: name in
+ * {"auto","direct","generic","naive"}; returns 1 for an unknown name. */
+int hq_set_apply_mode(const char *name);
+/* Name of the kernel family the last apply_U call dispatched to. */
+const char *hq_last_kernel(void);
+
+/* 64-bit-count variants (the reference's `unsigned int size` overflows at
+ * n = 32, python_U.cpp:116,145,150). */
+int hq_to_complex64(float *psi_re, float *psi_im, float *psi_out, uint64_t size);
+int hq_to_complex128(double *psi_re, double *psi_im, double *psi_out, uint64_t size);
+
+/* Device-side initial states (counterpart of prepare_state,
+ * hybridq/circuit/simulation/utils.py:106-113): kind 0 -> |basis> (re[basis]=1),
+ * kind 1 -> uniform |+...+> (re[i] = 2^{-n/2}).  Device pointers only. */
+int hq_init_state_float32(float *psi_re, float *psi_im, unsigned int n_qubits, int kind,
+                          uint64_t basis);
+int hq_init_state_float64(double *psi_re, double *psi_im, unsigned int n_qubits, int kind,
+                          uint64_t basis);
+
+/* sum_i re[i]^2 + im[i]^2 accumulated in double, written to *out (host).
+ * Synchronises the stream.  Device pointers only. */
+int hq_norm2_float32(const float *psi_re, const float *psi_im, uint64_t size, double *out);
+int hq_norm2_float64(const double *psi_re, const double *psi_im, uint64_t size, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HQ_HIP_H */

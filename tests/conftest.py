@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def oracle_port():
+    import subprocess
+    import oracle
+    if not os.path.exists(os.path.join(ROOT, 'oracle', 'libhq_oracle.so')):
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'port'])
+    return oracle.load_port()
+
+
+@pytest.fixture(scope='session')
+def oracle_ref():
+    import oracle
+    if not oracle.have_ref():
+        pytest.skip('oracle/_ref not built (needs /root/reference at build time)')
+    return oracle.load_ref()
+
+
+@pytest.fixture(scope='session')
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail('GPU test selected but no HIP device is visible')
+    return torch

@@ -1,0 +1,77 @@
+"""Full-size (BASELINE.json n=30, complex64) checks through size-independent properties:
+the oracle cannot run 2^30 amplitudes in seconds, so at this size we use
+  * norm preservation under Haar-random unitaries,
+  * U followed by U^dagger restores the state (round trip) on a non-trivial state,
+  * agreement between two independent kernel families (direct vs LDS-tile generic) on
+    the same inputs, checked through a strided sample + the norm.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = 30
+
+
+def _sample(planes, idx):
+    return planes[:, idx].double().cpu().numpy()
+
+
+def test_full_size_roundtrip_and_norm(torch_cuda):
+    torch = torch_cuda
+    from hybridq_amd import core
+    from hybridq_amd.circuits import haar_unitary
+    free, _ = torch.cuda.mem_get_info()
+    n = N_FULL if free > 3 * 8 * (1 << N_FULL) else 26
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(30)
+    planes = torch.empty((2, 1 << n), dtype=torch.float32, device='cuda')
+    core.init_state(planes[0], planes[1], 'plus')
+    # spread amplitude everywhere with one layer of Haar 1q gates on every position
+    for p in range(n):
+        core.apply_U(planes[0], planes[1], haar_unitary(2, rng), [p])
+    assert abs(core.norm2(planes[0], planes[1]) - 1.0) < 1e-4
+    idx = torch.from_numpy(rng.integers(0, 1 << n, 1 << 16)).cuda()
+    before = _sample(planes, idx)
+    cases = [[0], [1], [4], [n - 1], [0, 1], [1, n - 1], [3, 7], [12, 20], [n - 2, n - 1],
+             [0, 5, 17], [2, 3, 4], [10, 20, n - 1], [1, 6, 11, 21], [n - 4, n - 3, n - 2, n - 1],
+             [0, 8, 16, 24, n - 1]]
+    for pos in cases:
+        U = haar_unitary(1 << len(pos), rng)
+        core.apply_U(planes[0], planes[1], U, pos)
+        mid = _sample(planes, idx)
+        assert np.abs(mid - before).max() > 1e-7  # the gate did something
+        core.apply_U(planes[0], planes[1], U.conj().T, pos)
+        after = _sample(planes, idx)
+        err = np.abs(after - before).max() / np.abs(before).max()
+        assert err < 2e-6, (pos, err)
+    assert abs(core.norm2(planes[0], planes[1]) - 1.0) < 1e-4
+
+
+def test_full_size_direct_vs_generic(torch_cuda):
+    torch = torch_cuda
+    from hybridq_amd import core
+    from hybridq_amd.circuits import haar_unitary
+    free, _ = torch.cuda.mem_get_info()
+    n = N_FULL if free > 5 * 8 * (1 << N_FULL) else 26
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(31)
+    a = torch.empty((2, 1 << n), dtype=torch.float32, device='cuda')
+    core.init_state(a[0], a[1], 'plus')
+    for p in range(0, n, 3):
+        core.apply_U(a[0], a[1], haar_unitary(2, rng), [p])
+    b = a.clone()
+    idx = torch.from_numpy(rng.integers(0, 1 << n, 1 << 16)).cuda()
+    for pos in ([2], [0, n - 1], [5, 9], [1, 13, 27]):
+        U = haar_unitary(1 << len(pos), rng)
+        core.set_apply_mode('direct')
+        core.apply_U(a[0], a[1], U, pos)
+        assert core.last_kernel() == 'direct'
+        core.set_apply_mode('generic')
+        core.apply_U(b[0], b[1], U, pos)
+        assert core.last_kernel() == 'generic'
+        core.set_apply_mode('auto')
+        sa, sb = _sample(a, idx), _sample(b, idx)
+        assert np.abs(sa - sb).max() / np.abs(sa).max() < 1e-6, pos
+    core.set_apply_mode('auto')
+    assert abs(core.norm2(a[0], a[1]) - core.norm2(b[0], b[1])) < 1e-5

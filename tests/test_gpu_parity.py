@@ -1,0 +1,268 @@
+"""GPU parity tests: the HIP library (through its C ABI) against the CPU oracle on the
+same seeded inputs.  Bars (BASELINE.json north_star): max|d|/max|psi| <= 1e-6 for
+complex64, <= 1e-12 for complex128; swaps and to_complex are bit-exact.
+
+Mirrors the reference's own differential tests: tests.py:299-391 (dot: k=2..6, random
+NON-unitary U, random axes), :256-296 (transpose/swap, exact equality, six dtypes),
+:122-149 (to_complex)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.dtype('float32'): 1e-6, np.dtype('float64'): 1e-12}
+
+
+def _rand_state(rng, n, ft):
+    re = rng.standard_normal(1 << n).astype(ft)
+    im = rng.standard_normal(1 << n).astype(ft)
+    return re, im
+
+
+def _rand_U(rng, k):
+    d = 1 << k
+    return (rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) / np.sqrt(2.0 * d)
+
+
+def _oracle_apply(lib, re, im, U, pos):
+    from oracle.binding import aligned_empty
+    pl = aligned_empty((2, re.size), re.dtype)
+    pl[0], pl[1] = re, im
+    assert lib.apply_U(pl[0], pl[1], U, pos) == 0
+    return pl[0].copy(), pl[1].copy()
+
+
+def _gpu_apply(torch, re, im, U, pos, mode='auto'):
+    from hybridq_amd import core
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    core.set_apply_mode(mode)
+    try:
+        planes = torch.from_numpy(np.stack([re, im])).cuda()
+        core.apply_U(planes[0], planes[1], U, pos)
+        core.sync()
+        kern = core.last_kernel()
+        out = planes.cpu().numpy()
+    finally:
+        core.set_apply_mode('auto')
+    return out[0], out[1], kern
+
+
+def _relerr(gr, gi, orr, oi):
+    scale = max(np.abs(orr).max(), np.abs(oi).max())
+    return max(np.abs(gr - orr).max(), np.abs(gi - oi).max()) / scale
+
+
+# positions chosen to hit: in-vector targets (0,1), wave-lane bits (2..7), block bits,
+# high bits, unsorted orders, adjacent and spread targets
+POS_CASES = {
+    1: [[0], [1], [2], [3], [5], [7], [8], [11], [17]],
+    2: [[0, 1], [1, 0], [0, 5], [9, 1], [2, 3], [4, 12], [12, 4], [16, 17], [17, 8], [6, 7]],
+    3: [[0, 1, 2], [2, 1, 0], [0, 7, 13], [1, 2, 17], [3, 4, 5], [15, 9, 11], [17, 16, 15], [1, 0, 9]],
+    4: [[0, 1, 2, 3], [5, 6, 7, 8], [7, 6, 8, 11], [0, 9, 13, 17], [14, 15, 16, 17], [1, 12, 3, 16]],
+    5: [[0, 1, 2, 3, 4], [3, 8, 9, 12, 17], [17, 2, 11, 5, 9]],
+    6: [[1, 3, 5, 7, 9, 11], [12, 13, 14, 15, 16, 17]],
+}
+
+
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+@pytest.mark.parametrize('k', [1, 2, 3, 4, 5, 6])
+def test_apply_U_matches_oracle(torch_cuda, oracle_port, ft, k):
+    ft = np.dtype(ft)
+    n = 18
+    rng = np.random.default_rng(1000 + k)
+    for pos in POS_CASES[k]:
+        re, im = _rand_state(rng, n, ft)
+        U = _rand_U(rng, k)
+        orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+        gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
+        err = _relerr(gr, gi, orr, oi)
+        assert err <= TOL[ft], (ft, k, pos, kern, err)
+        if k <= 3:
+            assert kern == 'direct', kern
+
+
+@pytest.mark.parametrize('mode', ['generic', 'naive'])
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+def test_apply_U_alternative_kernels(torch_cuda, oracle_port, ft, mode):
+    ft = np.dtype(ft)
+    n = 14
+    rng = np.random.default_rng(7)
+    for k in (1, 2, 3, 4, 5, 7):
+        for trial in range(3):
+            pos = rng.permutation(n)[:k]
+            re, im = _rand_state(rng, n, ft)
+            U = _rand_U(rng, k)
+            orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+            gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos, mode=mode)
+            assert kern == mode
+            assert _relerr(gr, gi, orr, oi) <= TOL[ft], (k, list(pos))
+
+
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+def test_apply_U_small_and_edge_sizes(torch_cuda, oracle_port, ft):
+    """Ragged / tiny states: every n from 1, k up to n (full-state matrix), k = 0 no-op."""
+    ft = np.dtype(ft)
+    rng = np.random.default_rng(11)
+    for n in range(1, 13):
+        for k in range(1, min(n, 6) + 1):
+            pos = rng.permutation(n)[:k]
+            re, im = _rand_state(rng, n, ft)
+            U = _rand_U(rng, k)
+            orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+            gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
+            assert _relerr(gr, gi, orr, oi) <= TOL[ft], (n, k, list(pos), kern)
+    # k = 0: no-op, returns 0 (python_U.cpp:38-39)
+    re, im = _rand_state(rng, 8, ft)
+    gr, gi, _ = _gpu_apply(torch_cuda, re, im, np.ones((1, 1)), [])
+    assert (gr == re).all() and (gi == im).all()
+
+
+def test_apply_U_large_k(torch_cuda, oracle_port):
+    """k = 8 (simulate(compress=8), tests.py:2355) and k = 10 (dot.py:236 cap)."""
+    rng = np.random.default_rng(5)
+    for ft, n, k in (('float32', 16, 8), ('float64', 14, 8), ('float32', 14, 10)):
+        ft = np.dtype(ft)
+        pos = rng.permutation(n)[:k]
+        re, im = _rand_state(rng, n, ft)
+        U = _rand_U(rng, k)
+        orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+        gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
+        assert _relerr(gr, gi, orr, oi) <= 4 * TOL[ft], (k, kern)
+
+
+def test_apply_U_error_codes(torch_cuda):
+    import ctypes
+    from hybridq_amd import core
+    torch = torch_cuda
+    planes = torch.zeros((2, 1 << 10), dtype=torch.float32, device='cuda')
+    U = np.eye(2, dtype=np.complex64)
+
+    def call(pos, n=10, re=planes[0], im=planes[1]):
+        pos = np.asarray(pos, dtype=np.uint32)
+        return core._dot_core[np.dtype('float32')](core._ptr(re), core._ptr(im), U.ctypes.data,
+                                                   pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                   n, len(pos))
+
+    assert call([3]) == 0
+    assert call([10]) != 0  # position out of range
+    assert call([3, 3]) != 0  # duplicate positions
+    assert call([3], re=planes[0][1:]) != 0  # misaligned plane (U.h:34-36)
+    assert 'aligned' in core.last_error()
+    with pytest.raises(core.HQError):
+        core.apply_U(planes[0], planes[1], np.eye(2), [12])
+
+
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+def test_apply_U_host_pointer_path(torch_cuda, oracle_port, ft):
+    """Host numpy planes (what the unmodified reference Python passes) are staged."""
+    from hybridq_amd import core
+    from oracle.binding import aligned_empty
+    ft = np.dtype(ft)
+    rng = np.random.default_rng(3)
+    n = 15
+    for k in (1, 2, 4, 5):
+        pos = rng.permutation(n)[:k]
+        re, im = _rand_state(rng, n, ft)
+        U = _rand_U(rng, k)
+        orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+        pl = aligned_empty((2, 1 << n), ft, alignment=64)
+        pl[0], pl[1] = re, im
+        core.apply_U(pl[0], pl[1], U, pos)
+        assert _relerr(pl[0], pl[1], orr, oi) <= TOL[ft]
+
+
+@pytest.mark.parametrize('dt', ['float32', 'float64', 'int32', 'int64', 'uint32', 'uint64'])
+def test_swap_exact(torch_cuda, oracle_port, dt):
+    """tests.py:256-296: exact equality for all six dtypes; s from 1 to n (LDS path and the
+    out-of-place gather path), device and host pointers."""
+    from hybridq_amd import core
+    import oracle
+    torch = torch_cuda
+    dt = np.dtype(dt)
+    rng = np.random.default_rng(17)
+    n = 16
+    for s in (1, 2, 3, 5, 6, 8, 9, 11, 12, 13, 14, 16):
+        a = rng.integers(0, 2**31 - 1, 1 << n).astype(dt)
+        pos = rng.permutation(s)
+        exp = oracle.swap_numpy(a, pos)
+        tdt = getattr(torch, dt.name) if dt.name not in ('uint32', 'uint64') else None
+        if tdt is not None:
+            t = torch.from_numpy(a.copy()).cuda()
+            core.swap(t, pos)
+            core.sync()
+            assert (t.cpu().numpy() == exp).all(), (dt, s)
+        h = a.copy()
+        core.swap(h, pos)  # host path
+        assert (h == exp).all(), (dt, s, 'host')
+    # against numpy.transpose, the reference's own check
+    s = 6
+    a = rng.integers(0, 1000, 1 << n).astype(dt)
+    pos = rng.permutation(s)
+    h = a.copy()
+    core.swap(h, pos)
+    tr = np.transpose(a.reshape((2,) * n),
+                      list(range(n - s)) + [n - 1 - int(pos[i]) for i in reversed(range(s))])
+    assert (h == tr.reshape(-1)).all()
+
+
+def test_swap_rejects_non_permutation(torch_cuda):
+    import ctypes
+    from hybridq_amd import core
+    a = np.zeros(1 << 8, dtype=np.float32)
+    pos = np.asarray([0, 0, 1], dtype=np.uint32)
+    rc = core._swap_core[np.dtype('float32')](a.ctypes.data, pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 8, 3)
+    assert rc != 0
+
+
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+def test_to_complex_exact(torch_cuda, ft):
+    from hybridq_amd import core
+    torch = torch_cuda
+    ft = np.dtype(ft)
+    ct = np.dtype('complex64') if ft == np.dtype('float32') else np.dtype('complex128')
+    rng = np.random.default_rng(2)
+    for size in (1 << 12, 1 << 17, 1000, 7):
+        re = rng.standard_normal(size).astype(ft)
+        im = rng.standard_normal(size).astype(ft)
+        out = np.empty(size, dtype=ct)
+        core.to_complex(re, im, out)  # host path
+        assert (out == re + 1j * im).all()
+        dre, dim_ = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+        dout = torch.empty(size, dtype=getattr(torch, ct.name), device='cuda')
+        core.to_complex(dre, dim_, dout)
+        core.sync()
+        assert (dout.cpu().numpy() == re + 1j * im).all()
+
+
+@pytest.mark.parametrize('ct', ['complex64', 'complex128'])
+def test_simulate_matches_reference_protocol(torch_cuda, oracle_port, ct):
+    """End to end: hybridq_amd.simulate (no swaps, state in HBM) == the reference driver
+    protocol (swap policy + apply_U, simulation.py:491-675) replayed on the CPU oracle."""
+    import oracle
+    from hybridq_amd.simulation import simulate
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    n = 16
+    for gates in (random_dense(n, 80, kmax=4, seed=1), rqc_1q2q(n, depth=8, seed=2)):
+        exp, _ = oracle.evolve_reference_protocol(oracle_port, gates, n, complex_type=ct)
+        psi, info = simulate(gates, initial_state='0' * n, complex_type=ct, return_info=True,
+                             qubits=list(range(n)))
+        psi = psi.reshape(-1)
+        tol = 1e-6 if ct == 'complex64' else 1e-12
+        assert np.abs(psi - exp).max() / np.abs(exp).max() <= tol
+        assert info['runtime (s)'] > 0
+
+
+def test_simulate_initial_states(torch_cuda):
+    from hybridq_amd.simulation import simulate
+    n = 12
+    psi = simulate([(np.eye(2), (q,)) for q in range(n)], initial_state='+' * n)
+    assert np.allclose(psi, 2**(-n / 2))
+    s = '0110' * 3
+    psi = simulate([(np.eye(2), (q,)) for q in range(n)], initial_state=s).reshape(-1)
+    assert psi[int(s, 2)] == 1 and np.abs(psi).sum() == 1
+    psi = simulate([(np.eye(2), (q,)) for q in range(n)], initial_state='+-01' * 3).reshape(-1)
+    exp = np.ones(1)
+    single = {'0': [1, 0], '1': [0, 1], '+': [2**-0.5, 2**-0.5], '-': [2**-0.5, -2**-0.5]}
+    for c in '+-01' * 3:
+        exp = np.kron(exp, single[c])
+    assert np.allclose(psi, exp, atol=1e-6)
