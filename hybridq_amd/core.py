@@ -19,6 +19,14 @@ _LIB_PATH = os.path.join(_HERE, 'csrc', 'libhq_hip.so')
 def load_library(path=None):
     """Load libhq_hip.so.  Search order mirrors hybridq/utils/utils.py:534-553 (bare
     name first so LD_LIBRARY_PATH wins) after the in-tree build."""
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64/libhsa-runtime64.
+    # Importing torch FIRST makes the dynamic linker resolve this library's libamdhip64.so.7
+    # dependency to the copy torch already mapped; loading ours first would put a second
+    # runtime (/opt/rocm) in the process that cannot see torch's allocations.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # standalone use through ctypes (host-pointer path) is still valid
+        pass
     cands = [path] if path else [os.environ.get('HQ_HIP_LIBRARY'), _LIB_PATH, 'libhq_hip.so']
     errors = []
     for c in cands:

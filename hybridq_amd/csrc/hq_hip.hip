@@ -615,3 +615,15 @@ int hq_norm2_float64(const double* re, const double* im, uint64_t size, double* 
 }
 
 }  // extern "C"
+
+// Diagnostics (not part of the reference boundary): raw hipPointerGetAttributes result.
+extern "C" int hq_pointer_info(const void* p, int* type, int* device, int* err) {
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (err) *err = (int)e;
+  if (e != hipSuccess) (void)hipGetLastError();
+  if (type) *type = (int)attr.type;
+  if (device) *device = attr.device;
+  return e == hipSuccess ? 0 : 1;
+}

@@ -37,11 +37,13 @@ def _gpu_apply(torch, re, im, U, pos, mode='auto'):
     core.set_stream(torch.cuda.current_stream().cuda_stream)
     core.set_apply_mode(mode)
     try:
-        planes = torch.from_numpy(np.stack([re, im])).cuda()
-        core.apply_U(planes[0], planes[1], U, pos)
+        # separate allocations: for tiny n a stacked (2, 2^n) tensor would leave the
+        # imaginary plane short of the 32-byte alignment the ABI requires (U.h:34-36)
+        dre, dim_ = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+        core.apply_U(dre, dim_, U, pos)
         core.sync()
         kern = core.last_kernel()
-        out = planes.cpu().numpy()
+        out = dre.cpu().numpy(), dim_.cpu().numpy()
     finally:
         core.set_apply_mode('auto')
     return out[0], out[1], kern
