@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/hq_hip.h"
@@ -19,14 +20,14 @@ namespace hq {
 // ---------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------
-enum class Mode { Auto, Direct, Generic, Naive };
+enum class Mode { Auto, Direct, Mfma, Generic, Naive };
 
 struct Context {
   std::mutex mu;
   hipStream_t stream = nullptr;
   unsigned log2_pack = 1;
   Mode mode = Mode::Auto;
-  bool nontemporal = false;
+  int nontemporal = -1;  // -1 auto, 0 never, 1 always
   std::string last_error = "";
   const char* last_kernel = "none";
   // arena for matrices that do not fit kernel arguments (generic / naive kernels)
@@ -67,10 +68,11 @@ static void read_env(Context& c) {
   if (const char* e = getenv("HQ_APPLY_MODE")) {
     std::string s(e);
     if (s == "direct") c.mode = Mode::Direct;
+    else if (s == "mfma") c.mode = Mode::Mfma;
     else if (s == "generic") c.mode = Mode::Generic;
     else if (s == "naive") c.mode = Mode::Naive;
   }
-  if (const char* e = getenv("HQ_NONTEMPORAL")) c.nontemporal = atoi(e) != 0;
+  if (const char* e = getenv("HQ_NONTEMPORAL")) c.nontemporal = atoi(e) < 0 ? -1 : (atoi(e) != 0);
 }
 
 static int get_scratch(Context& c, int slot, size_t bytes, void** out) {
@@ -163,7 +165,16 @@ static int launch_direct_kv(Context& c, T* re, T* im, const T* U, const unsigned
   const uint64_t nslots = 1ull << (n - VB - KR);
   const uint64_t nblocks = nslots / (ILP * kBlock);
   if (nblocks == 0 || nblocks > 0x7fffffffull) return fail("direct: grid out of range");
-  if (c.nontemporal)
+  // Non-temporal loads/stores: +7..10 % when every wave-level access is a contiguous run of
+  // >= 512 B (all register targets at positions >= 7: measured 5.9 vs 5.5 TB/s at n=30),
+  // but they bypass the cache-line merging that low targets rely on (pos 2: 2.7 vs 5.3
+  // TB/s), so they are used only for high targets unless forced.
+  bool nt = c.nontemporal > 0;
+  if (c.nontemporal < 0) {
+    nt = true;
+    for (int j = 0; j < KR; ++j) nt = nt && (rp.p[j] + VB >= 7);
+  }
+  if (nt)
     hipLaunchKernelGGL((apply_direct_kernel<T, K, VMASK, ILP, true>), dim3((unsigned)nblocks),
                        dim3(kBlock), 0, c.stream, re, im, g, rp);
   else
@@ -219,6 +230,185 @@ static int launch_direct(Context& c, T* re, T* im, const T* U, const unsigned* p
     case 3: return launch_direct_k<T, 3>(c, re, im, U, pos, n, vmask);
   }
   return fail("direct: k out of range");
+}
+
+// U (interleaved, original bit order) -> planar re[D*D], im[D*D] with the matrix index
+// bits re-ordered to ASCENDING target position; `sorted` receives the positions.
+template <typename T>
+static void sort_gate(const T* U, const unsigned* pos, unsigned k, std::vector<T>& out,
+                      unsigned* sorted) {
+  const unsigned D = 1u << k;
+  unsigned order[kMaxK];
+  for (unsigned j = 0; j < k; ++j) order[j] = j;
+  std::sort(order, order + k, [&](unsigned a, unsigned b) { return pos[a] < pos[b]; });
+  for (unsigned j = 0; j < k; ++j) sorted[j] = pos[order[j]];
+  out.resize((size_t)2 * D * D);
+  for (unsigned t = 0; t < D; ++t) {
+    unsigned to = 0;
+    for (unsigned j = 0; j < k; ++j) to |= ((t >> j) & 1u) << order[j];
+    for (unsigned s = 0; s < D; ++s) {
+      unsigned so = 0;
+      for (unsigned j = 0; j < k; ++j) so |= ((s >> j) & 1u) << order[j];
+      out[(size_t)t * D + s] = U[2 * ((size_t)to * D + so)];
+      out[(size_t)D * D + (size_t)t * D + s] = U[2 * ((size_t)to * D + so) + 1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// matrix-core path (f32, k <= 4): role assignment + A-operand table (see hq_kernels.h)
+// ---------------------------------------------------------------------------------
+struct MfmaPlan {
+  int kbits = 0, vmask = 0, ilp = 1;
+  bool nt = false;
+  unsigned n_addr = 0;
+  MfmaRoles ro;
+  std::vector<float> A;
+};
+
+static bool plan_mfma(const Context& c, const float* U, const unsigned* pos, unsigned n, unsigned k,
+                      MfmaPlan& P) {
+  if (k < 1 || k > 4) return false;
+  std::vector<float> Us;
+  unsigned sp[kMaxK];
+  sort_gate<float>(U, pos, k, Us, sp);
+  const unsigned D = 1u << k;
+  const float* Ur = Us.data();
+  const float* Ui = Us.data() + (size_t)D * D;
+  const unsigned k_eff = k <= 3 ? 3 : 4;
+  P.kbits = (int)k_eff + 1;
+  // effective digits: real targets (tbit = sorted target index) + identity dummies (tbit = -1)
+  struct Digit { unsigned pos; int tbit; };
+  std::vector<Digit> E;
+  uint64_t used = 0;
+  for (unsigned j = 0; j < k; ++j) { E.push_back({sp[j], (int)j}); used |= 1ull << sp[j]; }
+  for (unsigned p = 0; p < n && E.size() < k_eff; ++p)  // free vector components first, then low bits
+    if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
+  if (E.size() < k_eff) return false;
+  std::sort(E.begin(), E.end(), [](const Digit& a, const Digit& b) { return a.pos < b.pos; });
+  int vmask = 0;
+  std::vector<int> comp_digit, addr_digit;  // indices into E
+  for (unsigned e = 0; e < k_eff; ++e) {
+    if (E[e].pos < 2) { vmask |= 1 << E[e].pos; comp_digit.push_back((int)e); }
+    else addr_digit.push_back((int)e);
+  }
+  P.vmask = vmask;
+  const int KV = (int)comp_digit.size(), NS = P.kbits - 2, NR = NS - KV, NL = 1 << NR;
+  const unsigned na = (unsigned)addr_digit.size();
+  if (na < 1 || na > 4) return false;
+  P.n_addr = na;
+  P.ilp = std::max(1, 8 / NL);
+  if (n < 2 + na) return false;
+  const uint64_t nslots = 1ull << (n - 2 - na);
+  if (nslots < (uint64_t)P.ilp * 64) return false;
+  // roles: -1 = plane, otherwise index into E.  q gets the low address digits first
+  // (positions 2..5: a permutation of a contiguous run), then the plane, then the rest.
+  constexpr int PLANE = -1;
+  std::vector<int> order;
+  for (int e : addr_digit) if (E[e].pos - 2 <= 3) order.push_back(e);
+  order.push_back(PLANE);
+  for (int e : addr_digit) if (E[e].pos - 2 > 3) order.push_back(e);
+  const int qd[2] = {order[0], order[1]};
+  std::vector<int> rd(order.begin() + 2, order.end());  // NR reg digits
+  if ((int)rd.size() != NR) return false;
+  MfmaRoles& ro = P.ro;
+  for (int m = 0; m < 4; ++m) ro.pos[m] = 63;
+  for (unsigned m = 0; m < na; ++m) ro.pos[m] = E[addr_digit[m]].pos - 2;
+  ro.q_plane = -1;
+  ro.r_plane = -1;
+  for (int b = 0; b < 2; ++b) {
+    ro.q_off[b] = qd[b] == PLANE ? 0u : (1u << (E[qd[b]].pos - 2));
+    if (qd[b] == PLANE) ro.q_plane = b;
+  }
+  for (int b = 0; b < 3; ++b) ro.r_off[b] = 0;
+  bool nt = true;
+  for (int b = 0; b < NR; ++b) {
+    if (rd[b] == PLANE) { ro.r_plane = b; continue; }
+    if (E[rd[b]].pos - 2 > 31) return false;  // offsets are 32-bit vec indices: index bit <= 33
+    ro.r_off[b] = 1u << (E[rd[b]].pos - 2);
+    nt = nt && E[rd[b]].pos >= 6;
+  }
+  for (int b = 0; b < 2; ++b)
+    if (qd[b] != PLANE && E[qd[b]].pos - 2 > 31) return false;
+  P.nt = c.nontemporal < 0 ? nt : c.nontemporal > 0;
+  // decode a K index (q, step) into (plane, effective amplitude index over E)
+  auto decode = [&](unsigned q, unsigned st, unsigned& plane, unsigned& teff) {
+    plane = 0;
+    teff = 0;
+    for (int b = 0; b < 2; ++b) {
+      const unsigned bit = (q >> b) & 1u;
+      if (qd[b] == PLANE) plane = bit; else teff |= bit << qd[b];
+    }
+    for (int cix = 0; cix < KV; ++cix) teff |= ((st >> cix) & 1u) << comp_digit[cix];
+    for (int b = 0; b < NR; ++b) {
+      const unsigned bit = (st >> (KV + b)) & 1u;
+      if (rd[b] == PLANE) plane = bit; else teff |= bit << rd[b];
+    }
+  };
+  auto split = [&](unsigned teff, unsigned& treal, unsigned& tdummy) {
+    treal = 0;
+    tdummy = 0;
+    for (unsigned e = 0; e < k_eff; ++e) {
+      const unsigned bit = (teff >> e) & 1u;
+      if (E[e].tbit >= 0) treal |= bit << E[e].tbit; else tdummy |= bit << e;
+    }
+  };
+  const int NSTEP = 1 << NS, NRB = 1 << (NS - 2);
+  P.A.assign((size_t)NRB * NSTEP * 64, 0.f);
+  for (int rb = 0; rb < NRB; ++rb)
+    for (int st = 0; st < NSTEP; ++st)
+      for (unsigned lane = 0; lane < 64; ++lane) {
+        const unsigned i = lane & 15, q_in = lane >> 4;
+        unsigned po, to, pi, ti, tor, tod, tir, tid;
+        decode(i >> 2, (i & 3) | ((unsigned)rb << 2), po, to);
+        decode(q_in, (unsigned)st, pi, ti);
+        split(to, tor, tod);
+        split(ti, tir, tid);
+        float val = 0.f;
+        if (tod == tid) {
+          const float ur = Ur[tor * D + tir], ui = Ui[tor * D + tir];
+          val = po == pi ? ur : (po == 0 ? -ui : ui);
+        }
+        P.A[((size_t)rb * NSTEP + st) * 64 + lane] = val;
+      }
+  return true;
+}
+
+template <int KBITS, int VMASK>
+static void launch_mfma_kv(Context& c, float* re, float* im, const float* dA, const MfmaPlan& P,
+                           unsigned nblocks) {
+  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NL = 1 << (NS - KV);
+  constexpr int ILP = NL >= 8 ? 1 : 8 / NL;
+  if (P.nt)
+    hipLaunchKernelGGL((apply_mfma_f32_kernel<KBITS, VMASK, ILP, true>), dim3(nblocks), dim3(kBlock), 0,
+                       c.stream, re, im, dA, P.ro);
+  else
+    hipLaunchKernelGGL((apply_mfma_f32_kernel<KBITS, VMASK, ILP, false>), dim3(nblocks), dim3(kBlock), 0,
+                       c.stream, re, im, dA, P.ro);
+}
+
+static int launch_mfma(Context& c, float* re, float* im, const MfmaPlan& P, unsigned n) {
+  void* dA = nullptr;
+  if (arena_upload(c, P.A.data(), P.A.size() * sizeof(float), &dA)) return 1;
+  const uint64_t nslots = 1ull << (n - 2 - P.n_addr);
+  const uint64_t nblocks64 = nslots / ((uint64_t)P.ilp * 64);
+  if (nblocks64 == 0 || nblocks64 > 0x7fffffffull) return fail("mfma: grid out of range");
+  const unsigned nb = (unsigned)nblocks64;
+  const float* A = (const float*)dA;
+  switch (P.kbits * 4 + P.vmask) {
+    case 16: launch_mfma_kv<4, 0>(c, re, im, A, P, nb); break;
+    case 17: launch_mfma_kv<4, 1>(c, re, im, A, P, nb); break;
+    case 18: launch_mfma_kv<4, 2>(c, re, im, A, P, nb); break;
+    case 19: launch_mfma_kv<4, 3>(c, re, im, A, P, nb); break;
+    case 20: launch_mfma_kv<5, 0>(c, re, im, A, P, nb); break;
+    case 21: launch_mfma_kv<5, 1>(c, re, im, A, P, nb); break;
+    case 22: launch_mfma_kv<5, 2>(c, re, im, A, P, nb); break;
+    case 23: launch_mfma_kv<5, 3>(c, re, im, A, P, nb); break;
+    default: return fail("mfma: bad plan");
+  }
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "mfma";
+  return 0;
 }
 
 template <typename T>
@@ -292,9 +482,22 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
                         unsigned k) {
   const bool can_direct = direct_ok<T>(n, k, pos);
   const bool can_generic = (n - k) >= 2 && k <= kMaxK;
+  MfmaPlan plan;
+  bool can_mfma = false;
+  if constexpr (std::is_same<T, float>::value) {
+    if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && k <= 4)
+      can_mfma = plan_mfma(c, U, pos, n, k, plan);
+  }
+  auto run_mfma = [&]() -> int {
+    if constexpr (std::is_same<T, float>::value) return launch_mfma(c, re, im, plan, n);
+    else return fail("mfma: f32 only");
+  };
   switch (c.mode) {
     case Mode::Direct:
       if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
+      break;
+    case Mode::Mfma:
+      if (can_mfma) return run_mfma();
       break;
     case Mode::Generic:
       if (can_generic) return launch_generic<T>(c, re, im, U, pos, n, k);
@@ -304,6 +507,7 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
     case Mode::Auto:
       break;
   }
+  if (can_mfma) return run_mfma();
   if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
   if (can_generic) return launch_generic<T>(c, re, im, U, pos, n, k);
   return launch_naive<T>(c, re, im, U, pos, n, k);
@@ -591,10 +795,12 @@ int hq_set_apply_mode(const char* name) {
   std::string s(name ? name : "");
   if (s == "auto") c.mode = hq::Mode::Auto;
   else if (s == "direct") c.mode = hq::Mode::Direct;
+  else if (s == "mfma") c.mode = hq::Mode::Mfma;
   else if (s == "generic") c.mode = hq::Mode::Generic;
   else if (s == "naive") c.mode = hq::Mode::Naive;
-  else if (s == "nt=1") c.nontemporal = true;
-  else if (s == "nt=0") c.nontemporal = false;
+  else if (s == "nt=1") c.nontemporal = 1;
+  else if (s == "nt=0") c.nontemporal = 0;
+  else if (s == "nt=auto") c.nontemporal = -1;
   else return hq::fail("unknown apply mode: " + s);
   return 0;
 }

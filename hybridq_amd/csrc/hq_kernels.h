@@ -13,6 +13,8 @@
 //                    interleaved 16/32/64-byte pieces of the same cache lines (both
 //                    halves issued back to back by the same wave) for lower targets.
 //                    U lives in SGPRs / the scalar cache (kernel argument).
+//   * apply_mfma     f32, k <= 4: the gate as a real-embedded GEMM on the matrix cores with
+//                    role-assigned index digits (see the kernel's header comment).
 //   * apply_generic  any k <= 10: workgroup tile of 2^(k+c) amplitudes staged
 //                    through LDS (c lowest non-target bits = contiguous columns),
 //                    dense complex mat-mat on the tile, results streamed back.
@@ -143,6 +145,124 @@ apply_direct_kernel(T* __restrict__ re, T* __restrict__ im, const GateArg<T, K> 
         vre[vb[i] | off[ro]] = yr;
         vim[vb[i] | off[ro]] = yi;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// apply_mfma (f32, k <= 4): the gate on the matrix cores, no LDS, no cross-lane traffic.
+//
+// The complex 2^k x 2^k gate acts as the REAL 2^(k+1) x 2^(k+1) matrix [[Ur,-Ui],[Ui,Ur]]
+// on [re; im] (the same 8*2^k flops per amplitude as complex arithmetic).  The f32-input
+// MFMA is an exact k-ordered f32 fma chain, so parity with the VALU path is at rounding
+// level.  v_mfma_f32_16x16x4_f32:  D[16x16] += A[16x4] B[4x16] with lane l holding
+// A[l&15][l>>4], B[l>>4][l&15] and D[4*(l>>4)+r][l&15] in register r.
+//
+// The K index of the embedded matrix has KBITS = k_eff+1 binary digits (k_eff = 3 or 4
+// "effective" targets: real targets plus identity dummies, and the re/im plane).  Each
+// digit is given one of three ROLES, the same on the input (B) and output (D) side:
+//   * q digit    (2 of them): lane>>4.  If it is an index bit, the lane's address carries
+//                that bit, so low targets (positions 2..5) become a PERMUTATION of a
+//                contiguous run instead of a stride; if it is the plane digit, the lane
+//                reads/writes that plane only.
+//   * comp digit (VMASK):     component of the 16-byte vector (index bits 0..1); on the
+//                input side it selects the component fed to the MFMA step, on the
+//                output side the accumulator register lands in that component.
+//   * reg digit  (the rest):  a separate 16-byte load/store per value.
+// Step s = (comp digits, reg digits) walks the K dimension; D register r (and the
+// row-block for k_eff = 4) enumerates the same digits, so every result register goes
+// back to exactly the address/component it came from.  Free vector components are
+// independent column blocks.  Host side (hq_hip.hip: plan_mfma) picks the roles and
+// builds the A-operand table A[row-block][step][lane].
+// ---------------------------------------------------------------------------------
+struct MfmaRoles {
+  unsigned pos[4];    // vec positions (index bit - 2) of all address digits, ascending; 63 = unused
+  unsigned q_off[2];  // vec offset carried by q bit b (0 if that digit is the plane)
+  int q_plane;        // q bit that selects the plane, -1 if the plane is a reg digit
+  unsigned r_off[3];  // vec offset carried by reg digit b (0 if plane)
+  int r_plane;        // reg digit that selects the plane, -1 if the plane is a q digit
+};
+
+template <int KBITS, int VMASK, int ILP, bool NT>
+__global__ void __launch_bounds__(kBlock)
+apply_mfma_f32_kernel(float* __restrict__ re, float* __restrict__ im,
+                      const float* __restrict__ A, const MfmaRoles ro) {
+  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
+  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (2 - KV), NSTEP = 1 << NS;
+  constexpr int FMASK = ~VMASK & 3;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, j = lane & 15;
+  f32x4* __restrict__ pre = reinterpret_cast<f32x4*>(re);
+  f32x4* __restrict__ pim = reinterpret_cast<f32x4*>(im);
+
+  float a[NRB][NSTEP];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
+
+  const uint64_t lane_off = ((q & 1) ? (uint64_t)ro.q_off[0] : 0ull) | ((q & 2) ? (uint64_t)ro.q_off[1] : 0ull);
+  const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
+  uint64_t off[NL];
+  unsigned pl[NL];
+#pragma unroll
+  for (int ld = 0; ld < NL; ++ld) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int b = 0; b < NR; ++b)
+      if ((ld >> b) & 1) o |= ro.r_off[b];
+    off[ld] = o;
+    pl[ld] = ro.r_plane >= 0 ? ((ld >> ro.r_plane) & 1u) : 0u;
+  }
+
+  f32x4 x[ILP][NL];
+  f32x4* ptr[ILP][NL];
+#pragma unroll
+  for (int i = 0; i < ILP; ++i) {
+    uint64_t v = (((uint64_t)blockIdx.x * ILP + i) * (kBlock / 64) + wave) * 16 + j;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const uint64_t lo = (1ull << ro.pos[m]) - 1;
+      v = ((v & ~lo) << 1) | (v & lo);
+    }
+    v |= lane_off;
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      ptr[i][ld] = ((lane_plane | pl[ld]) ? pim : pre) + (v | off[ld]);
+      x[i][ld] = NT ? __builtin_nontemporal_load(ptr[i][ld]) : *ptr[i][ld];
+    }
+  }
+  // every load of the workgroup is in flight before the first MFMA is scheduled
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < ILP; ++i) {
+    f32x4 acc[NCB][NRB];
+#pragma unroll
+    for (int cf = 0; cf < NCB; ++cf)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const int ck = s & ((1 << KV) - 1), ld = s >> KV;
+#pragma unroll
+      for (int cf = 0; cf < NCB; ++cf) {
+        const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+          acc[cf][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][s], x[i][ld][comp], acc[cf][rb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      f32x4 y;
+#pragma unroll
+      for (int comp = 0; comp < 4; ++comp) {
+        const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
+        const int so = ck | (ld << KV);
+        y[comp] = acc[cf][so >> 2][so & 3];
+      }
+      if (NT) __builtin_nontemporal_store(y, ptr[i][ld]);
+      else *ptr[i][ld] = y;
     }
   }
 }

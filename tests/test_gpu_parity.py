@@ -79,8 +79,44 @@ def test_apply_U_matches_oracle(torch_cuda, oracle_port, ft, k):
         gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
         err = _relerr(gr, gi, orr, oi)
         assert err <= TOL[ft], (ft, k, pos, kern, err)
-        if k <= 3:
+        if k <= 4 and ft == np.dtype('float32'):
+            assert kern == 'mfma', kern  # matrix-core path, any target position
+        elif k <= 3:
             assert kern == 'direct', kern
+
+
+def test_apply_U_mfma_kernels(torch_cuda, oracle_port):
+    """complex64 k=1..4 on the matrix cores (real-embedded f32 MFMA, role-assigned index
+    digits): every role combination -- targets in the vector components (bits 0,1), in the
+    permuted lane range (bits 2..5), high, unsorted -- with non-unitary U."""
+    ft = np.dtype('float32')
+    n = 18
+    rng = np.random.default_rng(77)
+    cases = {
+        1: [[p] for p in range(n)],
+        2: [[0, 1], [1, 0], [0, 2], [1, 5], [2, 3], [3, 2], [4, 5], [2, 17], [17, 3], [0, 17], [6, 7], [9, 13], [16, 17]],
+        3: [[0, 1, 2], [2, 1, 0], [0, 1, 17], [0, 2, 3], [1, 4, 9], [2, 3, 4], [4, 3, 2], [2, 9, 17], [17, 5, 11],
+            [7, 8, 9], [15, 16, 17], [10, 2, 6], [0, 7, 13], [3, 4, 5]],
+        4: [[0, 1, 2, 3], [3, 2, 1, 0], [0, 1, 9, 17], [0, 2, 3, 4], [1, 5, 6, 12], [2, 3, 4, 5], [5, 4, 3, 2],
+            [7, 6, 8, 11], [2, 9, 13, 17], [14, 15, 16, 17], [12, 3, 16, 8], [0, 9, 13, 17], [1, 12, 3, 16]],
+    }
+    for k, plist in cases.items():
+        for pos in plist:
+            re, im = _rand_state(rng, n, ft)
+            U = _rand_U(rng, k)
+            orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+            gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos, mode='mfma')
+            assert kern == 'mfma', (kern, k, pos)
+            assert _relerr(gr, gi, orr, oi) <= TOL[ft], (k, pos)
+    # smallest states the matrix-core path accepts, and the fallback below that
+    for nn in (10, 11, 12, 13):
+        for k in (1, 2, 3, 4):
+            pos = rng.permutation(nn)[:k]
+            re, im = _rand_state(rng, nn, ft)
+            U = _rand_U(rng, k)
+            orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+            gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
+            assert _relerr(gr, gi, orr, oi) <= TOL[ft], (nn, k, list(pos), kern)
 
 
 @pytest.mark.parametrize('mode', ['generic', 'naive'])
