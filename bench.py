@@ -47,15 +47,6 @@ def parse_args():
     return ap.parse_args()
 
 
-def kernel_class(pos, vb):
-    """Name of the kernel instantiation a call dispatches to (see csrc/hq_hip.hip)."""
-    k = len(pos)
-    vmask = sum(1 << p for p in pos if p < vb)
-    if k <= 3:
-        return f'apply_direct<k={k},vmask={vmask}>'
-    return f'apply_generic<k={k}>'
-
-
 def cpu_baseline(gates, n, seconds, complex_type):
     """Time the reference C++ core (or the port) on a bounded prefix of the same circuit."""
     import oracle
@@ -133,6 +124,8 @@ def main():
         state = EvolutionState(list(range(n)), complex_type=args.dtype, initial_state='0' * n)
         plan = [(U, qs, [state.map[q] for q in reversed(qs)]) for U, qs in gates]
 
+        kernel_of = [None] * len(plan)  # instantiation each gate dispatches to (from the library)
+
         def run_step(events=None):
             for i, (U, qs, pos) in enumerate(plan):
                 if events is not None:
@@ -140,6 +133,8 @@ def main():
                 core.apply_U(state.planes[0], state.planes[1], U, pos, n)
                 if events is not None:
                     events[i][1].record()
+                elif kernel_of[i] is None:
+                    kernel_of[i] = core.last_kernel_desc()
 
         n_exchanges = 0
     else:
@@ -157,7 +152,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):  # at least one untimed pass (also records kernel names)
         run_step()
     barrier()
     events = None
@@ -205,8 +200,8 @@ def main():
     if rank == 0 and events is not None:
         per_class = {}
         for s in range(args.steps):
-            for (U, qs, pos), (e0, e1) in zip(plan, events[s]):
-                per_class.setdefault(kernel_class(pos, vb), []).append(e0.elapsed_time(e1))
+            for kname, (e0, e1) in zip(kernel_of, events[s]):
+                per_class.setdefault(kname, []).append(e0.elapsed_time(e1))
         total = {c: float(np.sum(v)) for c, v in per_class.items()}
         dom = max(total, key=total.get)
         avg_ms = float(np.mean(per_class[dom]))

@@ -5,9 +5,18 @@ Drop-in replacement of the reference's C++/OpenMP "evolution" backend
 hand-written HIP library with the same C ABI, plus the host-side driver that mirrors
 ``hybridq.circuit.simulation.simulate(..., optimize='evolution')``.
 
-Importing the package loads ``csrc/libhq_hip.so`` and raises if it is missing: there
-is no CPU fallback in the product path.
+Submodules are imported on first use (so that ``python -m hybridq_amd.build`` can
+(re)build the library without loading a stale one).  ``hybridq_amd.core`` loads
+``csrc/libhq_hip.so`` and raises ImportError if it is missing or incomplete: there is
+no CPU fallback anywhere in the product path.
 """
-from . import core  # noqa: F401  (raises ImportError if the HIP library is absent)
+import importlib
 
 __version__ = '0.1.0'
+_SUBMODULES = ('core', 'simulation', 'circuits', 'build', 'dist', 'fusion', 'dot', 'transpose')
+
+
+def __getattr__(name):
+    if name in _SUBMODULES:
+        return importlib.import_module(f'{__name__}.{name}')
+    raise AttributeError(f'module {__name__!r} has no attribute {name!r}')

@@ -85,6 +85,7 @@ _set_stream = _define_function(_lib, 'hq_set_stream', ctypes.c_int, ctypes.c_voi
 _sync = _define_function(_lib, 'hq_sync', ctypes.c_int)
 _last_error = _define_function(_lib, 'hq_last_error', ctypes.c_char_p)
 _last_kernel = _define_function(_lib, 'hq_last_kernel', ctypes.c_char_p)
+_last_kernel_desc = _define_function(_lib, 'hq_last_kernel_desc', ctypes.c_char_p)
 _device_count = _define_function(_lib, 'hq_device_count', ctypes.c_int)
 _set_apply_mode = _define_function(_lib, 'hq_set_apply_mode', ctypes.c_int, ctypes.c_char_p)
 _set_log2_pack_size = _define_function(_lib, 'hq_set_log2_pack_size', ctypes.c_int, ctypes.c_uint)
@@ -104,7 +105,7 @@ EXPORTED = [
     'get_log2_pack_size', 'apply_U_float32', 'apply_U_float64', 'to_complex64', 'to_complex128',
     'swap_float32', 'swap_float64', 'swap_int32', 'swap_int64', 'swap_uint32', 'swap_uint64',
     'hq_set_stream', 'hq_sync', 'hq_set_log2_pack_size', 'hq_last_error', 'hq_device_count',
-    'hq_set_apply_mode', 'hq_last_kernel', 'hq_to_complex64', 'hq_to_complex128',
+    'hq_set_apply_mode', 'hq_last_kernel', 'hq_last_kernel_desc', 'hq_to_complex64', 'hq_to_complex128',
     'hq_init_state_float32', 'hq_init_state_float64', 'hq_norm2_float32', 'hq_norm2_float64',
 ]
 
@@ -119,6 +120,10 @@ def last_error():
 
 def last_kernel():
     return (_last_kernel() or b'').decode()
+
+
+def last_kernel_desc():
+    return (_last_kernel_desc() or b'').decode()
 
 
 def _check(rc, what):

@@ -28,8 +28,10 @@ struct Context {
   unsigned log2_pack = 1;
   Mode mode = Mode::Auto;
   int nontemporal = -1;  // -1 auto, 0 never, 1 always
+  int dummy_policy = -1;  // mfma identity dummies: 0 = free vector components first, 1 = lowest free bits >= 2, -1 = auto
   std::string last_error = "";
   const char* last_kernel = "none";
+  std::string last_desc = "none";  // full instantiation name of the last apply_U kernel
   // arena for matrices that do not fit kernel arguments (generic / naive kernels)
   unsigned char* arena_host = nullptr;  // pinned
   unsigned char* arena_dev = nullptr;
@@ -182,6 +184,9 @@ static int launch_direct_kv(Context& c, T* re, T* im, const T* U, const unsigned
                        dim3(kBlock), 0, c.stream, re, im, g, rp);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "direct";
+  c.last_desc = std::string("apply_direct_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(K) + ", " + std::to_string(VMASK) + ", " + std::to_string(ILP) + ", " +
+                (nt ? "true" : "false") + ">";
   return 0;
 }
 
@@ -282,7 +287,15 @@ static bool plan_mfma(const Context& c, const float* U, const unsigned* pos, uns
   std::vector<Digit> E;
   uint64_t used = 0;
   for (unsigned j = 0; j < k; ++j) { E.push_back({sp[j], (int)j}); used |= 1ull << sp[j]; }
-  for (unsigned p = 0; p < n && E.size() < k_eff; ++p)  // free vector components first, then low bits
+  // Where the identity dummies of a k < 3 gate go (measured at n = 30, sweep3): in free
+  // low index bits (they become q digits: every wave access is one contiguous permuted
+  // run) when a target occupies a vector component or for a single target at position
+  // >= 5; in the free vector components otherwise.
+  int dummy_low = c.dummy_policy;
+  if (dummy_low < 0) dummy_low = (sp[0] < 2 || (k == 1 && sp[0] >= 5)) ? 1 : 0;
+  for (unsigned p = dummy_low == 1 ? 2 : 0; p < n && E.size() < k_eff; ++p)
+    if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
+  for (unsigned p = 0; p < 2 && E.size() < k_eff; ++p)  // tiny n: fall back to the components
     if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
   if (E.size() < k_eff) return false;
   std::sort(E.begin(), E.end(), [](const Digit& a, const Digit& b) { return a.pos < b.pos; });
@@ -408,6 +421,8 @@ static int launch_mfma(Context& c, float* re, float* im, const MfmaPlan& P, unsi
   }
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "mfma";
+  c.last_desc = "apply_mfma_f32_kernel<" + std::to_string(P.kbits) + ", " + std::to_string(P.vmask) + ", " +
+                std::to_string(P.ilp) + ", " + (P.nt ? "true" : "false") + ">";
   return 0;
 }
 
@@ -448,6 +463,7 @@ static int launch_generic(Context& c, T* re, T* im, const T* U, const unsigned* 
                      (const T*)dU, a, nblocks);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "generic";
+  c.last_desc = std::string("apply_generic_kernel<") + (sizeof(T) == 4 ? "float" : "double") + "> k=" + std::to_string(k);
   return 0;
 }
 
@@ -474,6 +490,7 @@ static int launch_naive(Context& c, T* re, T* im, const T* U, const unsigned* po
                      (const T*)tre, (const T*)tim, re, im, (const T*)dU, a, size);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "naive";
+  c.last_desc = "apply_naive_kernel";
   return 0;
 }
 
@@ -801,11 +818,15 @@ int hq_set_apply_mode(const char* name) {
   else if (s == "nt=1") c.nontemporal = 1;
   else if (s == "nt=0") c.nontemporal = 0;
   else if (s == "nt=auto") c.nontemporal = -1;
+  else if (s == "dummy=comp") c.dummy_policy = 0;
+  else if (s == "dummy=low") c.dummy_policy = 1;
+  else if (s == "dummy=auto") c.dummy_policy = -1;
   else return hq::fail("unknown apply mode: " + s);
   return 0;
 }
 
 const char* hq_last_kernel(void) { return hq::ctx().last_kernel; }
+const char* hq_last_kernel_desc(void) { return hq::ctx().last_desc.c_str(); }
 
 int hq_init_state_float32(float* re, float* im, unsigned int n, int kind, uint64_t basis) {
   return hq::init_state_entry<float>(re, im, n, kind, basis);

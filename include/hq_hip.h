@@ -88,11 +88,17 @@ int hq_set_log2_pack_size(unsigned int v);
 const char *hq_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime failure). */
 int hq_device_count(void);
-/* Kernel variant selection for A/B measurements: name in
- * {"auto","direct","generic","naive"}; returns 1 for an unknown name. */
+/* Kernel variant selection for A/B measurements: name in {"auto","mfma","direct",
+ * "generic","naive"} selects the apply_U kernel family (a forced family that cannot run
+ * a call falls back to auto); {"nt=auto","nt=0","nt=1"} the non-temporal policy;
+ * {"dummy=auto","dummy=comp","dummy=low"} the placement of identity digits in the
+ * matrix-core kernel.  Returns 1 for an unknown name. */
 int hq_set_apply_mode(const char *name);
 /* Name of the kernel family the last apply_U call dispatched to. */
 const char *hq_last_kernel(void);
+/* Full template instantiation name of that kernel, as rocprofv3 prints it (e.g.
+ * "apply_mfma_f32_kernel<4, 0, 2, true>"). */
+const char *hq_last_kernel_desc(void);
 
 /* 64-bit-count variants (the reference's `unsigned int size` overflows at
  * n = 32, python_U.cpp:116,145,150). */

@@ -38,6 +38,7 @@ def timeit(pos, mode, reps=8):
     torch.cuda.synchronize()
     core.set_apply_mode('auto')
     core.set_apply_mode('nt=auto')
+    core.set_apply_mode('dummy=auto')
     ms = e0.elapsed_time(e1) / reps
     gbs = 4 * esz * (1 << n) / ms / 1e6
     print(f'k={len(pos)} pos={str(pos):<22} mode={mode:<14} kern={kern:<8} {ms:8.3f} ms {gbs:8.1f} GB/s {gbs/80:5.1f}%',
@@ -45,17 +46,11 @@ def timeit(pos, mode, reps=8):
 
 
 H = n - 1
-cases = [
-    ([12], 'auto'), ([12], 'auto+nt=0'), ([5], 'auto'), ([5], 'auto+nt=1'), ([6], 'auto'), ([6], 'auto+nt=1'),
-    ([7], 'auto'), ([0], 'auto'), ([2], 'auto'), ([H], 'auto'),
-    ([12, 20], 'auto'), ([3, 20], 'auto'), ([2, 3], 'auto'), ([2, 3], 'generic'), ([0, 1], 'auto'), ([1, H], 'auto'),
-    ([10, 15, 20], 'direct'), ([10, 15, 20], 'mfma'), ([10, 15, 20], 'mfma+nt=0'), ([10, 15, 20], 'generic'),
-    ([2, 3, 4], 'direct'), ([2, 3, 4], 'mfma'), ([2, 3, 4], 'generic'), ([3, 12, 21], 'direct'), ([3, 12, 21], 'mfma'),
-    ([0, 9, 17], 'direct'), ([0, 1, 2], 'direct'),
-    ([10, 14, 18, 22], 'mfma'), ([10, 14, 18, 22], 'mfma+nt=0'), ([10, 14, 18, 22], 'generic'),
-    ([2, 3, 4, 5], 'mfma'), ([2, 3, 4, 5], 'generic'), ([4, 9, 15, H], 'mfma'), ([0, 9, 15, H], 'auto'),
-    ([8, 9, 10, 11, 12], 'auto'), ([3, 9, 14, 20, 25], 'auto'), ([8, 9, 10, 11, 12, 13], 'auto'),
-]
+cases = []
+for pos in ([12], [20], [H], [0], [1], [2], [3], [4], [5], [6], [7], [9]):
+    cases += [(pos, 'mfma+dummy=comp'), (pos, 'mfma+dummy=low'), (pos, 'mfma+dummy=low+nt=0'), (pos, 'direct')]
+for pos in ([12, 20], [H - 1, H], [0, 15], [1, H], [2, 20], [5, 20], [3, 4], [8, 9], [0, 3]):
+    cases += [(pos, 'mfma+dummy=comp'), (pos, 'mfma+dummy=low'), (pos, 'direct')]
 if dt != 'float32':
     cases = [c for c in cases if 'mfma' not in c[1]]
 for pos, mode in cases:
