@@ -136,15 +136,27 @@ def main():
                 elif kernel_of[i] is None:
                     kernel_of[i] = core.last_kernel_desc()
 
-        n_exchanges = 0
+        n_exchanges = n_permutes = 0
     else:
         from hybridq_amd.dist import ShardedEvolution
         sharded = ShardedEvolution(n, complex_type=args.dtype, initial_state='0' * n)
-        schedule = sharded.plan(gates)
-        n_exchanges = sum(1 for op in schedule if op[0] == 'X')
+        # every step applies the SAME logical circuit; the qubit placement it starts from is
+        # whatever the previous step left, so each step gets its own (pre-computed) schedule
+        pos0 = dict(sharded.pos)
+        schedules = []
+        for _ in range(max(1, args.warmup) + args.steps):
+            schedules.append(sharded.plan(gates))
+            sharded.pos = dict(sharded._planned_final_pos)
+        sharded.pos = pos0
+        n_exchanges = sum(1 for op in schedules[-1] if op[0] == 'X')
+        n_permutes = sum(1 for op in schedules[-1] if op[0] == 'P')
+        step_no = [0]
 
         def run_step(events=None):
-            sharded.run(schedule)
+            sched = schedules[step_no[0]]
+            step_no[0] += 1
+            sharded._planned_final_pos = None
+            sharded.run(sched, update_map=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -194,6 +206,7 @@ def main():
             'state_bytes_per_gpu': 2 * (1 << n_local) * ft.itemsize,
             'parallelism': f'high-qubit shard x{world}' if world > 1 else 'single GPU',
             'exchanges_per_step': n_exchanges,
+            'local_permutation_passes_per_step': n_permutes,
         },
     }
 

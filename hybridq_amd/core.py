@@ -100,6 +100,11 @@ _norm2 = {
                                             ctypes.POINTER(ctypes.c_double)) for b in (32, 64)
 }
 
+_permute_bits = {
+    b: _define_function(_lib, f'hq_permute_bits_{8 * b}', ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                        ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint) for b in (4, 8)
+}
+
 #: symbols the C header include/hq_hip.h declares (checked by tests/test_abi.py)
 EXPORTED = [
     'get_log2_pack_size', 'apply_U_float32', 'apply_U_float64', 'to_complex64', 'to_complex128',
@@ -107,6 +112,7 @@ EXPORTED = [
     'hq_set_stream', 'hq_sync', 'hq_set_log2_pack_size', 'hq_last_error', 'hq_device_count',
     'hq_set_apply_mode', 'hq_last_kernel', 'hq_last_kernel_desc', 'hq_to_complex64', 'hq_to_complex128',
     'hq_init_state_float32', 'hq_init_state_float64', 'hq_norm2_float32', 'hq_norm2_float64',
+    'hq_permute_bits_32', 'hq_permute_bits_64',
 ]
 
 
@@ -229,3 +235,14 @@ def norm2(psi_re, psi_im):
     rc = _norm2[ft](_ptr(psi_re), _ptr(psi_im), size, ctypes.byref(out))
     _check(rc, 'norm2')
     return out.value
+
+
+def permute_bits(src, dst, perm, n_qubits=None):
+    """dst[x] = src[pi(x)], bit i of x -> bit perm[i] of pi(x); out of place, device tensors."""
+    dt = _float_dtype(src)
+    perm = np.ascontiguousarray(perm, dtype=np.uint32)
+    n = _n_qubits(src) if n_qubits is None else int(n_qubits)
+    if len(perm) != n:
+        raise ValueError("'perm' must have one entry per index bit")
+    rc = _permute_bits[dt.itemsize](_ptr(src), _ptr(dst), perm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n)
+    _check(rc, 'permute_bits')

@@ -620,6 +620,49 @@ static int swap_entry(E* a, const unsigned* pos, unsigned n, unsigned s) {
 }
 
 // ---------------------------------------------------------------------------------
+// permute_bits (device pointers only)
+// ---------------------------------------------------------------------------------
+template <typename E>
+static int permute_bits_entry(const E* src, E* dst, const unsigned* perm, unsigned n) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!src || !dst || !perm) return fail("permute_bits: null pointer");
+  if (n > 62) return fail("permute_bits: n too large");
+  if (src == dst) return fail("permute_bits: must be out of place");
+  if (!is_device_pointer(src) || !is_device_pointer(dst)) return fail("permute_bits: device pointers only");
+  uint64_t seen = 0;
+  PermArg pa;
+  memset(&pa, 0, sizeof(pa));
+  for (unsigned i = 0; i < n; ++i) {
+    if (perm[i] >= n || (seen >> perm[i]) & 1) return fail("permute_bits: perm is not a permutation of 0..n-1");
+    seen |= 1ull << perm[i];
+    if (perm[i] == i) pa.fixed_mask |= 1ull << i;
+    else {
+      if (pa.nmoved >= 16) return fail("permute_bits: more than 16 moved bits");
+      pa.from[pa.nmoved] = i;
+      pa.to[pa.nmoved] = perm[i];
+      ++pa.nmoved;
+    }
+  }
+  const uint64_t size = 1ull << n;
+  const bool vec16 = (pa.fixed_mask & 3) == 3 && n >= 2 && sizeof(E) == 4 &&
+                     reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0;
+  const bool vec16d = (pa.fixed_mask & 1) == 1 && n >= 1 && sizeof(E) == 8 &&
+                      reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0;
+  const uint64_t units = vec16 ? size / 4 : (vec16d ? size / 2 : size);
+  const unsigned grid = (unsigned)std::min<uint64_t>((units + kBlock - 1) / kBlock, 256 * 64);
+  if (vec16)
+    hipLaunchKernelGGL((permute_bits_kernel<E, 4>), dim3(grid), dim3(kBlock), 0, c.stream, src, dst, pa, units);
+  else if (vec16d)
+    hipLaunchKernelGGL((permute_bits_kernel<E, 2>), dim3(grid), dim3(kBlock), 0, c.stream, src, dst, pa, units);
+  else
+    hipLaunchKernelGGL((permute_bits_kernel<E, 1>), dim3(grid), dim3(kBlock), 0, c.stream, src, dst, pa, units);
+  HQ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // to_complex
 // ---------------------------------------------------------------------------------
 template <typename T>
@@ -768,6 +811,13 @@ int swap_uint32(unsigned int* a, const unsigned int* pos, unsigned int n, unsign
 }
 int swap_uint64(unsigned long* a, const unsigned int* pos, unsigned int n, unsigned int s) {
   return hq::swap_entry<uint64_t>(reinterpret_cast<uint64_t*>(a), pos, n, s);
+}
+
+int hq_permute_bits_32(const void* src, void* dst, const unsigned int* perm, unsigned int n) {
+  return hq::permute_bits_entry<uint32_t>((const uint32_t*)src, (uint32_t*)dst, perm, n);
+}
+int hq_permute_bits_64(const void* src, void* dst, const unsigned int* perm, unsigned int n) {
+  return hq::permute_bits_entry<uint64_t>((const uint64_t*)src, (uint64_t*)dst, perm, n);
 }
 
 int hq_set_stream(void* hip_stream) {

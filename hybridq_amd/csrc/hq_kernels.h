@@ -444,6 +444,35 @@ swap_gather_kernel(const E* __restrict__ in, E* __restrict__ out, const SwapArg 
 }
 
 // ---------------------------------------------------------------------------------
+// permute_bits: out-of-place permutation of ARBITRARY index bits, dst[x] = src[pi(x)],
+// where bit i of x moves to bit perm[i] of pi(x).  Generalises swap (which only moves the
+// low s bits) to the whole index; used to bring qubits into the exchange slots of the
+// multi-GPU shard exchange and to restore the canonical order.  Only the moved bits cost
+// index arithmetic; if bits 0..1 are fixed the copy runs on 16-byte vectors.
+// ---------------------------------------------------------------------------------
+struct PermArg {
+  unsigned nmoved;
+  unsigned from[16];   // destination-index bit ...
+  unsigned to[16];     // ... lands at this source-index bit
+  uint64_t fixed_mask; // bits that stay where they are
+};
+
+template <typename E, int VEC>
+__global__ void __launch_bounds__(kBlock)
+permute_bits_kernel(const E* __restrict__ src, E* __restrict__ dst, const PermArg pa,
+                    const uint64_t nunits /* 2^n / VEC */) {
+  struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t u = (uint64_t)blockIdx.x * kBlock + threadIdx.x; u < nunits; u += stride) {
+    const uint64_t x = u * VEC;
+    uint64_t y = x & pa.fixed_mask;
+#pragma unroll 4
+    for (unsigned i = 0; i < pa.nmoved; ++i) y |= ((x >> pa.from[i]) & 1ull) << pa.to[i];
+    *reinterpret_cast<Pack*>(dst + x) = *reinterpret_cast<const Pack*>(src + y);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // to_complex, init_state, norm2
 // ---------------------------------------------------------------------------------
 template <typename T>

@@ -1,0 +1,300 @@
+"""Multi-GPU state-vector evolution: high-qubit sharding + RCCL all-to-all qubit exchange.
+
+No reference counterpart: ``optimize='evolution'`` "does not support MPI"
+(hybridq/circuit/simulation/simulation.py:379-380).  This is the extension named by
+BASELINE.json's north_star.
+
+Layout.  G = 2^g ranks (one process per GPU).  Rank r holds the 2^m amplitudes
+(m = n - g) whose top g index bits equal r, as split re/im planes -- i.e. index bit
+m+i IS bit i of the rank.  A gate whose targets all sit at positions < m runs the
+single-GPU kernel on every shard with no communication.  When a gate needs a qubit that
+currently sits at a global position the planner
+
+  1. picks g local qubits to evict (Belady: the ones whose next use is farthest away,
+     never one the blocked gates need),
+  2. if they are not already at the top g local positions, moves them there with ONE
+     out-of-place bit-permutation pass (``hq_permute_bits``; 'P' op),
+  3. exchanges the top g local bits with the g global bits: ``all_to_all_single`` on the
+     plane viewed as [G, 2^(m-g)] -- chunk j of rank r becomes chunk r of rank j
+     ('X' op).  Every GPU talks to all 7 peers at once, which is what the xGMI
+     point-to-point mesh wants (per-link bound), unlike a ring.
+
+Gates are list-scheduled over their dependency DAG so that everything executable
+locally runs before an exchange is paid.  The schedule is a pure function of the gate
+list, so every rank computes the same one without communication.
+
+The numerical work goes through ``hybridq_amd.core`` (HIP library) by default.  The
+``backend`` argument exists so that the CPU test-suite can drive the SAME planner and
+exchange logic over gloo with a host backend; the product never selects one itself.
+"""
+from collections import deque
+
+import numpy as np
+
+_FLOAT_OF = {np.dtype('complex64'): np.dtype('float32'), np.dtype('complex128'): np.dtype('float64')}
+
+
+# ------------------------------------------------------------------------------------
+# planner (pure Python, deterministic)
+# ------------------------------------------------------------------------------------
+def plan_schedule(gate_qubits, qubits, g):
+    """Schedule gates (given as tuples of qubit labels) on n = len(qubits) qubits sharded
+    over 2^g ranks.
+
+    Returns (ops, final_pos): ops is a list of
+        ('G', gate_index, local_positions)   positions are LSB-first like simulation.py:633
+        ('P', perm)                          local bit permutation, dst bit i <- src bit perm[i]
+        ('X',)                               exchange top-g local bits with the rank bits
+    and final_pos maps qubit label -> physical position after the last op."""
+    n = len(qubits)
+    m = n - g
+    pos = {q: n - 1 - i for i, q in enumerate(qubits)}  # simulation.py:512
+    at = {p: q for q, p in pos.items()}
+    queues = {q: deque() for q in qubits}
+    for gi, qs in enumerate(gate_qubits):
+        for q in qs:
+            queues[q].append(gi)
+    done = [False] * len(gate_qubits)
+    n_done = 0
+    ops = []
+
+    def ready(gi):
+        return all(queues[q][0] == gi for q in gate_qubits[gi])
+
+    while n_done < len(gate_qubits):
+        progress = True
+        while progress:
+            progress = False
+            heads = sorted({queues[q][0] for q in qubits if queues[q]})
+            for gi in heads:
+                if done[gi] or not ready(gi):
+                    continue
+                qs = gate_qubits[gi]
+                if all(pos[q] < m for q in qs):
+                    ops.append(('G', gi, [pos[q] for q in reversed(qs)]))
+                    for q in qs:
+                        queues[q].popleft()
+                    done[gi] = True
+                    n_done += 1
+                    progress = True
+        if n_done == len(gate_qubits):
+            break
+        if g == 0:
+            raise RuntimeError('planner stalled without global qubits')
+        # blocked frontier: ready gates that touch a global position
+        heads = sorted({queues[q][0] for q in qubits if queues[q]})
+        needed = set()
+        for gi in heads:
+            if ready(gi):
+                needed.update(gate_qubits[gi])
+        local = [q for q in qubits if pos[q] < m and q not in needed]
+        if len(local) < g:
+            raise RuntimeError('not enough evictable local qubits for an exchange')
+        inf = len(gate_qubits) + 1
+
+        def key(q):
+            nxt = queues[q][0] if queues[q] else inf
+            in_top = pos[q] >= m - g
+            return (-nxt, 0 if in_top else 1, -pos[q])
+
+        evict = sorted(local, key=key)[:g]
+        # bring the evictees to the top-g local positions (keep those already there)
+        top = list(range(m - g, m))
+        stay = [q for q in evict if pos[q] in top]
+        free_slots = [p for p in top if at[p] not in stay]
+        movers = [q for q in evict if q not in stay]
+        if movers:
+            perm = list(range(m))
+            for slot, q in zip(free_slots, movers):
+                a, b = slot, pos[q]
+                perm[a], perm[b] = perm[b], perm[a]
+                qa, qb = at[a], at[b]
+                at[a], at[b] = qb, qa
+                pos[qa], pos[qb] = b, a
+            ops.append(('P', perm))
+        ops.append(('X',))
+        for i in range(g):
+            a, b = m - g + i, m + i
+            qa, qb = at[a], at[b]
+            at[a], at[b] = qb, qa
+            pos[qa], pos[qb] = b, a
+    return ops, dict(pos)
+
+
+# ------------------------------------------------------------------------------------
+# backends
+# ------------------------------------------------------------------------------------
+class HipBackend:
+    """Shard planes in HBM (torch tensors), kernels from libhq_hip.so, RCCL collectives."""
+
+    def __init__(self, float_type, device=None):
+        import torch
+        import torch.distributed as dist
+        from . import core
+        if not torch.cuda.is_available():
+            raise RuntimeError('HipBackend needs a HIP device')
+        self.torch, self.dist, self.core = torch, dist, core
+        self.float_type = np.dtype(float_type)
+        self.tdt = {np.dtype('float32'): torch.float32, np.dtype('float64'): torch.float64}[self.float_type]
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        core.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def empty_planes(self, m):
+        return self.torch.empty((2, 1 << m), dtype=self.tdt, device=self.device)
+
+    def fill_zero(self, planes):
+        planes.zero_()
+
+    def fill_basis(self, planes, local_index):
+        self.core.init_state(planes[0], planes[1], 'basis', local_index)
+
+    def fill_const(self, planes, value):
+        planes[0].fill_(value)
+        planes[1].zero_()
+
+    def apply(self, planes, U, pos, m):
+        self.core.apply_U(planes[0], planes[1], U, pos, m)
+
+    def permute(self, src, dst, perm, m):
+        self.core.permute_bits(src[0], dst[0], perm, m)
+        self.core.permute_bits(src[1], dst[1], perm, m)
+
+    def all_to_all(self, dst, src, group):
+        self.dist.all_to_all_single(dst[0], src[0], group=group)
+        self.dist.all_to_all_single(dst[1], src[1], group=group)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def to_numpy(self, planes):
+        return planes.cpu().numpy()
+
+    def norm2(self, planes):
+        return self.core.norm2(planes[0], planes[1])
+
+
+# ------------------------------------------------------------------------------------
+# runtime
+# ------------------------------------------------------------------------------------
+class ShardedEvolution:
+    """n-qubit state sharded by the top g = log2(world) index bits over the process group."""
+
+    def __init__(self, n, complex_type='complex64', initial_state=None, qubits=None, backend=None,
+                 group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.g = int(self.world).bit_length() - 1
+        if 1 << self.g != self.world:
+            raise ValueError('the number of ranks must be a power of two')
+        self.n = n
+        self.m = n - self.g
+        if self.m < 2 * self.g:
+            raise ValueError('need at least 2*log2(world) local qubits')
+        self.qubits = list(range(n)) if qubits is None else list(qubits)
+        self.complex_type = np.dtype(complex_type)
+        self.float_type = _FLOAT_OF[self.complex_type]
+        self.backend = HipBackend(self.float_type) if backend is None else backend
+        self.bufs = [self.backend.empty_planes(self.m), self.backend.empty_planes(self.m) if self.g else None]
+        self.cur = 0
+        self.pos = {q: n - 1 - i for i, q in enumerate(self.qubits)}
+        self._gates = None
+        self.set_state('0' * n if initial_state is None else initial_state)
+
+    # -- state ------------------------------------------------------------------
+    @property
+    def planes(self):
+        return self.bufs[self.cur]
+
+    def set_state(self, initial_state):
+        """'0'/'1' strings (basis states) and the all-'+' string; canonical qubit order."""
+        s = initial_state
+        if len(s) == 1:
+            s = s * self.n
+        if len(s) != self.n:
+            raise ValueError("'initial_state' has the wrong number of qubits.")
+        self.pos = {q: self.n - 1 - i for i, q in enumerate(self.qubits)}
+        if all(c in '01' for c in s):
+            b = int(s, 2)
+            if (b >> self.m) == self.rank:
+                self.backend.fill_basis(self.planes, b & ((1 << self.m) - 1))
+            else:
+                self.backend.fill_zero(self.planes)
+        elif all(c == '+' for c in s):
+            self.backend.fill_const(self.planes, 2.0**(-0.5 * self.n))
+        else:
+            raise ValueError("sharded initial states: '0'/'1' strings or all '+'")
+
+    # -- planning ----------------------------------------------------------------
+    def plan(self, gates):
+        """Schedule `gates` ([(U, qubits), ...]) from the CURRENT qubit placement.  Returns
+        the op list for run(); the matrices are cast once here."""
+        gq = [tuple(qs) for _, qs in gates]
+        order = sorted(self.qubits, key=lambda q: -self.pos[q])  # label at position n-1, n-2, ...
+        ops, final_pos = plan_schedule(gq, order, self.g)
+        mats = [np.ascontiguousarray(U, dtype=self.complex_type) for U, _ in gates]
+        sched = []
+        for op in ops:
+            if op[0] == 'G':
+                sched.append(('G', mats[op[1]], np.asarray(op[2], dtype=np.uint32)))
+            elif op[0] == 'P':
+                sched.append(('P', np.asarray(op[1], dtype=np.uint32)))
+            else:
+                sched.append(op)
+        self._planned_final_pos = final_pos
+        return sched
+
+    def run(self, schedule, update_map=True):
+        be = self.backend
+        for op in schedule:
+            if op[0] == 'G':
+                be.apply(self.bufs[self.cur], op[1], op[2], self.m)
+            elif op[0] == 'P':
+                be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m)
+                self.cur = 1 - self.cur
+            else:
+                be.all_to_all(self.bufs[1 - self.cur], self.bufs[self.cur], self.group)
+                self.cur = 1 - self.cur
+        if update_map:
+            self.pos = dict(self._planned_final_pos)
+
+    def simulate(self, gates):
+        self.run(self.plan(gates))
+        return self
+
+    # -- results -----------------------------------------------------------------
+    def norm2(self):
+        """Global squared norm (all-reduce of the local ones)."""
+        import torch
+        v = torch.tensor([self.backend.norm2(self.planes)], dtype=torch.float64)
+        if self.world > 1:
+            if self.dist.get_backend(self.group) == 'nccl':
+                v = v.cuda()
+            self.dist.all_reduce(v, group=self.group)
+        return float(v.item())
+
+    def state_numpy(self):
+        """Full state in CANONICAL qubit order on every rank (tests / small n only)."""
+        import torch
+        self.backend.sync()
+        local = np.ascontiguousarray(self.backend.to_numpy(self.planes))
+        if self.world > 1:
+            t = torch.from_numpy(local)
+            nccl = self.dist.get_backend(self.group) == 'nccl'
+            if nccl:
+                t = t.cuda()
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            self.dist.all_gather(parts, t, group=self.group)
+            full = np.stack([p.cpu().numpy() for p in parts], axis=1)  # [plane, rank, local]
+        else:
+            full = local[:, None, :]
+        psi = (full[0] + 1j * full[1]).reshape(-1)  # physical order: index bit p <-> position p
+        # physical position p holds qubit at[p]; canonical wants label #x at position n-1-x
+        n = self.n
+        at = {p: q for q, p in self.pos.items()}
+        axes_now = [at[n - 1 - a] for a in range(n)]  # qubit label on numpy axis a
+        want = self.qubits
+        perm = [axes_now.index(q) for q in want]
+        return np.ascontiguousarray(np.transpose(psi.reshape((2,) * n), perm)).reshape(-1)

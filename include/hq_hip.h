@@ -113,6 +113,14 @@ int hq_init_state_float32(float *psi_re, float *psi_im, unsigned int n_qubits, i
 int hq_init_state_float64(double *psi_re, double *psi_im, unsigned int n_qubits, int kind,
                           uint64_t basis);
 
+/* Out-of-place permutation of ARBITRARY index bits of an array of 2^n 4-byte
+ * (_32) or 8-byte (_64) elements: dst[x] = src[pi(x)], where bit i of x moves to
+ * bit perm[i] of pi(x) (perm = a permutation of 0..n-1, at most 16 moved bits).
+ * Generalises swap_* (low bits only, in place) to the whole index; the multi-GPU
+ * driver uses it to bring qubits into the exchange slots.  Device pointers only. */
+int hq_permute_bits_32(const void *src, void *dst, const unsigned int *perm, unsigned int n);
+int hq_permute_bits_64(const void *src, void *dst, const unsigned int *perm, unsigned int n);
+
 /* sum_i re[i]^2 + im[i]^2 accumulated in double, written to *out (host).
  * Synchronises the stream.  Device pointers only. */
 int hq_norm2_float32(const float *psi_re, const float *psi_im, uint64_t size, double *out);
