@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference and oracle/_ref built by
+`make -C oracle ref`); the outputs (.npz, data only) are committed, the reference is not.
+
+    cd /tmp && LD_LIBRARY_PATH=/root/repo/oracle/_ref PYTHONDONTWRITEBYTECODE=1 \
+        python /root/repo/tests/golden/make_golden.py
+
+What is recorded
+  calls_apply_U.npz   per-call vectors of apply_U_float32/64 produced by the reference's
+                      compiled C++ core (include/python_U.cpp -> oracle/_ref/hybridq.so):
+                      k = 1..6, sorted/unsorted positions (>= 3, U.h:48-54), unitary and
+                      non-unitary U, inputs and outputs.
+  calls_swap.npz      swap_* of arange(2^n) by the reference core, n_pos = 1..12.
+  e2e_simple_qasm.npz examples/circuit_simple.qasm (24 qubits, 99 gates) through the
+                      reference's simulate(optimize='evolution-hybridq'): gate list as
+                      (name, qubits), the C-ABI call trace with the fused 16x16 matrices,
+                      and a strided sample / head / norm of the final state.
+  e2e_rqc.npz         hybridq.extras.random.get_rqc circuits (n = 12) through simulate():
+                      gate list as dense (U, qubits), final states for complex64
+                      (compress=4) and complex128 (compress=0).
+  e2e_dm.npz          a 6-qubit circuit with depolarizing noise through
+                      hybridq.dm.circuit.simulation.simulate (-> 12-qubit state vector):
+                      the C-ABI call trace (swaps + fused NON-unitary gates) and the final rho.
+The import of the reference Python needs stand-ins for three absent third-party modules
+(opt_einsum, more_itertools, numba); none of them is on the evolution-hybridq path except
+numba.vectorize for '+-' initial states.
+"""
+import ctypes
+import itertools
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+
+def install_stubs():
+    oe = types.ModuleType('opt_einsum')
+    oe.contract = lambda path, *ops, **kw: np.einsum(path, *ops)
+    oe.get_symbol = lambda i: chr(ord('a') + i) if i < 26 else chr(ord('A') + i - 26)
+    oec = types.ModuleType('opt_einsum.contract')
+    oec.PathInfo = type('PathInfo', (), {})
+    sys.modules['opt_einsum'] = oe
+    sys.modules['opt_einsum.contract'] = oec
+    mi = types.ModuleType('more_itertools')
+    mi.flatten = lambda it: itertools.chain.from_iterable(it)
+
+    def chunked(it, n):
+        it = iter(it)
+        while True:
+            c = list(itertools.islice(it, n))
+            if not c:
+                return
+            yield c
+
+    mi.chunked = chunked
+    mi.ichunked = chunked
+    mi.distribute = lambda n, it: [list(it)[i::n] for i in range(n)]
+    sys.modules['more_itertools'] = mi
+    nb = types.ModuleType('numba')
+
+    def vectorize(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return np.vectorize(a[0])
+        return lambda f: np.vectorize(f)
+
+    def njit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    nb.vectorize, nb.njit, nb.jit, nb.prange = vectorize, njit, njit, range
+    sys.modules['numba'] = nb
+
+
+def per_call_vectors():
+    import oracle
+    from oracle.binding import aligned_empty
+    ref = oracle.load_ref()
+    rng = np.random.default_rng(20260928)
+    n = 10
+    out = {}
+    idx = 0
+    for ft in (np.float32, np.float64):
+        for k in range(1, 7):
+            for variant in range(3):
+                pos = rng.permutation(np.arange(3, n))[:k]
+                if variant == 0:
+                    pos = np.sort(pos)
+                d = 1 << k
+                U = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+                if variant == 2:  # unitary
+                    U = np.linalg.qr(U)[0]
+                U = U.astype(np.complex64 if ft == np.float32 else np.complex128)
+                pl = aligned_empty((2, 1 << n), ft)
+                pl[:] = rng.standard_normal((2, 1 << n))
+                inp = pl.copy()
+                assert ref.apply_U(pl[0], pl[1], U, pos) == 0
+                out[f'c{idx}_in'] = inp
+                out[f'c{idx}_out'] = pl.copy()
+                out[f'c{idx}_U'] = U
+                out[f'c{idx}_pos'] = pos.astype(np.uint32)
+                idx += 1
+    out['n_cases'] = idx
+    out['n_qubits'] = n
+    np.savez_compressed(os.path.join(HERE, 'calls_apply_U.npz'), **out)
+    print('calls_apply_U.npz:', idx, 'cases')
+
+    out = {}
+    idx = 0
+    n = 12
+    for s in range(1, 13):
+        pos = rng.permutation(s).astype(np.uint32)
+        a = aligned_empty(1 << n, np.uint32, alignment=4096)
+        a[:] = np.arange(1 << n)
+        assert ref.swap(a, pos) == 0
+        out[f's{idx}_pos'] = pos
+        out[f's{idx}_out'] = a.astype(np.uint16 if n <= 16 else np.uint32)
+        idx += 1
+    out['n_cases'] = idx
+    out['n_qubits'] = n
+    np.savez_compressed(os.path.join(HERE, 'calls_swap.npz'), **out)
+    print('calls_swap.npz:', idx, 'cases')
+
+
+class Tracer:
+    """Wrap the reference's ctypes function tables (looked up at call time,
+    simulation.py:482-485) to record the C-ABI call sequence."""
+
+    def __init__(self, sim):
+        self.sim = sim
+        self.calls = []
+        self._dot = dict(sim._dot_core)
+        self._swap = dict(sim._swap_core)
+
+    def __enter__(self):
+        calls = self.calls
+
+        def wrap_dot(f, ft):
+            def g(re, im, U, pos, n, k):
+                d = 1 << k
+                Uarr = np.ctypeslib.as_array(U, shape=(2 * d * d,)).copy()
+                parr = np.ctypeslib.as_array(pos, shape=(k,)).copy()
+                calls.append(('U', parr, Uarr.view(np.complex64 if ft == np.float32 else np.complex128).reshape(d, d)))
+                return f(re, im, U, pos, n, k)
+            return g
+
+        def wrap_swap(f):
+            def g(a, pos, n, s):
+                calls.append(('S', np.ctypeslib.as_array(pos, shape=(s,)).copy(), None))
+                return f(a, pos, n, s)
+            return g
+
+        for dt, f in self._dot.items():
+            self.sim._dot_core[dt] = wrap_dot(f, dt.type)
+        for dt, f in self._swap.items():
+            self.sim._swap_core[dt] = wrap_swap(f)
+        return self
+
+    def __exit__(self, *a):
+        self.sim._dot_core.update(self._dot)
+        self.sim._swap_core.update(self._swap)
+
+
+def pack_trace(calls, prefix, out):
+    kinds = ''.join(c[0] for c in calls)
+    out[prefix + 'kinds'] = np.frombuffer(kinds.encode(), dtype=np.uint8)
+    for i, (kind, pos, U) in enumerate(calls):
+        out[f'{prefix}{i}_pos'] = np.asarray(pos, dtype=np.uint32)
+        if U is not None:
+            out[f'{prefix}{i}_U'] = U
+
+
+def end_to_end():
+    install_stubs()
+    sys.path.insert(0, REF)
+    import hybridq.circuit.simulation.simulation as sim
+    from hybridq.circuit.simulation import simulate
+    from hybridq.extras.io.qasm import from_qasm
+    from hybridq.extras.random import get_rqc
+    from hybridq.circuit import utils
+    assert sim._log2_pack_size == 3, 'reference core not found: set LD_LIBRARY_PATH=oracle/_ref'
+
+    # ---- examples/circuit_simple.qasm -------------------------------------------------
+    c = from_qasm(open(os.path.join(REF, 'examples', 'circuit_simple.qasm')).read())
+    qubits = c.all_qubits()
+    n = len(qubits)
+    out = {}
+    names = [g.name for g in c]
+    out['gate_names'] = np.array(names)
+    out['gate_qubits'] = np.array([list(g.qubits) + [-1] * (2 - len(g.qubits)) for g in c], dtype=np.int32)
+    uniq = sorted(set(names))
+    out['matrix_names'] = np.array(uniq)
+    for nm in uniq:
+        out['matrix_' + nm] = np.asarray(next(g for g in c if g.name == nm).matrix(), dtype=np.complex128)
+    with Tracer(sim) as tr:
+        psi, info = simulate(c, initial_state='0', optimize='evolution-hybridq', complex_type='complex64',
+                             return_info=True, verbose=False)
+    psi = psi.reshape(-1)
+    pack_trace(tr.calls, 'trace_', out)
+    out['n_qubits'] = n
+    out['sample_stride'] = (1 << n) // 4096
+    out['psi_sample'] = psi[::(1 << n) // 4096].copy()
+    out['psi_head'] = psi[:8].copy()
+    out['norm2'] = float(np.vdot(psi, psi).real)
+    np.savez_compressed(os.path.join(HERE, 'e2e_simple_qasm.npz'), **out)
+    print('e2e_simple_qasm.npz: n =', n, 'gates =', len(c), 'calls =', ''.join(k for k, _, _ in tr.calls),
+          'norm2 =', out['norm2'], 'psi[0:2] =', psi[:2])
+
+    # ---- seeded reference RQCs ---------------------------------------------------------
+    out = {}
+    np.random.seed(1234)
+    n = 12
+    for tag, ct, compress in (('a', 'complex64', 4), ('b', 'complex128', 0)):
+        c = get_rqc(n, 60, use_random_indexes=False)
+        qubits = c.all_qubits()
+        c = utils.flatten(c) if hasattr(utils, 'flatten') else c
+        mats, qs = [], []
+        for g in c:
+            mats.append(np.asarray(g.matrix(), dtype=np.complex128))
+            qs.append([qubits.index(q) for q in g.qubits])
+        with Tracer(sim) as tr:
+            psi = simulate(c, initial_state='0', optimize='evolution-hybridq', complex_type=ct,
+                           compress=compress, simplify=False, remove_id_gates=False, verbose=False)
+        out[f'{tag}_n_gates'] = len(mats)
+        for i, (U, q) in enumerate(zip(mats, qs)):
+            out[f'{tag}_U{i}'] = U
+            out[f'{tag}_q{i}'] = np.asarray(q, dtype=np.int32)
+        out[f'{tag}_psi'] = psi.reshape(-1)
+        pack_trace(tr.calls, f'{tag}_trace_', out)
+        out[f'{tag}_calls'] = np.frombuffer(''.join(k for k, _, _ in tr.calls).encode(), dtype=np.uint8)
+        print(f'e2e_rqc {tag}: {ct} compress={compress} gates={len(mats)} calls={"".join(k for k, _, _ in tr.calls)}')
+    out['n_qubits'] = n
+    np.savez_compressed(os.path.join(HERE, 'e2e_rqc.npz'), **out)
+
+    # ---- density matrix with noise -> 2n-qubit state vector ----------------------------
+    import hybridq.dm.circuit.simulation as dmsim
+    from hybridq.noise.utils import add_depolarizing_noise
+    from hybridq.gate import Gate
+    np.random.seed(4321)
+    nq = 6
+    circ = get_rqc(nq, 20, use_random_indexes=False)
+    noisy = add_depolarizing_noise(circ, probs=(0.01, 0.02))
+    with Tracer(sim) as tr:
+        rho = dmsim.simulate(noisy, initial_state='0', optimize='evolution-hybridq', verbose=False)
+    # what the evolution driver was asked to do, at the C ABI: swaps + fused (non-unitary) gates
+    out = {'n_qubits': 2 * nq}
+    pack_trace(tr.calls, 'trace_', out)
+    out['rho'] = np.asarray(rho).reshape(-1)
+    np.savez_compressed(os.path.join(HERE, 'e2e_dm.npz'), **out)
+    r = np.asarray(rho).reshape(1 << nq, 1 << nq)
+    print('e2e_dm.npz: 2n =', 2 * nq, 'trace(rho) =', np.trace(r).real,
+          'calls =', ''.join(k for k, _, _ in tr.calls))
+
+
+if __name__ == '__main__':
+    if os.path.exists('hybridq.so'):
+        raise SystemExit('run from a directory that does not contain hybridq.so')
+    per_call_vectors()
+    end_to_end()
