@@ -223,7 +223,9 @@ def main():
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(dom)
+                tj = json.load(open(tfile))  # PMC-measured HBM bytes per launch (profiles/r01_pmc_hbm_traffic.csv)
+                if tj.get('n_qubits') == n_local and tj.get('dtype') == args.dtype:
+                    traffic = tj.get(dom)
             except Exception:
                 traffic = None
         result['roofline'] = {

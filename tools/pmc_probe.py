@@ -1,0 +1,24 @@
+"""HBM-traffic probe for rocprofv3 --pmc passes: a read-only kernel (norm2: 8*2^n B), a
+write-only kernel (init_state: 8*2^n B) for calibration, then one launch of each gate
+kernel class (16*2^n algorithmic bytes each).  Usage: python tools/pmc_probe.py [n]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hybridq_amd import core  # noqa: E402
+from hybridq_amd.circuits import haar_unitary  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+core.set_stream(torch.cuda.current_stream().cuda_stream)
+planes = torch.empty((2, 1 << n), dtype=torch.float32, device='cuda')
+rng = np.random.default_rng(0)
+core.init_state(planes[0], planes[1], 'plus')
+print('norm2', core.norm2(planes[0], planes[1]))
+for pos in ([12], [3], [0], [12, 20], [2, 3], [0, 15], [10, 15, 20], [10, 14, 18, 22], [0, 9, 15, n - 1]):
+    core.apply_U(planes[0], planes[1], haar_unitary(1 << len(pos), rng), pos)
+    print(pos, core.last_kernel_desc())
+core.sync()
+print('norm2', core.norm2(planes[0], planes[1]))
