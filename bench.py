@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument('--workload', default='rqc_1q2q', choices=['rqc_1q2q', 'dense_k34'])
     ap.add_argument('--dtype', default='complex64', choices=['complex64', 'complex128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fused', action='store_true', help='skip the fused (compress=4) variant')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-events', action='store_true', help='skip per-gate HIP events in the timed region')
     return ap.parse_args()
@@ -241,6 +242,35 @@ def main():
             'launches': len(per_class[dom]),
             'per_kernel_avg_ms': {c: float(np.mean(v)) for c, v in sorted(per_class.items())},
             'per_kernel_launches': {c: len(v) for c, v in sorted(per_class.items())},
+        }
+    if rank == 0 and world == 1 and not args.no_fused:
+        # The reference's DEFAULT driver setting fuses the circuit into <= 4-qubit gates first
+        # (compress=4, simulation.py:314,436-454; untimed there, :519).  Reported separately:
+        # same circuit, same state, fewer and larger gates; "logical" rates count the ORIGINAL
+        # gate applications.
+        from hybridq_amd.fusion import fuse
+        t_f = time.perf_counter()
+        fused = fuse(gates, 4, complex_type=args.dtype)
+        t_fuse = time.perf_counter() - t_f
+        fplan = [(U, [state.map[q] for q in reversed(qs)]) for U, qs in fused]
+        for U, pos in fplan:
+            core.apply_U(state.planes[0], state.planes[1], U, pos, n)
+        barrier()
+        t0f = time.perf_counter()
+        for _ in range(args.steps):
+            for U, pos in fplan:
+                core.apply_U(state.planes[0], state.planes[1], U, pos, n)
+        barrier()
+        el = (time.perf_counter() - t0f) / args.steps
+        result['fused'] = {
+            'max_n_qubits': 4,
+            'apply_U_calls_per_step': len(fplan),
+            'k_histogram': {str(k): sum(1 for _, p in fplan if len(p) == k) for k in range(1, 5)},
+            'ms_per_step': 1e3 * el,
+            'ms_per_call': 1e3 * el / len(fplan),
+            'logical_gate_apps_per_s': len(gates) / el,
+            'logical_amplitudes_per_s': len(gates) / el * float(1 << n),
+            'host_fusion_seconds_untimed': t_fuse,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -140,7 +140,8 @@ class HipBackend:
         core.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def empty_planes(self, m):
-        return self.torch.empty((2, 1 << m), dtype=self.tdt, device=self.device)
+        from .simulation import alloc_planes
+        return alloc_planes(m, self.tdt, self.device)  # re/im rows offset by PLANE_PAD_BYTES
 
     def fill_zero(self, planes):
         planes.zero_()

@@ -55,13 +55,31 @@ def _torch():
     return torch
 
 
+#: bytes between the end of the re plane and the start of the im plane.  With im = re + 2^n
+#: elements both planes map to the same HBM channel/bank for every index (power-of-two
+#: distance) and the two streams of every kernel fight for row buffers; an offset of a few
+#: 4 KiB pages removes that (measured at n=30, gpurun_out/sweep_pad*.txt: targets at positions
+#: >= 22 run 3-7 % faster, pairs of high targets up to 15 %).
+PLANE_PAD_BYTES = 12288
+
+
+def alloc_planes(n, torch_dtype, device):
+    """(2, 2^n) view of one allocation whose two rows are PLANE_PAD_BYTES further apart than
+    2^n elements.  planes[0] / planes[1] are contiguous, 32-byte aligned 1-D tensors."""
+    torch = _torch()
+    itemsize = torch.empty((), dtype=torch_dtype).element_size()
+    pad = PLANE_PAD_BYTES // itemsize if n >= 12 else 0
+    raw = torch.empty((2, (1 << n) + pad), dtype=torch_dtype, device=device)
+    return raw[:, :1 << n]
+
+
 def prepare_state_planes(initial_state, n, float_type, device):
     """Planes for an initial state given as a '01+-' string (hybridq/circuit/simulation/
     utils.py:41-156) or as an array of 2^n amplitudes.  Basis and all-'+' states are
     written by a device kernel; anything else is built on the host and uploaded."""
     torch = _torch()
     tdt = {np.dtype('float32'): torch.float32, np.dtype('float64'): torch.float64}[float_type]
-    planes = torch.empty((2, 1 << n), dtype=tdt, device=device)
+    planes = alloc_planes(n, tdt, device)
     if isinstance(initial_state, str):
         s = initial_state
         if len(s) == 1:
@@ -142,18 +160,19 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     reference routes elsewhere (einsum, tensor networks, Clifford) is out of scope.
     Supported kwargs: ``return_info``, ``return_numpy_array`` (default True),
     ``max_largest_intermediate`` (default 2**36 amplitudes: one MI355X holds n=34 in
-    complex64), ``compress`` (accepted; fusion is not implemented yet, must be 0/None),
-    ``device``.
+    complex64), ``compress`` (max qubits of a fused gate, default 4 like simulation.py:314;
+    0 applies the gates as given; a dict may carry ``max_n_qubits`` plus the keyword
+    arguments of ``fusion.fuse``), ``device``.  ``simplify`` (the reference's commuting-gate
+    reordering / inverse cancellation, circuit/utils.py:825) is a host-side IR transform
+    upstream of this path and is not reproduced: gates are fused in the order given.
     """
     if optimize not in ('evolution', 'evolution-hybridq'):
         raise ValueError(f"hybridq_amd only implements optimize='evolution' (got {optimize!r})")
     kwargs.setdefault('return_info', False)
     kwargs.setdefault('return_numpy_array', True)
     kwargs.setdefault('max_largest_intermediate', 2**36)
-    kwargs.setdefault('compress', 0)
+    kwargs.setdefault('compress', 4)  # simulation.py:314
     kwargs.setdefault('device', None)
-    if kwargs['compress'] not in (0, None):
-        warn("'compress' (gate fusion) is not implemented in hybridq_amd yet; applying gates as given.")
     if final_state is not None:  # simulation.py:415-418
         warn("'final_state' cannot be specified in optimize='evolution'. Ignoring 'final_state'.")
     if initial_state is None:  # simulation.py:421-423
@@ -162,6 +181,15 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     gates = [_gate_qubits_matrix(g) for g in circuit]
     qubits = kwargs.get('qubits') or all_qubits([(U, qs) for qs, U in gates])
     n = len(qubits)
+    n_given = len(gates)
+    # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519)
+    comp = kwargs['compress']
+    comp_kw = {k: v for k, v in comp.items() if k != 'max_n_qubits'} if isinstance(comp, dict) else {}
+    comp_n = comp.get('max_n_qubits', 4) if isinstance(comp, dict) else comp
+    if comp_n:
+        from .fusion import fuse
+        ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
+        gates = [(qs, U) for U, qs in fuse([(U, qs) for qs, U in gates], comp_n, complex_type=ctype, **comp_kw)]
     if 2**n > kwargs['max_largest_intermediate']:  # simulation.py:409-412
         raise MemoryError("Memory for the given number of qubits exceeds the 'max_largest_intermediate'.")
 
@@ -176,7 +204,8 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     core.sync()  # the ONLY synchronisation of the loop
     t1 = time.perf_counter()  # simulation.py:666
     info['runtime (s)'] = t1 - t0
-    info['n_gates'] = len(gates)
+    info['n_gates'] = len(gates)  # apply_U calls issued (after fusion)
+    info['n_gates_given'] = n_given
     info['n_qubits'] = n
 
     if kwargs['return_numpy_array']:

@@ -94,3 +94,35 @@ def test_dm_trace(oracle_port):
     assert np.abs(rho - exp).max() / np.abs(exp).max() < 5e-6
     r = rho.reshape(1 << (n // 2), 1 << (n // 2))
     assert abs(np.trace(r).real - 1) < 1e-5 and np.abs(r - r.conj().T).max() < 1e-6
+
+
+def test_fusion_reproduces_reference_compress():
+    """hybridq_amd.fusion.fuse == utils.compress + to_matrix_gate of the reference on the same
+    gate order: the fused matrices equal the ones the reference handed to apply_U (recorded
+    trace of get_rqc with compress=4, simplify=False), one for one."""
+    from hybridq_amd.fusion import compress, fuse, to_matrix_gate
+    z = gu.load('e2e_rqc.npz')
+    gates = gu.rqc_gates(z, 'a')
+    fused = fuse(gates, 4)
+    rec = [U for kind, pos, U in gu.trace(z, 'a_trace_') if kind == 'U']
+    assert len(fused) == len(rec) == 11
+    for (U, qs), Ur in zip(fused, rec):
+        assert U.shape == Ur.shape and np.abs(U - Ur).max() < 5e-7
+        assert list(qs) == sorted(qs)
+    # compress() layers + to_matrix_gate() agree with fuse(); compress=0 splits every gate
+    layers = compress(gates, 4)
+    assert sum(len(L) for L in layers) == len(gates)
+    for L, (U, qs) in zip(layers, fused):
+        U2, q2 = to_matrix_gate(L)
+        assert q2 == qs and np.abs(U2 - U).max() < 1e-6
+    assert len(fuse(gates, 0)) == len(gates)
+    # fused circuit == unfused circuit
+    n = int(z['n_qubits'])
+    a = oracle.evolve_tensordot(gates, n)
+    b = oracle.evolve_tensordot([(U.astype(np.complex128), qs) for U, qs in fuse(gates, 4, complex_type='complex128')], n)
+    assert np.abs(a - b).max() < 1e-12
+    for kmax in (2, 3, 5):
+        f = fuse(gates, kmax, complex_type='complex128')
+        assert max(len(qs) for _, qs in f) <= max(kmax, max(len(qs) for _, qs in gates))
+        b = oracle.evolve_tensordot(f, n, qubits=list(range(n)))
+        assert np.abs(a - b).max() < 1e-12

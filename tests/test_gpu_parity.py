@@ -282,12 +282,14 @@ def test_simulate_matches_reference_protocol(torch_cuda, oracle_port, ct):
     n = 16
     for gates in (random_dense(n, 80, kmax=4, seed=1), rqc_1q2q(n, depth=8, seed=2)):
         exp, _ = oracle.evolve_reference_protocol(oracle_port, gates, n, complex_type=ct)
-        psi, info = simulate(gates, initial_state='0' * n, complex_type=ct, return_info=True,
-                             qubits=list(range(n)))
-        psi = psi.reshape(-1)
         tol = 1e-6 if ct == 'complex64' else 1e-12
-        assert np.abs(psi - exp).max() / np.abs(exp).max() <= tol
-        assert info['runtime (s)'] > 0
+        for compress in (0, 4, 6):  # as given / the reference's default fusion / k>4 generic path
+            psi, info = simulate(gates, initial_state='0' * n, complex_type=ct, return_info=True,
+                                 qubits=list(range(n)), compress=compress)
+            psi = psi.reshape(-1)
+            assert np.abs(psi - exp).max() / np.abs(exp).max() <= tol * (1 if compress == 0 else 2)
+            assert info['runtime (s)'] > 0 and info['n_gates_given'] == len(gates)
+            assert (info['n_gates'] == len(gates)) == (compress == 0)
 
 
 def test_simulate_initial_states(torch_cuda):
