@@ -263,23 +263,26 @@ static void sort_gate(const T* U, const unsigned* pos, unsigned k, std::vector<T
 // ---------------------------------------------------------------------------------
 // matrix-core path (f32, k <= 4): role assignment + A-operand table (see hq_kernels.h)
 // ---------------------------------------------------------------------------------
+template <typename T>
 struct MfmaPlan {
   int kbits = 0, vmask = 0, ilp = 1;
   bool nt = false;
   unsigned n_addr = 0;
   MfmaRoles ro;
-  std::vector<float> A;
+  std::vector<T> A;
 };
 
-static bool plan_mfma(const Context& c, const float* U, const unsigned* pos, unsigned n, unsigned k,
-                      MfmaPlan& P) {
+template <typename T>
+static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigned n, unsigned k,
+                      MfmaPlan<T>& P) {
+  constexpr unsigned CB = Vec<T>::VB;  // vector-component index bits: 2 (f32) / 1 (f64)
   if (k < 1 || k > 4) return false;
-  std::vector<float> Us;
+  std::vector<T> Us;
   unsigned sp[kMaxK];
-  sort_gate<float>(U, pos, k, Us, sp);
+  sort_gate<T>(U, pos, k, Us, sp);
   const unsigned D = 1u << k;
-  const float* Ur = Us.data();
-  const float* Ui = Us.data() + (size_t)D * D;
+  const T* Ur = Us.data();
+  const T* Ui = Us.data() + (size_t)D * D;
   const unsigned k_eff = k <= 3 ? 3 : 4;
   P.kbits = (int)k_eff + 1;
   // effective digits: real targets (tbit = sorted target index) + identity dummies (tbit = -1)
@@ -292,17 +295,17 @@ static bool plan_mfma(const Context& c, const float* U, const unsigned* pos, uns
   // run) when a target occupies a vector component or for a single target at position
   // >= 5; in the free vector components otherwise.
   int dummy_low = c.dummy_policy;
-  if (dummy_low < 0) dummy_low = (sp[0] < 2 || (k == 1 && sp[0] >= 5)) ? 1 : 0;
-  for (unsigned p = dummy_low == 1 ? 2 : 0; p < n && E.size() < k_eff; ++p)
+  if (dummy_low < 0) dummy_low = (sp[0] < CB || (k == 1 && sp[0] >= 5)) ? 1 : 0;
+  for (unsigned p = dummy_low == 1 ? CB : 0; p < n && E.size() < k_eff; ++p)
     if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
-  for (unsigned p = 0; p < 2 && E.size() < k_eff; ++p)  // tiny n: fall back to the components
+  for (unsigned p = 0; p < CB && E.size() < k_eff; ++p)  // tiny n: fall back to the components
     if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
   if (E.size() < k_eff) return false;
   std::sort(E.begin(), E.end(), [](const Digit& a, const Digit& b) { return a.pos < b.pos; });
   int vmask = 0;
   std::vector<int> comp_digit, addr_digit;  // indices into E
   for (unsigned e = 0; e < k_eff; ++e) {
-    if (E[e].pos < 2) { vmask |= 1 << E[e].pos; comp_digit.push_back((int)e); }
+    if (E[e].pos < CB) { vmask |= 1 << E[e].pos; comp_digit.push_back((int)e); }
     else addr_digit.push_back((int)e);
   }
   P.vmask = vmask;
@@ -311,38 +314,38 @@ static bool plan_mfma(const Context& c, const float* U, const unsigned* pos, uns
   if (na < 1 || na > 4) return false;
   P.n_addr = na;
   P.ilp = std::max(1, 8 / NL);
-  if (n < 2 + na) return false;
-  const uint64_t nslots = 1ull << (n - 2 - na);
+  if (NR < 0 || n < CB + na) return false;
+  const uint64_t nslots = 1ull << (n - CB - na);
   if (nslots < (uint64_t)P.ilp * 64) return false;
   // roles: -1 = plane, otherwise index into E.  q gets the low address digits first
   // (positions 2..5: a permutation of a contiguous run), then the plane, then the rest.
   constexpr int PLANE = -1;
   std::vector<int> order;
-  for (int e : addr_digit) if (E[e].pos - 2 <= 3) order.push_back(e);
+  for (int e : addr_digit) if (E[e].pos - CB <= 3) order.push_back(e);
   order.push_back(PLANE);
-  for (int e : addr_digit) if (E[e].pos - 2 > 3) order.push_back(e);
+  for (int e : addr_digit) if (E[e].pos - CB > 3) order.push_back(e);
   const int qd[2] = {order[0], order[1]};
   std::vector<int> rd(order.begin() + 2, order.end());  // NR reg digits
   if ((int)rd.size() != NR) return false;
   MfmaRoles& ro = P.ro;
   for (int m = 0; m < 4; ++m) ro.pos[m] = 63;
-  for (unsigned m = 0; m < na; ++m) ro.pos[m] = E[addr_digit[m]].pos - 2;
+  for (unsigned m = 0; m < na; ++m) ro.pos[m] = E[addr_digit[m]].pos - CB;
   ro.q_plane = -1;
   ro.r_plane = -1;
   for (int b = 0; b < 2; ++b) {
-    ro.q_off[b] = qd[b] == PLANE ? 0u : (1u << (E[qd[b]].pos - 2));
+    ro.q_off[b] = qd[b] == PLANE ? 0u : (1u << (E[qd[b]].pos - CB));
     if (qd[b] == PLANE) ro.q_plane = b;
   }
   for (int b = 0; b < 3; ++b) ro.r_off[b] = 0;
   bool nt = true;
   for (int b = 0; b < NR; ++b) {
     if (rd[b] == PLANE) { ro.r_plane = b; continue; }
-    if (E[rd[b]].pos - 2 > 31) return false;  // offsets are 32-bit vec indices: index bit <= 33
-    ro.r_off[b] = 1u << (E[rd[b]].pos - 2);
+    if (E[rd[b]].pos - CB > 31) return false;  // offsets are 32-bit vec indices
+    ro.r_off[b] = 1u << (E[rd[b]].pos - CB);
     nt = nt && E[rd[b]].pos >= 6;
   }
   for (int b = 0; b < 2; ++b)
-    if (qd[b] != PLANE && E[qd[b]].pos - 2 > 31) return false;
+    if (qd[b] != PLANE && E[qd[b]].pos - CB > 31) return false;
   P.nt = c.nontemporal < 0 ? nt : c.nontemporal > 0;
   // decode a K index (q, step) into (plane, effective amplitude index over E)
   auto decode = [&](unsigned q, unsigned st, unsigned& plane, unsigned& teff) {
@@ -367,19 +370,21 @@ static bool plan_mfma(const Context& c, const float* U, const unsigned* pos, uns
     }
   };
   const int NSTEP = 1 << NS, NRB = 1 << (NS - 2);
-  P.A.assign((size_t)NRB * NSTEP * 64, 0.f);
+  P.A.assign((size_t)NRB * NSTEP * 64, (T)0);
   for (int rb = 0; rb < NRB; ++rb)
     for (int st = 0; st < NSTEP; ++st)
       for (unsigned lane = 0; lane < 64; ++lane) {
         const unsigned i = lane & 15, q_in = lane >> 4;
         unsigned po, to, pi, ti, tor, tod, tir, tid;
-        decode(i >> 2, (i & 3) | ((unsigned)rb << 2), po, to);
+        // D row of lane (q', j) register r: 4q'+r for the f32 MFMA, q'+4r for the f64 one
+        const unsigned q_out = sizeof(T) == 4 ? (i >> 2) : (i & 3), r_out = sizeof(T) == 4 ? (i & 3) : (i >> 2);
+        decode(q_out, r_out | ((unsigned)rb << 2), po, to);
         decode(q_in, (unsigned)st, pi, ti);
         split(to, tor, tod);
         split(ti, tir, tid);
-        float val = 0.f;
+        T val = 0;
         if (tod == tid) {
-          const float ur = Ur[tor * D + tir], ui = Ui[tor * D + tir];
+          const T ur = Ur[tor * D + tir], ui = Ui[tor * D + tir];
           val = po == pi ? ur : (po == 0 ? -ui : ui);
         }
         P.A[((size_t)rb * NSTEP + st) * 64 + lane] = val;
@@ -387,42 +392,53 @@ static bool plan_mfma(const Context& c, const float* U, const unsigned* pos, uns
   return true;
 }
 
-template <int KBITS, int VMASK>
-static void launch_mfma_kv(Context& c, float* re, float* im, const float* dA, const MfmaPlan& P,
-                           unsigned nblocks) {
+template <typename T, int KBITS, int VMASK>
+static void launch_mfma_kv(Context& c, T* re, T* im, const T* dA, const MfmaPlan<T>& P, unsigned nblocks) {
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NL = 1 << (NS - KV);
   constexpr int ILP = NL >= 8 ? 1 : 8 / NL;
   if (P.nt)
-    hipLaunchKernelGGL((apply_mfma_f32_kernel<KBITS, VMASK, ILP, true>), dim3(nblocks), dim3(kBlock), 0,
+    hipLaunchKernelGGL((apply_mfma_kernel<T, KBITS, VMASK, ILP, true>), dim3(nblocks), dim3(kBlock), 0,
                        c.stream, re, im, dA, P.ro);
   else
-    hipLaunchKernelGGL((apply_mfma_f32_kernel<KBITS, VMASK, ILP, false>), dim3(nblocks), dim3(kBlock), 0,
+    hipLaunchKernelGGL((apply_mfma_kernel<T, KBITS, VMASK, ILP, false>), dim3(nblocks), dim3(kBlock), 0,
                        c.stream, re, im, dA, P.ro);
 }
 
-static int launch_mfma(Context& c, float* re, float* im, const MfmaPlan& P, unsigned n) {
+template <typename T>
+static int launch_mfma(Context& c, T* re, T* im, const MfmaPlan<T>& P, unsigned n) {
+  constexpr unsigned CB = Vec<T>::VB;
   void* dA = nullptr;
-  if (arena_upload(c, P.A.data(), P.A.size() * sizeof(float), &dA)) return 1;
-  const uint64_t nslots = 1ull << (n - 2 - P.n_addr);
+  if (arena_upload(c, P.A.data(), P.A.size() * sizeof(T), &dA)) return 1;
+  const uint64_t nslots = 1ull << (n - CB - P.n_addr);
   const uint64_t nblocks64 = nslots / ((uint64_t)P.ilp * 64);
   if (nblocks64 == 0 || nblocks64 > 0x7fffffffull) return fail("mfma: grid out of range");
   const unsigned nb = (unsigned)nblocks64;
-  const float* A = (const float*)dA;
+  const T* A = (const T*)dA;
+  bool ok = true;
   switch (P.kbits * 4 + P.vmask) {
-    case 16: launch_mfma_kv<4, 0>(c, re, im, A, P, nb); break;
-    case 17: launch_mfma_kv<4, 1>(c, re, im, A, P, nb); break;
-    case 18: launch_mfma_kv<4, 2>(c, re, im, A, P, nb); break;
-    case 19: launch_mfma_kv<4, 3>(c, re, im, A, P, nb); break;
-    case 20: launch_mfma_kv<5, 0>(c, re, im, A, P, nb); break;
-    case 21: launch_mfma_kv<5, 1>(c, re, im, A, P, nb); break;
-    case 22: launch_mfma_kv<5, 2>(c, re, im, A, P, nb); break;
-    case 23: launch_mfma_kv<5, 3>(c, re, im, A, P, nb); break;
-    default: return fail("mfma: bad plan");
+    case 16: launch_mfma_kv<T, 4, 0>(c, re, im, A, P, nb); break;
+    case 17: launch_mfma_kv<T, 4, 1>(c, re, im, A, P, nb); break;
+    case 20: launch_mfma_kv<T, 5, 0>(c, re, im, A, P, nb); break;
+    case 21: launch_mfma_kv<T, 5, 1>(c, re, im, A, P, nb); break;
+    default:
+      if constexpr (CB == 2) {
+        switch (P.kbits * 4 + P.vmask) {
+          case 18: launch_mfma_kv<T, 4, 2>(c, re, im, A, P, nb); break;
+          case 19: launch_mfma_kv<T, 4, 3>(c, re, im, A, P, nb); break;
+          case 22: launch_mfma_kv<T, 5, 2>(c, re, im, A, P, nb); break;
+          case 23: launch_mfma_kv<T, 5, 3>(c, re, im, A, P, nb); break;
+          default: ok = false;
+        }
+      } else {
+        ok = false;
+      }
   }
+  if (!ok) return fail("mfma: bad plan");
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "mfma";
-  c.last_desc = "apply_mfma_f32_kernel<" + std::to_string(P.kbits) + ", " + std::to_string(P.vmask) + ", " +
-                std::to_string(P.ilp) + ", " + (P.nt ? "true" : "false") + ">";
+  c.last_desc = std::string("apply_mfma_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(P.kbits) + ", " + std::to_string(P.vmask) + ", " + std::to_string(P.ilp) + ", " +
+                (P.nt ? "true" : "false") + ">";
   return 0;
 }
 
@@ -499,16 +515,10 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
                         unsigned k) {
   const bool can_direct = direct_ok<T>(n, k, pos);
   const bool can_generic = (n - k) >= 2 && k <= kMaxK;
-  MfmaPlan plan;
+  MfmaPlan<T> plan;
   bool can_mfma = false;
-  if constexpr (std::is_same<T, float>::value) {
-    if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && k <= 4)
-      can_mfma = plan_mfma(c, U, pos, n, k, plan);
-  }
-  auto run_mfma = [&]() -> int {
-    if constexpr (std::is_same<T, float>::value) return launch_mfma(c, re, im, plan, n);
-    else return fail("mfma: f32 only");
-  };
+  if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && k <= 4) can_mfma = plan_mfma<T>(c, U, pos, n, k, plan);
+  auto run_mfma = [&]() -> int { return launch_mfma<T>(c, re, im, plan, n); };
   switch (c.mode) {
     case Mode::Direct:
       if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);

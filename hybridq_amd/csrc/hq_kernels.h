@@ -150,7 +150,7 @@ apply_direct_kernel(T* __restrict__ re, T* __restrict__ im, const GateArg<T, K> 
 }
 
 // ---------------------------------------------------------------------------------
-// apply_mfma (f32, k <= 4): the gate on the matrix cores, no LDS, no cross-lane traffic.
+// apply_mfma (f32 and f64, k <= 4): the gate on the matrix cores, no LDS, no cross-lane traffic.
 //
 // The complex 2^k x 2^k gate acts as the REAL 2^(k+1) x 2^(k+1) matrix [[Ur,-Ui],[Ui,Ur]]
 // on [re; im] (the same 8*2^k flops per amplitude as complex arithmetic).  The f32-input
@@ -165,7 +165,8 @@ apply_direct_kernel(T* __restrict__ re, T* __restrict__ im, const GateArg<T, K> 
 //                that bit, so low targets (positions 2..5) become a PERMUTATION of a
 //                contiguous run instead of a stride; if it is the plane digit, the lane
 //                reads/writes that plane only.
-//   * comp digit (VMASK):     component of the 16-byte vector (index bits 0..1); on the
+//   * comp digit (VMASK):     component of the 16-byte vector (index bits 0..1 for f32,
+//                bit 0 for f64); on the
 //                input side it selects the component fed to the MFMA step, on the
 //                output side the accumulator register lands in that component.
 //   * reg digit  (the rest):  a separate 16-byte load/store per value.
@@ -176,26 +177,43 @@ apply_direct_kernel(T* __restrict__ re, T* __restrict__ im, const GateArg<T, K> 
 // builds the A-operand table A[row-block][step][lane].
 // ---------------------------------------------------------------------------------
 struct MfmaRoles {
-  unsigned pos[4];    // vec positions (index bit - 2) of all address digits, ascending; 63 = unused
+  unsigned pos[4];    // vec positions (index bit - #component bits) of all address digits, ascending; 63 = unused
   unsigned q_off[2];  // vec offset carried by q bit b (0 if that digit is the plane)
   int q_plane;        // q bit that selects the plane, -1 if the plane is a reg digit
   unsigned r_off[3];  // vec offset carried by reg digit b (0 if plane)
   int r_plane;        // reg digit that selects the plane, -1 if the plane is a q digit
 };
 
-template <int KBITS, int VMASK, int ILP, bool NT>
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+  using acc = f32x4;
+  static __device__ __forceinline__ acc run(float a, float b, acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<double> {  // v_mfma_f64_16x16x4_f64: D row = (l>>4) + 4r (host table differs)
+  using acc = f64x4;
+  static __device__ __forceinline__ acc run(double a, double b, acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T, int KBITS, int VMASK, int ILP, bool NT>
 __global__ void __launch_bounds__(kBlock)
-apply_mfma_f32_kernel(float* __restrict__ re, float* __restrict__ im,
-                      const float* __restrict__ A, const MfmaRoles ro) {
+apply_mfma_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ A,
+                  const MfmaRoles ro) {
+  using V = typename Vec<T>::type;
+  using Acc = typename Mfma<T>::acc;
+  constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;  // vector components: 4 (f32) / 2 (f64)
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
-  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (2 - KV), NSTEP = 1 << NS;
-  constexpr int FMASK = ~VMASK & 3;
+  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS;
+  constexpr int FMASK = ~VMASK & (NCOMP - 1);
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, j = lane & 15;
-  f32x4* __restrict__ pre = reinterpret_cast<f32x4*>(re);
-  f32x4* __restrict__ pim = reinterpret_cast<f32x4*>(im);
+  V* __restrict__ pre = reinterpret_cast<V*>(re);
+  V* __restrict__ pim = reinterpret_cast<V*>(im);
 
-  float a[NRB][NSTEP];
+  T a[NRB][NSTEP];
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -215,8 +233,8 @@ apply_mfma_f32_kernel(float* __restrict__ re, float* __restrict__ im,
     pl[ld] = ro.r_plane >= 0 ? ((ld >> ro.r_plane) & 1u) : 0u;
   }
 
-  f32x4 x[ILP][NL];
-  f32x4* ptr[ILP][NL];
+  V x[ILP][NL];
+  V* ptr[ILP][NL];
 #pragma unroll
   for (int i = 0; i < ILP; ++i) {
     uint64_t v = (((uint64_t)blockIdx.x * ILP + i) * (kBlock / 64) + wave) * 16 + j;
@@ -236,11 +254,11 @@ apply_mfma_f32_kernel(float* __restrict__ re, float* __restrict__ im,
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < ILP; ++i) {
-    f32x4 acc[NCB][NRB];
+    Acc acc[NCB][NRB];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf)
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Acc{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       const int ck = s & ((1 << KV) - 1), ld = s >> KV;
@@ -249,14 +267,14 @@ apply_mfma_f32_kernel(float* __restrict__ re, float* __restrict__ im,
         const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
-          acc[cf][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][s], x[i][ld][comp], acc[cf][rb], 0, 0, 0);
+          acc[cf][rb] = Mfma<T>::run(a[rb][s], x[i][ld][comp], acc[cf][rb]);
       }
     }
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
-      f32x4 y;
+      V y;
 #pragma unroll
-      for (int comp = 0; comp < 4; ++comp) {
+      for (int comp = 0; comp < NCOMP; ++comp) {
         const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
         const int so = ck | (ld << KV);
         y[comp] = acc[cf][so >> 2][so & 3];

@@ -28,6 +28,23 @@ from . import core
 _FLOAT_OF = {np.dtype('complex64'): np.dtype('float32'), np.dtype('complex128'): np.dtype('float64')}
 
 
+class FunctionalGate:
+    """Minimal stand-in for ``hybridq.gate.property.FunctionalGate`` (property.py:732): a gate
+    given as ``apply(psi, order) -> (new_psi, new_order)`` acting on the raw split-plane
+    state ``psi`` of shape (2,) + (2,)*n (simulation.py:525-554).  Reference FunctionalGate
+    objects (anything with ``.qubits`` and ``.apply`` but no ``.matrix``) are accepted too."""
+
+    def __init__(self, qubits, apply, name='FN'):
+        self.qubits = tuple(qubits)
+        self.apply = apply
+        self.name = name
+
+
+def _is_functional(gate):
+    return (not isinstance(gate, (tuple, list)) and callable(getattr(gate, 'apply', None)) and
+            not hasattr(gate, 'matrix'))
+
+
 def _gate_qubits_matrix(gate):
     """Accept ``(U, qubits)`` pairs or reference-style gate objects exposing
     ``.qubits`` and ``.matrix()`` (``gate.provides(['qubits','matrix'])``, :556)."""
@@ -36,12 +53,12 @@ def _gate_qubits_matrix(gate):
         return tuple(qs), np.asarray(U)
     if hasattr(gate, 'qubits') and hasattr(gate, 'matrix'):
         return tuple(gate.qubits), np.asarray(gate.matrix())
-    raise RuntimeError(f"'{gate}' not supported")
+    raise RuntimeError(f"'{gate}' not supported")  # simulation.py:648-649
 
 
 def all_qubits(circuit):
     """Sorted qubit labels (hybridq/circuit/circuit.py:406-451)."""
-    qs = {q for g in circuit for q in _gate_qubits_matrix(g)[0]}
+    qs = {q for g in circuit for q in (g.qubits if _is_functional(g) else _gate_qubits_matrix(g)[0])}
     try:
         return sorted(qs)
     except TypeError:  # heterogeneous labels: order by (type name, value) like utils.sort
@@ -138,6 +155,21 @@ class EvolutionState:
         pos = [self.map[q] for q in reversed(qubits)]  # simulation.py:633
         core.apply_U(self.planes[0], self.planes[1], U, pos, self.n)
 
+    def apply_functional(self, gate):
+        """FunctionalGate branch of the loop (simulation.py:525-554): the gate receives the raw
+        (2,)+(2,)*n real array and the current qubit order.  Reference functional gates are
+        host numpy code, so the state makes a D2H/H2D round trip here (rare; device-side
+        projection/measurement are the "next" row of SURVEY 8f)."""
+        torch = _torch()
+        core.sync()
+        order = tuple(q for q, _ in sorted(self.map.items(), key=lambda x: x[1])[::-1])  # :528-530
+        host = self.planes.cpu().numpy().reshape((2,) + (2,) * self.n)
+        new_psi, new_order = gate.apply(psi=host, order=order)
+        if any(x != y for x, y in zip(order, new_order)):  # :552-554
+            raise RuntimeError("'order' has changed.")
+        new_psi = np.ascontiguousarray(new_psi, dtype=self.float_type).reshape(2, -1)
+        self.planes.copy_(torch.from_numpy(new_psi))
+
     def to_complex(self):
         """Interleave the planes into a complex torch tensor on the device (:669-675)."""
         torch = _torch()
@@ -178,18 +210,36 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     if initial_state is None:  # simulation.py:421-423
         raise ValueError("'initial_state' must be specified for optimize='evolution'.")
 
-    gates = [_gate_qubits_matrix(g) for g in circuit]
-    qubits = kwargs.get('qubits') or all_qubits([(U, qs) for qs, U in gates])
+    circuit = list(circuit)
+    qubits = kwargs.get('qubits') or all_qubits(circuit)
     n = len(qubits)
-    n_given = len(gates)
-    # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519)
+    n_given = len(circuit)
+    # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519).
+    # FunctionalGates are never fused (skip_compression=[FunctionalGate], :441): the circuit
+    # is cut at them and every run of matrix gates is fused on its own.
     comp = kwargs['compress']
     comp_kw = {k: v for k, v in comp.items() if k != 'max_n_qubits'} if isinstance(comp, dict) else {}
     comp_n = comp.get('max_n_qubits', 4) if isinstance(comp, dict) else comp
-    if comp_n:
-        from .fusion import fuse
-        ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
-        gates = [(qs, U) for U, qs in fuse([(U, qs) for qs, U in gates], comp_n, complex_type=ctype, **comp_kw)]
+    ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
+    gates, run = [], []
+
+    def flush():
+        if not run:
+            return
+        if comp_n:
+            from .fusion import fuse
+            gates.extend((qs, U) for U, qs in fuse([(U, qs) for qs, U in run], comp_n, complex_type=ctype, **comp_kw))
+        else:
+            gates.extend(run)
+        run.clear()
+
+    for g in circuit:
+        if _is_functional(g):
+            flush()
+            gates.append(g)
+        else:
+            run.append(_gate_qubits_matrix(g))
+    flush()
     if 2**n > kwargs['max_largest_intermediate']:  # simulation.py:409-412
         raise MemoryError("Memory for the given number of qubits exceeds the 'max_largest_intermediate'.")
 
@@ -199,8 +249,11 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     info = {}
     core.sync()
     t0 = time.perf_counter()  # simulation.py:519
-    for qs, U in gates:
-        state.apply(U, qs)
+    for g in gates:
+        if _is_functional(g):
+            state.apply_functional(g)
+        else:
+            state.apply(g[1], g[0])
     core.sync()  # the ONLY synchronisation of the loop
     t1 = time.perf_counter()  # simulation.py:666
     info['runtime (s)'] = t1 - t0

@@ -79,17 +79,16 @@ def test_apply_U_matches_oracle(torch_cuda, oracle_port, ft, k):
         gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
         err = _relerr(gr, gi, orr, oi)
         assert err <= TOL[ft], (ft, k, pos, kern, err)
-        if k <= 4 and ft == np.dtype('float32'):
-            assert kern == 'mfma', kern  # matrix-core path, any target position
-        elif k <= 3:
-            assert kern == 'direct', kern
+        if k <= 4:
+            assert kern == 'mfma', kern  # matrix-core path (f32 and f64), any target position
 
 
-def test_apply_U_mfma_kernels(torch_cuda, oracle_port):
-    """complex64 k=1..4 on the matrix cores (real-embedded f32 MFMA, role-assigned index
-    digits): every role combination -- targets in the vector components (bits 0,1), in the
-    permuted lane range (bits 2..5), high, unsorted -- with non-unitary U."""
-    ft = np.dtype('float32')
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+def test_apply_U_mfma_kernels(torch_cuda, oracle_port, ft):
+    """k=1..4 on the matrix cores (real-embedded f32 / f64 MFMA, role-assigned index
+    digits): every role combination -- targets in the vector components (bits 0,1 / bit 0),
+    in the permuted lane range, high, unsorted -- with non-unitary U."""
+    ft = np.dtype(ft)
     n = 18
     rng = np.random.default_rng(77)
     cases = {
@@ -353,3 +352,37 @@ def test_sharded_single_rank_matches_oracle(torch_cuda, oracle_port):
     psi = sh.state_numpy()
     assert np.abs(psi - exp).max() / np.abs(exp).max() < 1e-6
     assert abs(sh.norm2() - float(np.vdot(exp, exp).real)) < 1e-4 * float(np.vdot(exp, exp).real)
+
+
+def test_simulate_functional_gate_branch(torch_cuda, oracle_port):
+    """simulation.py:525-554: a FunctionalGate receives the raw (2,)+(2,)*n split-plane state
+    and the qubit order; matrix gates around it are fused separately (never across it)."""
+    import oracle
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.simulation import FunctionalGate, simulate
+    n = 12
+    seen = {}
+
+    def project_q3_to_1(psi, order):  # numpy code in the style of gate/projection.py:72-119
+        seen['shape'], seen['order'] = psi.shape, order
+        ax = order.index(3)
+        new = np.zeros_like(psi)
+        idx = [slice(None)] * psi.ndim
+        idx[ax + 1] = 1
+        new[tuple(idx)] = psi[tuple(idx)]
+        new /= np.linalg.norm(new.ravel())
+        return new, order
+
+    g1, g2 = random_dense(n, 30, kmax=3, seed=1, unitary=True), random_dense(n, 30, kmax=3, seed=2, unitary=True)
+    circuit = list(g1) + [FunctionalGate((3,), project_q3_to_1)] + list(g2)
+    psi, info = simulate(circuit, initial_state='+' * n, complex_type='complex128', return_info=True)
+    assert seen['shape'] == (2,) + (2,) * n and seen['order'] == tuple(range(n))
+    a = oracle.evolve_tensordot(g1, n, initial_state=np.full(1 << n, 2.0**(-n / 2)), qubits=list(range(n)))
+    a = a.reshape((2,) * n).copy()
+    idx = [slice(None)] * n
+    idx[3] = 0
+    a[tuple(idx)] = 0
+    a /= np.linalg.norm(a.ravel())
+    exp = oracle.evolve_tensordot(g2, n, initial_state=a.reshape(-1), qubits=list(range(n)))
+    assert np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max() < 1e-12
+    assert info['n_gates'] < len(circuit)  # fused on both sides of the functional gate
