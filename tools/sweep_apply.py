@@ -47,11 +47,14 @@ def timeit(pos, mode, reps=8):
 
 H = n - 1
 cases = []
-for pos in ([12], [20], [H], [0], [1], [2], [3], [4], [5], [6], [7], [9]):
-    cases += [(pos, 'mfma+dummy=comp'), (pos, 'mfma+dummy=low'), (pos, 'mfma+dummy=low+nt=0'), (pos, 'direct')]
-for pos in ([12, 20], [H - 1, H], [0, 15], [1, H], [2, 20], [5, 20], [3, 4], [8, 9], [0, 3]):
-    cases += [(pos, 'mfma+dummy=comp'), (pos, 'mfma+dummy=low'), (pos, 'direct')]
-if dt != 'float32':
-    cases = [c for c in cases if 'mfma' not in c[1]]
+for pos in ([12], [20], [H], [0], [1], [2], [3], [5], [7]):
+    cases += [(pos, 'mfma'), (pos, 'direct')]
+for pos in ([12, 20], [H - 1, H], [0, 15], [1, H], [2, 20], [3, 4], [8, 9], [0, 3], [0, 1]):
+    cases += [(pos, 'mfma'), (pos, 'direct')]
+for pos in ([10, 15, 20], [0, 1, 2], [0, 9, 17], [2, 3, 4], [3, 12, 21], [H - 2, H - 1, H]):
+    cases += [(pos, 'mfma'), (pos, 'direct')]
+for pos in ([10, 14, 18, 22], [0, 1, 2, 3], [0, 9, 15, H], [1, 4, 15, 20], [2, 3, 4, 5], [6, 7, 8, 9]):
+    cases += [(pos, 'mfma'), (pos, 'generic')]
+cases += [([8, 9, 10, 11, 12], 'auto'), ([3, 9, 14, 20, 25], 'auto'), ([8, 9, 10, 11, 12, 13], 'auto')]
 for pos, mode in cases:
     timeit(pos, mode)
