@@ -483,6 +483,67 @@ static int launch_generic(Context& c, T* re, T* im, const T* U, const unsigned* 
   return 0;
 }
 
+// k = 5, 6: LDS-staged tile GEMM on the matrix cores (apply_mfma_tile_kernel)
+template <typename T>
+static bool mfma_tile_ok(unsigned n, unsigned k) {
+  const unsigned tile_bits = sizeof(T) == 4 ? 12 : 11;
+  return (k == 5 || k == 6) && n >= tile_bits;
+}
+
+template <typename T>
+static int launch_mfma_tile(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                            unsigned k) {
+  const unsigned tile_bits = sizeof(T) == 4 ? 12 : 11;
+  GenArg a;
+  memset(&a, 0, sizeof(a));
+  a.k = k;
+  a.c = tile_bits - k;
+  uint64_t tmask = 0;
+  for (unsigned j = 0; j < k; ++j) {
+    a.tpos[j] = pos[j];
+    tmask |= 1ull << pos[j];
+  }
+  unsigned nc = 0;
+  for (unsigned p = 0; p < n && nc < a.c; ++p)
+    if (!((tmask >> p) & 1)) a.cpos[nc++] = p;
+  std::vector<unsigned> all(a.tpos, a.tpos + k);
+  all.insert(all.end(), a.cpos, a.cpos + a.c);
+  std::sort(all.begin(), all.end());
+  for (unsigned j = 0; j < k + a.c; ++j) a.apos[j] = all[j];
+  constexpr unsigned VB = Vec<T>::VB;
+  a.vec_ok = 1;
+  for (unsigned b = 0; b < VB; ++b) a.vec_ok &= (a.cpos[b] == b) ? 1u : 0u;
+  // A-operand table: A[row block][step][lane] = M[16 rb + (lane & 15)][4 step + (lane >> 4)],
+  // M = [[Ur,-Ui],[Ui,Ur]] with row/column index = plane * 2^k + t (t in the caller's bit order)
+  const unsigned D = 1u << k, E = 2 * D, NSTEP = E / 4, NRBT = E / 16;
+  std::vector<T> A((size_t)NRBT * NSTEP * 64);
+  for (unsigned rb = 0; rb < NRBT; ++rb)
+    for (unsigned st = 0; st < NSTEP; ++st)
+      for (unsigned lane = 0; lane < 64; ++lane) {
+        const unsigned row = 16 * rb + (lane & 15), col = 4 * st + (lane >> 4);
+        const unsigned po = row / D, to = row % D, pi = col / D, ti = col % D;
+        const T ur = U[2 * ((size_t)to * D + ti)], ui = U[2 * ((size_t)to * D + ti) + 1];
+        A[((size_t)rb * NSTEP + st) * 64 + lane] = po == pi ? ur : (po == 0 ? -ui : ui);
+      }
+  void* dA = nullptr;
+  if (arena_upload(c, A.data(), A.size() * sizeof(T), &dA)) return 1;
+  const size_t C = (size_t)1 << a.c;
+  const size_t lds = D * 8 + C * 4 + 2 * (size_t)D * C * sizeof(T);
+  const uint64_t nblocks = 1ull << (n - tile_bits);
+  const unsigned grid = (unsigned)std::min<uint64_t>(nblocks, 256 * 4);
+  if (k == 5)
+    hipLaunchKernelGGL((apply_mfma_tile_kernel<T, 5>), dim3(grid), dim3(kBlock), lds, c.stream, re, im,
+                       (const T*)dA, a, nblocks);
+  else
+    hipLaunchKernelGGL((apply_mfma_tile_kernel<T, 6>), dim3(grid), dim3(kBlock), lds, c.stream, re, im,
+                       (const T*)dA, a, nblocks);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "mfma_tile";
+  c.last_desc = std::string("apply_mfma_tile_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(k) + ">";
+  return 0;
+}
+
 template <typename T>
 static int launch_naive(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
                         unsigned k) {
@@ -536,6 +597,8 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
   }
   if (can_mfma) return run_mfma();
   if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
+  if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && mfma_tile_ok<T>(n, k))
+    return launch_mfma_tile<T>(c, re, im, U, pos, n, k);
   if (can_generic) return launch_generic<T>(c, re, im, U, pos, n, k);
   return launch_naive<T>(c, re, im, U, pos, n, k);
 }

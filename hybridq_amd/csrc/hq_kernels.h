@@ -379,6 +379,127 @@ apply_generic_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict
 }
 
 // ---------------------------------------------------------------------------------
+// apply_mfma_tile (k = 5, 6): LDS-staged tile GEMM on the matrix cores.
+//
+// Same workgroup tile as apply_generic (2^k target rows x C = 2^c lowest non-target
+// columns, both planes, 32 KiB of LDS) but the dense product is the REAL 2^(k+1)-square
+// embedded matrix M = [[Ur,-Ui],[Ui,Ur]] (row/column index = plane*2^k + t) applied with
+// v_mfma_*_16x16x4: wave w owns the output row blocks {w*RBW .. w*RBW+RBW-1} for every
+// column of the tile, keeps its A operands (rows of M) in registers for the whole launch,
+// reads B operands from LDS as 16-byte vectors (one ds_read_b128 feeds CW MFMAs: the CW
+// vector components are CW column blocks) and streams the result registers straight back
+// to HBM (the inputs of the tile are safe in LDS, so the update is in place).
+// k = 5 needs 57 % of the f32 MFMA peak at full HBM rate, k = 6 is MFMA-bound (512 flop per
+// amplitude: >= 3.5 ms at n = 30).
+// ---------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ void __launch_bounds__(kBlock)
+apply_mfma_tile_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ A,
+                       const GenArg a, const uint64_t nblocks) {
+  using V = typename Vec<T>::type;
+  using Acc = typename Mfma<T>::acc;
+  constexpr int CW = 1 << Vec<T>::VB;                 // components of a 16-byte vector
+  constexpr int D = 1 << K, E = 2 * D, NSTEP = E / 4, NRBT = E / 16, RBW = NRBT / 4;
+  constexpr int CBITS = (sizeof(T) == 4 ? 12 : 11) - K, C = 1 << CBITS, NCG = C / (16 * CW);
+  static_assert(NCG >= 1 && RBW >= 1, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* toff = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* coff = reinterpret_cast<uint32_t*>(toff + D);
+  T* xr = reinterpret_cast<T*>(coff + C);
+  T* xi = xr + (size_t)D * C;
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned q = lane >> 4, j = lane & 15;
+
+  for (unsigned i = tid; i < (unsigned)D; i += kBlock) {
+    uint64_t o = 0;
+    for (unsigned b = 0; b < (unsigned)K; ++b) o |= (uint64_t)((i >> b) & 1u) << a.tpos[b];
+    toff[i] = o;
+  }
+  for (unsigned i = tid; i < (unsigned)C; i += kBlock) {
+    uint32_t o = 0;
+    for (unsigned b = 0; b < (unsigned)CBITS; ++b) o |= ((i >> b) & 1u) << a.cpos[b];
+    coff[i] = o;
+  }
+  T areg[RBW][NSTEP];
+#pragma unroll
+  for (int i = 0; i < RBW; ++i)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) areg[i][s] = A[((size_t)(wave * RBW + i) * NSTEP + s) * 64 + lane];
+  __syncthreads();
+
+  constexpr unsigned CV = C / CW;  // 16-byte vectors per tile row
+  for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    uint64_t base = b;
+    for (unsigned m = 0; m < (unsigned)(K + CBITS); ++m) {
+      const uint64_t lo = (1ull << a.apos[m]) - 1;
+      base = ((base & ~lo) << 1) | (base & lo);
+    }
+    // stage the tile: rows t, columns c (16-byte vectors when the low index bits are columns)
+    for (unsigned e = tid; e < (unsigned)D * CV; e += kBlock) {
+      const unsigned t = e / CV, cv = e % CV;
+      const uint64_t idx = base | toff[t];
+      V vr, vi;
+      if (a.vec_ok) {
+        vr = *reinterpret_cast<const V*>(re + (idx | coff[CW * cv]));
+        vi = *reinterpret_cast<const V*>(im + (idx | coff[CW * cv]));
+      } else {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          vr[c] = re[idx | coff[CW * cv + c]];
+          vi[c] = im[idx | coff[CW * cv + c]];
+        }
+      }
+      *reinterpret_cast<V*>(xr + (size_t)t * C + CW * cv) = vr;
+      *reinterpret_cast<V*>(xi + (size_t)t * C + CW * cv) = vi;
+    }
+    __syncthreads();
+    Acc acc[RBW][NCG][CW];
+#pragma unroll
+    for (int i = 0; i < RBW; ++i)
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) acc[i][cg][c] = Acc{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const unsigned kk = 4 * s + q;  // K-row of this lane group: plane*D + t
+      const T* xp = (kk >= (unsigned)D ? xi : xr) + (size_t)(kk & (D - 1)) * C;
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        const V bv = *reinterpret_cast<const V*>(xp + (cg * 16 + j) * CW);
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+#pragma unroll
+          for (int i = 0; i < RBW; ++i) acc[i][cg][c] = Mfma<T>::run(areg[i][s], bv[c], acc[i][cg][c]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RBW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // D row of lane (q, j) register r inside its 16-row block: 4q+r (f32) / q+4r (f64)
+        const unsigned row = 16 * (wave * RBW + i) + (sizeof(T) == 4 ? 4 * q + r : q + 4 * r);
+        T* plane = row >= (unsigned)D ? im : re;
+        const uint64_t idx = base | toff[row & (D - 1)];
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) {
+          const unsigned col0 = (cg * 16 + j) * CW;
+          V y;
+#pragma unroll
+          for (int c = 0; c < CW; ++c) y[c] = acc[i][cg][c][r];
+          if (a.vec_ok) {
+            *reinterpret_cast<V*>(plane + (idx | coff[col0])) = y;
+          } else {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) plane[idx | coff[col0 + c]] = y[c];
+          }
+        }
+      }
+    __syncthreads();  // LDS is restaged by the next tile
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // apply_naive: out-of-place, one thread per output amplitude (tiny states only)
 // ---------------------------------------------------------------------------------
 struct NaiveArg {

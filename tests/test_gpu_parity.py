@@ -81,6 +81,8 @@ def test_apply_U_matches_oracle(torch_cuda, oracle_port, ft, k):
         assert err <= TOL[ft], (ft, k, pos, kern, err)
         if k <= 4:
             assert kern == 'mfma', kern  # matrix-core path (f32 and f64), any target position
+        else:
+            assert kern == 'mfma_tile', kern  # k = 5, 6: LDS-staged tile GEMM on the matrix cores
 
 
 @pytest.mark.parametrize('ft', ['float32', 'float64'])

@@ -47,14 +47,8 @@ def timeit(pos, mode, reps=8):
 
 H = n - 1
 cases = []
-for pos in ([12], [20], [H], [0], [1], [2], [3], [5], [7]):
-    cases += [(pos, 'mfma'), (pos, 'direct')]
-for pos in ([12, 20], [H - 1, H], [0, 15], [1, H], [2, 20], [3, 4], [8, 9], [0, 3], [0, 1]):
-    cases += [(pos, 'mfma'), (pos, 'direct')]
-for pos in ([10, 15, 20], [0, 1, 2], [0, 9, 17], [2, 3, 4], [3, 12, 21], [H - 2, H - 1, H]):
-    cases += [(pos, 'mfma'), (pos, 'direct')]
-for pos in ([10, 14, 18, 22], [0, 1, 2, 3], [0, 9, 15, H], [1, 4, 15, 20], [2, 3, 4, 5], [6, 7, 8, 9]):
-    cases += [(pos, 'mfma'), (pos, 'generic')]
-cases += [([8, 9, 10, 11, 12], 'auto'), ([3, 9, 14, 20, 25], 'auto'), ([8, 9, 10, 11, 12, 13], 'auto')]
+for pos in ([8, 9, 10, 11, 12], [3, 9, 14, 20, 25], [0, 1, 2, 3, 4], [2, 3, 4, 5, 6], [0, 7, 13, 21, H], [H - 4, H - 3, H - 2, H - 1, H],
+            [8, 9, 10, 11, 12, 13], [1, 5, 9, 14, 20, 25], [0, 1, 2, 3, 4, 5], [H - 5, H - 4, H - 3, H - 2, H - 1, H]):
+    cases += [(pos, 'auto'), (pos, 'generic')]
 for pos, mode in cases:
     timeit(pos, mode)
