@@ -388,3 +388,68 @@ def test_simulate_functional_gate_branch(torch_cuda, oracle_port):
     exp = oracle.evolve_tensordot(g2, n, initial_state=a.reshape(-1), qubits=list(range(n)))
     assert np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max() < 1e-12
     assert info['n_gates'] < len(circuit)  # fused on both sides of the functional gate
+
+
+@pytest.mark.parametrize('t', ['float32', 'float64'])
+@pytest.mark.parametrize('k', [2, 3, 4, 5, 6])
+def test_dot_api(torch_cuda, t, k):
+    """Reference tests.py:299-391 (test_utils__dot) against hybridq_amd.dot: split-plane and
+    complex inputs, inplace, swap_back=False, vs the explicit numpy path."""
+    from hybridq_amd.dot import aligned_empty, dot
+    from hybridq_amd.transpose import transpose
+    rng = np.random.default_rng(100 + k)
+    n = 14
+    tol = dict(rtol=1e-3, atol=1e-3)  # the reference's own bar (tests.py:56-62) ...
+    tight = 1e-5 if t == 'float32' else 1e-12  # ... and ours
+    for _ in range(3):
+        psi = rng.random((2, 2**n)).astype(t)
+        psi = (psi.T / np.linalg.norm(psi, axis=1)).T
+        psi1 = np.array(psi)
+        psi2 = aligned_empty(psi.shape, t)
+        psi2[...] = psi
+        U = (rng.random((2**k, 2**k)) + 1j * rng.random((2**k, 2**k))).astype((1j * psi[0][:1]).dtype)
+        axes_b = rng.choice(n, size=k, replace=False)
+        shp = (2,) * (n + 1)
+        b1 = dot(U, np.reshape(psi1, shp), axes_b=axes_b, b_as_complex_array=True, force_numpy=True)
+        b1h = dot(U, np.reshape(psi1, shp), axes_b=axes_b, b_as_complex_array=True, raise_if_hcore_fails=True)
+        p2 = dot(U, np.reshape(psi2, shp), axes_b=axes_b, b_as_complex_array=True, inplace=True,
+                 raise_if_hcore_fails=True)
+        np.testing.assert_allclose(psi, psi1)  # not modified unless inplace
+        np.testing.assert_allclose(b1, b1h, **tol)
+        assert np.abs(np.asarray(b1) - b1h).max() < tight * 2**k
+        np.testing.assert_allclose(p2, b1h, **tol)
+        assert np.shares_memory(p2, psi2)
+        no_tr, tr1 = dot(U, np.reshape(psi, shp), axes_b=axes_b, b_as_complex_array=True, swap_back=False,
+                         raise_if_hcore_fails=True)
+        assert tr1 is None
+        np.testing.assert_allclose(b1, no_tr, **tol)
+        c = np.reshape(psi[0] + 1j * psi[1], (2,) * n)
+        b2 = dot(U, c, axes_b=axes_b, force_numpy=True)
+        b2h = dot(U, c, axes_b=axes_b, raise_if_hcore_fails=True)
+        np.testing.assert_allclose(b2, b2h, **tol)
+        assert np.abs(b2 - b2h).max() < tight * 2**k
+    # device-resident planes
+    torch = torch_cuda
+    d = torch.from_numpy(np.reshape(psi, shp)).cuda()
+    out = dot(U, d, axes_b=axes_b, b_as_complex_array=True, inplace=True)
+    assert out.data_ptr() == d.data_ptr()
+    np.testing.assert_allclose(d.cpu().numpy(), b1h, **tol)
+
+
+@pytest.mark.parametrize('t', ['float32', 'float64', 'int32', 'int64', 'uint32', 'uint64'])
+def test_transpose_api(torch_cuda, t):
+    """Reference tests.py:256-296 (test_utils__transpose): exact equality with np.transpose."""
+    from hybridq_amd.transpose import transpose
+    rng = np.random.default_rng(5)
+    n = 14
+    v = np.reshape(rng.integers(0, 2**31 - 1, 2**n).astype(t), (2,) * n)
+    v0 = np.array(v)
+    axes = rng.permutation(n)
+    v1 = transpose(v, axes, force_numpy=True)
+    v1h = transpose(v, axes, raise_if_hcore_fails=True)
+    assert (v == v0).all() and (v1 == v1h).all()
+    v2 = np.array(v)
+    v2h = transpose(v2, axes, inplace=True, raise_if_hcore_fails=True)
+    assert (v1 == v2h).all() and np.shares_memory(v2, v2h)
+    axes = np.concatenate([np.arange(n - 6), n - 6 + rng.permutation(6)])
+    assert (transpose(v, axes, force_numpy=True) == transpose(v, axes, raise_if_hcore_fails=True)).all()
