@@ -23,6 +23,9 @@ What is recorded
   e2e_dm.npz          a 6-qubit circuit with depolarizing noise through
                       hybridq.dm.circuit.simulation.simulate (-> 12-qubit state vector):
                       the C-ABI call trace (swaps + fused NON-unitary gates) and the final rho.
+  e2e_dm_circuit.npz  the same noisy circuit UNFUSED, as data: unitaries, Kraus operators,
+                      weights and the reference's superoperator matrices (python
+                      make_golden.py dm_circuit).
 The import of the reference Python needs stand-ins for three absent third-party modules
 (opt_einsum, more_itertools, numba); none of them is on the evolution-hybridq path except
 numba.vectorize for '+-' initial states.
@@ -260,7 +263,46 @@ def end_to_end():
           'calls =', ''.join(k for k, _, _ in tr.calls))
 
 
+def dm_circuit():
+    """e2e_dm_circuit.npz: the UNFUSED noisy circuit of e2e_dm.npz as data -- unitary gates
+    (U, qubits) and channels (Kraus operators L_i = R_i, weights s_i, qubits, and the
+    superoperator matrix gate.map() the reference builds from them) -- plus the final rho."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    import hybridq.dm.circuit.simulation as dmsim
+    from hybridq.extras.random import get_rqc
+    from hybridq.noise.utils import add_depolarizing_noise
+    np.random.seed(4321)
+    nq = 6
+    circ = get_rqc(nq, 20, use_random_indexes=False)
+    noisy = add_depolarizing_noise(circ, probs=(0.01, 0.02))
+    out = {'n_qubits': nq, 'n_items': len(noisy)}
+    kinds = ''
+    for i, g in enumerate(noisy):
+        out[f'q{i}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+        if hasattr(g, 'Kraus'):
+            kinds += 'K'
+            L, R = g.Kraus.gates
+            out[f'L{i}'] = np.stack([np.asarray(x.matrix(), dtype=np.complex128) for x in L])
+            out[f'R{i}'] = np.stack([np.asarray(x.matrix(), dtype=np.complex128) for x in R])
+            out[f's{i}'] = np.asarray(g.Kraus.s, dtype=np.float64)
+            out[f'M{i}'] = np.asarray(g.map(), dtype=np.complex128)
+        else:
+            kinds += 'U'
+            out[f'U{i}'] = np.asarray(g.matrix(), dtype=np.complex128)
+    out['kinds'] = np.frombuffer(kinds.encode(), dtype=np.uint8)
+    rho = dmsim.simulate(noisy, initial_state='0', optimize='evolution-hybridq', verbose=False)
+    out['rho'] = np.asarray(rho).reshape(-1)
+    ref = np.load(os.path.join(HERE, 'e2e_dm.npz'))['rho']
+    assert np.abs(out['rho'] - ref).max() < 1e-6, 'not the same circuit as e2e_dm.npz'
+    np.savez_compressed(os.path.join(HERE, 'e2e_dm_circuit.npz'), **out)
+    print('e2e_dm_circuit.npz:', kinds)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'dm_circuit':
+        dm_circuit()
+        raise SystemExit(0)
     if os.path.exists('hybridq.so'):
         raise SystemExit('run from a directory that does not contain hybridq.so')
     per_call_vectors()

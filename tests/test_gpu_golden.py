@@ -87,3 +87,23 @@ def test_dm_trace(torch_cuda):
     rho = _replay_on_gpu(torch, z, 'trace_', n, torch.float32)
     exp = z['rho']
     assert np.abs(rho - exp).max() / np.abs(exp).max() < 5e-6
+
+
+def test_dm_front_end(torch_cuda):
+    """BASELINE cfg5 path: noisy 6-qubit circuit -> hybridq_amd.dm.simulate (12-qubit state
+    vector, fused non-unitary gates on the matrix cores) == the reference's rho."""
+    from hybridq_amd.dm import Kraus, simulate
+    z = gu.load('e2e_dm_circuit.npz')
+    kinds = bytes(z['kinds']).decode()
+    circuit = []
+    for i, kind in enumerate(kinds):
+        qs = tuple(int(q) for q in z[f'q{i}'])
+        circuit.append(Kraus(list(z[f'L{i}']), qs, s=z[f's{i}']) if kind == 'K' else (z[f'U{i}'], qs))
+    n = int(z['n_qubits'])
+    for compress in (4, 0):
+        rho = simulate(circuit, initial_state='0', complex_type='complex64', compress=compress).reshape(-1)
+        assert np.abs(rho - z['rho']).max() / np.abs(z['rho']).max() < 5e-6
+    r = rho.reshape(1 << n, 1 << n)
+    assert abs(np.trace(r).real - 1) < 1e-5 and np.abs(r - r.conj().T).max() < 1e-6
+    rho128 = simulate(circuit, initial_state='0' * n, complex_type='complex128').reshape(-1)
+    assert np.abs(rho128 - z['rho']).max() / np.abs(z['rho']).max() < 5e-6
