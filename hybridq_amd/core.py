@@ -105,6 +105,17 @@ _permute_bits = {
                         ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint) for b in (4, 8)
 }
 
+_probabilities = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_probabilities_float{b}', ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.c_uint, ctypes.POINTER(ctypes.c_double)) for b in (32, 64)
+}
+_project = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_project_float{b}', ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.c_uint, ctypes.c_uint64, ctypes.c_double) for b in (32, 64)
+}
+
 #: symbols the C header include/hq_hip.h declares (checked by tests/test_abi.py)
 EXPORTED = [
     'get_log2_pack_size', 'apply_U_float32', 'apply_U_float64', 'to_complex64', 'to_complex128',
@@ -113,6 +124,7 @@ EXPORTED = [
     'hq_set_apply_mode', 'hq_last_kernel', 'hq_last_kernel_desc', 'hq_to_complex64', 'hq_to_complex128',
     'hq_init_state_float32', 'hq_init_state_float64', 'hq_norm2_float32', 'hq_norm2_float64',
     'hq_permute_bits_32', 'hq_permute_bits_64',
+    'hq_probabilities_float32', 'hq_probabilities_float64', 'hq_project_float32', 'hq_project_float64',
 ]
 
 
@@ -246,3 +258,25 @@ def permute_bits(src, dst, perm, n_qubits=None):
         raise ValueError("'perm' must have one entry per index bit")
     rc = _permute_bits[dt.itemsize](_ptr(src), _ptr(dst), perm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n)
     _check(rc, 'permute_bits')
+
+
+def probabilities(psi_re, psi_im, pos, n_qubits=None):
+    """Marginal probabilities of the index bits `pos` (bit j of the outcome <-> pos[j])."""
+    ft = _float_dtype(psi_re)
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    n = _n_qubits(psi_re) if n_qubits is None else int(n_qubits)
+    out = np.zeros(1 << len(pos), dtype=np.float64)
+    rc = _probabilities[ft](_ptr(psi_re), _ptr(psi_im), n, pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                            len(pos), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    _check(rc, 'probabilities')
+    return out
+
+
+def project(psi_re, psi_im, pos, state, scale=1.0, n_qubits=None):
+    """psi[x] *= scale where bits pos[j] of x equal bit j of `state`, 0 elsewhere."""
+    ft = _float_dtype(psi_re)
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    n = _n_qubits(psi_re) if n_qubits is None else int(n_qubits)
+    rc = _project[ft](_ptr(psi_re), _ptr(psi_im), n, pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                      len(pos), int(state), float(scale))
+    _check(rc, 'project')

@@ -831,6 +831,55 @@ static int norm2_entry(const T* re, const T* im, uint64_t size, double* out) {
   return 0;
 }
 
+template <typename T>
+static int probabilities_entry(const T* re, const T* im, unsigned n, const unsigned* pos, unsigned k,
+                               double* out) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!re || !im || !pos || !out) return fail("probabilities: null pointer");
+  if (k > kMaxK || check_positions(pos, n, k)) return fail("probabilities: invalid positions");
+  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("probabilities: device pointers only");
+  BitsArg ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.k = k;
+  for (unsigned j = 0; j < k; ++j) ba.pos[j] = pos[j];
+  const size_t nb = (size_t)1 << k;
+  void* s1 = nullptr;
+  if (get_scratch(c, 1, std::max<size_t>(256, nb * sizeof(double)), &s1)) return 1;
+  HQ_HIP_CHECK(hipMemsetAsync(s1, 0, nb * sizeof(double), c.stream));
+  const uint64_t size = 1ull << n;
+  const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 8);
+  hipLaunchKernelGGL((probabilities_kernel<T>), dim3(grid), dim3(kBlock), nb * sizeof(double), c.stream, re,
+                     im, size, ba, (double*)s1);
+  HQ_HIP_CHECK(hipGetLastError());
+  HQ_HIP_CHECK(hipMemcpyAsync(out, s1, nb * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+template <typename T>
+static int project_entry(T* re, T* im, unsigned n, const unsigned* pos, unsigned k, uint64_t state,
+                         double scale) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!re || !im || !pos) return fail("project: null pointer");
+  if (k > 62 || check_positions(pos, n, k)) return fail("project: invalid positions");
+  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("project: device pointers only");
+  uint64_t mask = 0, want = 0;
+  for (unsigned j = 0; j < k; ++j) {
+    mask |= 1ull << pos[j];
+    want |= ((state >> j) & 1ull) << pos[j];
+  }
+  const uint64_t size = 1ull << n;
+  const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
+  hipLaunchKernelGGL((project_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, size, mask, want,
+                     (T)scale);
+  HQ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 }  // namespace hq
 
 // -----------------------------------------------------------------------------------
@@ -891,6 +940,23 @@ int hq_permute_bits_32(const void* src, void* dst, const unsigned int* perm, uns
 }
 int hq_permute_bits_64(const void* src, void* dst, const unsigned int* perm, unsigned int n) {
   return hq::permute_bits_entry<uint64_t>((const uint64_t*)src, (uint64_t*)dst, perm, n);
+}
+
+int hq_probabilities_float32(const float* re, const float* im, unsigned int n, const unsigned int* pos,
+                             unsigned int k, double* out) {
+  return hq::probabilities_entry<float>(re, im, n, pos, k, out);
+}
+int hq_probabilities_float64(const double* re, const double* im, unsigned int n, const unsigned int* pos,
+                             unsigned int k, double* out) {
+  return hq::probabilities_entry<double>(re, im, n, pos, k, out);
+}
+int hq_project_float32(float* re, float* im, unsigned int n, const unsigned int* pos, unsigned int k,
+                       uint64_t state, double scale) {
+  return hq::project_entry<float>(re, im, n, pos, k, state, scale);
+}
+int hq_project_float64(double* re, double* im, unsigned int n, const unsigned int* pos, unsigned int k,
+                       uint64_t state, double scale) {
+  return hq::project_entry<double>(re, im, n, pos, k, state, scale);
 }
 
 int hq_set_stream(void* hip_stream) {

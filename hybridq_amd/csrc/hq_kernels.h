@@ -675,4 +675,47 @@ norm2_kernel(const T* __restrict__ re, const T* __restrict__ im, const uint64_t 
   }
 }
 
+// ---------------------------------------------------------------------------------
+// probabilities / project: device side of the Measure and Projection functional gates
+// (hybridq/gate/measure.py:25-125, gate/projection.py:25-119), so that circuits containing
+// them need no D2H round trip of the state.
+// ---------------------------------------------------------------------------------
+struct BitsArg {
+  unsigned k;
+  unsigned pos[kMaxK];  // bit j of the outcome index <-> index bit pos[j]
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+probabilities_kernel(const T* __restrict__ re, const T* __restrict__ im, const uint64_t size,
+                     const BitsArg ba, double* __restrict__ out /* 2^k, pre-zeroed */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* bins = reinterpret_cast<double*>(smem);
+  const unsigned nb = 1u << ba.k;
+  for (unsigned i = threadIdx.x; i < nb; i += kBlock) bins[i] = 0.0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < size; x += stride) {
+    unsigned t = 0;
+    for (unsigned j = 0; j < ba.k; ++j) t |= (unsigned)((x >> ba.pos[j]) & 1ull) << j;
+    const double r = re[x], m = im[x];
+    atomicAdd(&bins[t], r * r + m * m);
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < nb; i += kBlock)
+    if (bins[i] != 0.0) atomicAdd(&out[i], bins[i]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+project_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t size, const uint64_t mask,
+               const uint64_t want, const T scale) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < size; x += stride) {
+    const bool keep = (x & mask) == want;
+    re[x] = keep ? re[x] * scale : (T)0;
+    im[x] = keep ? im[x] * scale : (T)0;
+  }
+}
+
 }  // namespace hq

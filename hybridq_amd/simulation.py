@@ -41,8 +41,11 @@ class FunctionalGate:
 
 
 def _is_functional(gate):
-    return (not isinstance(gate, (tuple, list)) and callable(getattr(gate, 'apply', None)) and
-            not hasattr(gate, 'matrix'))
+    if isinstance(gate, (tuple, list)):
+        return False
+    if callable(getattr(gate, 'apply_device', None)):  # hybridq_amd.functional: stays in HBM
+        return True
+    return callable(getattr(gate, 'apply', None)) and not hasattr(gate, 'matrix')
 
 
 def _gate_qubits_matrix(gate):
@@ -160,6 +163,9 @@ class EvolutionState:
         (2,)+(2,)*n real array and the current qubit order.  Reference functional gates are
         host numpy code, so the state makes a D2H/H2D round trip here (rare; device-side
         projection/measurement are the "next" row of SURVEY 8f)."""
+        if callable(getattr(gate, 'apply_device', None)):
+            gate.apply_device(self)
+            return
         torch = _torch()
         core.sync()
         order = tuple(q for q, _ in sorted(self.map.items(), key=lambda x: x[1])[::-1])  # :528-530

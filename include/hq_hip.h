@@ -126,6 +126,20 @@ int hq_permute_bits_64(const void *src, void *dst, const unsigned int *perm, uns
 int hq_norm2_float32(const float *psi_re, const float *psi_im, uint64_t size, double *out);
 int hq_norm2_float64(const double *psi_re, const double *psi_im, uint64_t size, double *out);
 
+/* Device side of the Measure / Projection functional gates (hybridq/gate/measure.py:25-125,
+ * gate/projection.py:25-119).  probabilities: out[t] = sum of |psi[x]|^2 over the x whose
+ * bits pos[0..k) spell t (bit j of t <-> index bit pos[j]); `out` is a HOST array of 2^k
+ * doubles, the call synchronises.  project: psi[x] *= scale where those bits spell `state`,
+ * psi[x] = 0 elsewhere (asynchronous).  Device pointers only, k <= 10. */
+int hq_probabilities_float32(const float *psi_re, const float *psi_im, unsigned int n_qubits,
+                             const unsigned int *pos, unsigned int n_pos, double *out);
+int hq_probabilities_float64(const double *psi_re, const double *psi_im, unsigned int n_qubits,
+                             const unsigned int *pos, unsigned int n_pos, double *out);
+int hq_project_float32(float *psi_re, float *psi_im, unsigned int n_qubits, const unsigned int *pos,
+                       unsigned int n_pos, uint64_t state, double scale);
+int hq_project_float64(double *psi_re, double *psi_im, unsigned int n_qubits, const unsigned int *pos,
+                       unsigned int n_pos, uint64_t state, double scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -453,3 +453,62 @@ def test_transpose_api(torch_cuda, t):
     assert (v1 == v2h).all() and np.shares_memory(v2, v2h)
     axes = np.concatenate([np.arange(n - 6), n - 6 + rng.permutation(6)])
     assert (transpose(v, axes, force_numpy=True) == transpose(v, axes, raise_if_hcore_fails=True)).all()
+
+
+@pytest.mark.parametrize('ct', ['complex64', 'complex128'])
+def test_device_projection_and_measure(torch_cuda, ct):
+    """Device-side Projection / Measure (gate/projection.py, gate/measure.py semantics) vs
+    numpy on the gathered state: probabilities, collapse, renormalisation, inside simulate."""
+    import oracle
+    from hybridq_amd import core
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.functional import Measure, Projection
+    from hybridq_amd.simulation import EvolutionState, simulate
+    n = 12
+    tol = 1e-5 if ct == 'complex64' else 1e-12
+    g1 = random_dense(n, 25, kmax=3, seed=4, unitary=True)
+    psi1 = oracle.evolve_tensordot(g1, n, initial_state=np.full(1 << n, 2.0**(-n / 2)), qubits=list(range(n)))
+    t = psi1.reshape((2,) * n)
+    # marginal probabilities, qubits[0] = most significant outcome bit, arbitrary order
+    st = EvolutionState(list(range(n)), complex_type=ct, initial_state='+' * n)
+    for U, qs in g1:
+        st.apply(U.astype(ct), qs)
+    for qs in ((3,), (7, 2), (0, 11, 5), (9, 1, 4, 10)):
+        m = Measure(qs)
+        probs = m.probabilities(st)
+        ax = list(qs) + [a for a in range(n) if a not in qs]
+        exp = (np.abs(np.transpose(t, ax).reshape(1 << len(qs), -1))**2).sum(1)
+        assert np.abs(probs - exp).max() < tol
+    # projection inside a circuit
+    g2 = random_dense(n, 25, kmax=3, seed=5, unitary=True)
+    circuit = list(g1) + [Projection('10', (7, 2))] + list(g2)
+    psi = simulate(circuit, initial_state='+' * n, complex_type=ct).reshape(-1)
+    a = t.copy()
+    keep = np.zeros((2,) * n, dtype=bool)
+    idx = [slice(None)] * n
+    idx[7], idx[2] = 1, 0
+    keep[tuple(idx)] = True
+    a = np.where(keep, a, 0)
+    a /= np.linalg.norm(a.ravel())
+    exp = oracle.evolve_tensordot(g2, n, initial_state=a.reshape(-1), qubits=list(range(n)))
+    assert np.abs(psi - exp).max() / np.abs(exp).max() < 2 * tol
+    # measurement: outcome is recorded, state collapses onto it with norm 1
+    m = Measure((4, 8), rng=np.random.default_rng(3))
+    psi = simulate(list(g1) + [m], initial_state='+' * n, complex_type=ct).reshape((2,) * n)
+    o = m.outcome
+    assert 0 <= o < 4 and abs(np.linalg.norm(psi.ravel()) - 1) < 10 * tol
+    b4, b8 = (o >> 1) & 1, o & 1
+    idx = [slice(None)] * n
+    idx[4], idx[8] = 1 - b4, slice(None)
+    assert np.abs(psi[tuple(idx)]).max() == 0
+    idx[4], idx[8] = b4, b8
+    ref = t[tuple(idx)] / np.linalg.norm(t[tuple(idx)].ravel())
+    assert np.abs(psi[tuple(idx)] - ref).max() < 10 * tol
+    # sampling statistics follow the probabilities
+    st2 = EvolutionState(list(range(n)), complex_type=ct, initial_state='+' * n)
+    for U, qs in g1:
+        st2.apply(U.astype(ct), qs)
+    mm = Measure((6,), rng=np.random.default_rng(0))
+    p = mm.probabilities(st2)
+    draws = np.array([mm.sample(p) for _ in range(4000)])
+    assert abs(draws.mean() - p[1]) < 0.05
