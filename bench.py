@@ -214,6 +214,38 @@ def main():
         },
     }
 
+    if sharded_path:
+        # the exchange on its own: every rank sends (G-1)/G of both planes, one
+        # distinct chunk per peer, so the per-link figure is chunk bytes / time
+        reps = 3
+        barrier()
+        t0x = time.perf_counter()
+        for _ in range(2 * reps):  # an even count leaves the state where it was
+            sharded.run([('X',)], update_map=False)
+        barrier()
+        tx = (time.perf_counter() - t0x) / (2 * reps)
+        perm = np.arange(n_local, dtype=np.uint32)
+        if n_local >= 2:
+            perm[n_local - 1], perm[n_local - 2] = n_local - 2, n_local - 1
+        barrier()
+        t0p = time.perf_counter()
+        for _ in range(2 * reps):
+            sharded.run([('P', perm)], update_map=False)
+        barrier()
+        tp = (time.perf_counter() - t0p) / (2 * reps)
+        shard_bytes = 2 * (1 << n_local) * ft.itemsize
+        chunk_bytes = shard_bytes // max(world, 1)
+        result['exchange'] = {
+            'ms_per_exchange': 1e3 * tx,
+            'bytes_sent_per_gpu': shard_bytes - chunk_bytes,
+            'bytes_per_link': chunk_bytes,
+            'GBps_per_link': chunk_bytes / tx / 1e9 if world > 1 else None,
+            'GBps_per_gpu_out': (shard_bytes - chunk_bytes) / tx / 1e9 if world > 1 else None,
+            'xgmi_link_peak_GBps': 153.0,
+            'ms_per_permutation_pass': 1e3 * tp,
+            'exchanges_per_step': n_exchanges,
+            'permutation_passes_per_step': n_permutes,
+        }
     if rank == 0 and events is not None:
         per_class = {}
         for s in range(args.steps):

@@ -198,6 +198,8 @@ class ShardedEvolution:
         self.complex_type = np.dtype(complex_type)
         self.float_type = _FLOAT_OF[self.complex_type]
         self.backend = HipBackend(self.float_type) if backend is None else backend
+        # second buffer (receive side of the exchange / destination of the permutation pass)
+        # is allocated on first use when there is a single rank
         self.bufs = [self.backend.empty_planes(self.m), self.backend.empty_planes(self.m) if self.g else None]
         self.cur = 0
         self.pos = {q: n - 1 - i for i, q in enumerate(self.qubits)}
@@ -250,6 +252,8 @@ class ShardedEvolution:
     def run(self, schedule, update_map=True):
         be = self.backend
         for op in schedule:
+            if op[0] != 'G' and self.bufs[1 - self.cur] is None:
+                self.bufs[1 - self.cur] = be.empty_planes(self.m)
             if op[0] == 'G':
                 be.apply(self.bufs[self.cur], op[1], op[2], self.m)
             elif op[0] == 'P':

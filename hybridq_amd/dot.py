@@ -8,8 +8,9 @@ returns ``(result, None)`` (the reference returns ``None`` for the transposition
 no swap was needed, dot.py:323-329).  Host numpy inputs go through the library's
 host-pointer path (staged over PCIe); split-plane torch CUDA tensors are updated in place
 in HBM.  ``force_numpy=True`` is the explicit numpy path of the reference API (its tests
-use it as the cross-check); inputs outside the core's domain (non-binary axes, > 10
-target axes, unsupported dtypes) take it with the reference's warning.
+use it as the cross-check).  There is NO implicit CPU fallback: inputs outside the core's
+domain (non-binary axes, > 10 target axes, unsupported dtypes) raise NotImplementedError
+where the reference would warn and fall back (dot.py:332-335).
 """
 from warnings import warn
 
@@ -144,7 +145,12 @@ def dot(a, b, axes_b=None, b_as_complex_array=False, inplace=False, backend='num
         return res if kwargs['swap_back'] is True else (res, None)
 
     if not kwargs['force_numpy']:
-        warn("Fallback to 'numpy.dot'")
+        # The reference warns and falls back to numpy here (dot.py:332-335).  This package has no
+        # implicit CPU path: inputs outside the HIP core's domain are an error unless the caller
+        # asks for numpy explicitly.
+        raise NotImplementedError(
+            "dot: input outside the HIP core's domain (needs all axes of dimension 2, a square matrix, "
+            "float32/float64 planes, <= 10 target axes); pass force_numpy=True for the numpy path")
     if b_as_complex_array:
         b = np.reshape(b[0] + 1j * b[1], b_shape)
     perm = axes_b.tolist() + [x for x in range(b_ndim) if x not in axes_b]

@@ -2,10 +2,9 @@
 ``hybridq.utils.transpose`` (hybridq/utils/transpose.py:61-169) on ``swap_<dtype>`` of
 libhq_hip.so.  Same rule as the reference: the leading already-ordered axes are skipped
 and the remaining (trailing) axes are permuted by the core when their number is in
-(3, 16] (transpose.py:131), otherwise numpy.transpose is used (with the reference's
-warning unless ``force_numpy``)."""
-from warnings import warn
-
+(3, 16] (transpose.py:131).  Anything else raises NotImplementedError unless
+``force_numpy=True`` asks for numpy.transpose explicitly (the reference warns and falls
+back; this package has no implicit CPU path)."""
 import numpy as np
 
 from . import core
@@ -41,5 +40,8 @@ def transpose(a, axes=None, inplace=False, backend='numpy', **kwargs):
             core.swap(a.reshape(-1), pos, a.ndim)
             return a
     if not kwargs['force_numpy']:
-        warn("Fallback to 'numpy.transpose'")
+        # reference: warn + numpy.transpose (transpose.py:155-166).  No implicit CPU path here.
+        raise NotImplementedError(
+            "transpose: outside the HIP core's domain (needs all dimensions 2, a 4/8-byte real or integer "
+            "dtype and 4..16 unordered trailing axes); pass force_numpy=True for numpy.transpose")
     return np.transpose(a, axes)
