@@ -121,6 +121,66 @@ def plan_schedule(gate_qubits, qubits, g):
     return ops, dict(pos)
 
 
+def plan_restore(pos, qubits, g):
+    """Ops that bring the placement `pos` (label -> position) back to the canonical one
+    (label #x at position n-1-x): at most three exchanges and four permutation passes.
+    Returns (ops, canonical_pos)."""
+    n = len(qubits)
+    m = n - g
+    pos = dict(pos)
+    at = {p: q for q, p in pos.items()}
+    want = {q: n - 1 - i for i, q in enumerate(qubits)}
+    ops = []
+
+    def permute_to(target):  # target: {qubit: local position} for a subset; others fill the rest in order
+        taken = set(target.values())
+        free = [p for p in range(m) if p not in taken]
+        rest = [at[p] for p in range(m) if at[p] not in target]
+        new_local = dict(target)
+        new_local.update({q: p for q, p in zip(rest, free)})
+        perm = [0] * m
+        for q, p_new in new_local.items():
+            perm[p_new] = pos[q]  # dst bit p_new <- src bit pos[q]
+        if perm != list(range(m)):
+            ops.append(('P', perm))
+            for q, p_new in new_local.items():
+                pos[q] = p_new
+            for q in new_local:
+                at[pos[q]] = q
+
+    def exchange():
+        ops.append(('X',))
+        for i in range(g):
+            a, b = m - g + i, m + i
+            qa, qb = at[a], at[b]
+            at[a], at[b] = qb, qa
+            pos[qa], pos[qb] = b, a
+
+    if g:
+        W = [q for q in qubits if want[q] >= m]  # must end up global
+        if any(pos[q] >= m and pos[q] != want[q] for q in W):
+            # some wanted-global qubit is global but in the wrong slot: bring every global in,
+            # sending out g local qubits that are not wanted-global
+            evict = [at[p] for p in range(m - 1, -1, -1) if at[p] not in W][:g]
+            permute_to({q: m - g + i for i, q in enumerate(evict)})
+            exchange()
+        if any(pos[q] != want[q] for q in W):
+            movers = {q: want[q] - g for q in W if pos[q] < m}  # slot m-g+i feeds global position m+i
+            # slots whose global partner is already correct must keep a non-W qubit: handled because
+            # after the step above either every W qubit is local or the global ones are already right
+            if any(pos[q] >= m for q in W):
+                # the correct globals would be swapped out by a full exchange: park them first
+                evict = [at[p] for p in range(m - 1, -1, -1) if at[p] not in W][:g]
+                permute_to({q: m - g + i for i, q in enumerate(evict)})
+                exchange()
+                movers = {q: want[q] - g for q in W}
+            permute_to(movers)
+            exchange()
+    permute_to({q: want[q] for q in qubits if want[q] < m})
+    assert all(pos[q] == want[q] for q in qubits), 'restore planning failed'
+    return ops, dict(pos)
+
+
 # ------------------------------------------------------------------------------------
 # backends
 # ------------------------------------------------------------------------------------
@@ -231,9 +291,14 @@ class ShardedEvolution:
             raise ValueError("sharded initial states: '0'/'1' strings or all '+'")
 
     # -- planning ----------------------------------------------------------------
-    def plan(self, gates):
+    def plan(self, gates, compress=0):
         """Schedule `gates` ([(U, qubits), ...]) from the CURRENT qubit placement.  Returns
-        the op list for run(); the matrices are cast once here."""
+        the op list for run(); the matrices are cast once here.  ``compress`` > 0 first fuses
+        the circuit into <= compress-qubit gates (hybridq_amd.fusion, the reference's default
+        is 4): fewer local passes, same exchanges."""
+        if compress:
+            from .fusion import fuse
+            gates = fuse(gates, compress, complex_type=self.complex_type)
         gq = [tuple(qs) for _, qs in gates]
         order = sorted(self.qubits, key=lambda q: -self.pos[q])  # label at position n-1, n-2, ...
         ops, final_pos = plan_schedule(gq, order, self.g)
@@ -265,8 +330,18 @@ class ShardedEvolution:
         if update_map:
             self.pos = dict(self._planned_final_pos)
 
-    def simulate(self, gates):
-        self.run(self.plan(gates))
+    def simulate(self, gates, compress=0):
+        self.run(self.plan(gates, compress=compress))
+        return self
+
+    def restore_order(self):
+        """Bring every qubit back to its canonical position (label #x at index bit n-1-x), the
+        counterpart of the reference's final un-permute (simulation.py:655-663)."""
+        order = list(self.qubits)
+        ops, final = plan_restore(self.pos, order, self.g)
+        sched = [('P', np.asarray(op[1], dtype=np.uint32)) if op[0] == 'P' else op for op in ops]
+        self._planned_final_pos = final
+        self.run(sched)
         return self
 
     # -- results -----------------------------------------------------------------

@@ -97,9 +97,22 @@ def _worker(rank, world, port, n, seed, ct, out_dir):
         sh2.simulate(g2[:12])
         sh2.simulate(g2[12:])  # re-planned from a non-identity map
         psi2 = sh2.state_numpy()
+        # fused schedule + restore to the canonical placement: the raw shards, concatenated in
+        # rank order, must then BE the canonical state (no host-side un-permutation)
+        sh3 = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, backend=CpuBackend(ft))
+        sh3.simulate(gates, compress=4)
+        moved = any(sh3.pos[q] != n - 1 - q for q in range(n))
+        sh3.restore_order()
+        assert all(sh3.pos[q] == n - 1 - q for q in range(n))
+        import torch
+        loc = torch.from_numpy(np.ascontiguousarray(sh3.backend.to_numpy(sh3.planes)))
+        parts = [torch.empty_like(loc) for _ in range(world)]
+        dist.all_gather(parts, loc)
+        raw = np.concatenate([p[0].numpy() + 1j * p[1].numpy() for p in parts])
         nrm = sh.norm2()
         if rank == 0:
-            np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psi2=psi2, n_x=n_x, n_p=n_p, nrm=nrm)
+            np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psi2=psi2, n_x=n_x, n_p=n_p, nrm=nrm, raw=raw,
+                     moved=moved)
     finally:
         dist.destroy_process_group()
 
@@ -118,6 +131,7 @@ def test_sharded_matches_single_process(tmp_path, world, n, ct):
     assert np.abs(out['psi'] - exp).max() / np.abs(exp).max() < tol
     assert int(out['n_x']) >= 1  # the circuit really needed exchanges
     assert abs(float(out['nrm']) - float(np.vdot(exp, exp).real)) < 1e-5 * float(np.vdot(exp, exp).real)
+    assert np.abs(out['raw'] - exp).max() / np.abs(exp).max() < tol  # fused + restore_order
     g2 = random_dense(n, 25, kmax=3, seed=seed + 2)
     exp2 = oracle.evolve_tensordot(g2, n, initial_state=np.full(1 << n, 2.0**(-n / 2)))
     assert np.abs(out['psi2'] - exp2).max() / np.abs(exp2).max() < tol
@@ -163,3 +177,28 @@ def test_planner_properties():
         assert pos == final
         if g == 0:
             assert all(op[0] == 'G' for op in ops)
+
+
+def test_plan_restore_properties():
+    from hybridq_amd.dist import plan_restore
+    rng = np.random.default_rng(1)
+    for n, g in ((10, 0), (10, 1), (12, 2), (14, 3)):
+        m = n - g
+        qubits = list(range(n))
+        for trial in range(50):
+            perm = rng.permutation(n)
+            pos = {q: int(perm[q]) for q in qubits}
+            ops, final = plan_restore(pos, qubits, g)
+            cur = dict(pos)
+            for op in ops:
+                at = {p: q for q, p in cur.items()}
+                if op[0] == 'P':
+                    assert sorted(op[1]) == list(range(m))
+                    for i in range(m):
+                        cur[at[op[1][i]]] = i
+                else:
+                    for i in range(g):
+                        a, b = m - g + i, m + i
+                        cur[at[a]], cur[at[b]] = b, a
+            assert all(cur[q] == n - 1 - q for q in qubits) and final == cur
+            assert sum(op[0] == 'X' for op in ops) <= 3
