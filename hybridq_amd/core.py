@@ -116,6 +116,12 @@ _project = {
                                             ctypes.c_uint, ctypes.c_uint64, ctypes.c_double) for b in (32, 64)
 }
 
+_vdot = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_vdot_float{b}', ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                            ctypes.POINTER(ctypes.c_double)) for b in (32, 64)
+}
+
 #: symbols the C header include/hq_hip.h declares (checked by tests/test_abi.py)
 EXPORTED = [
     'get_log2_pack_size', 'apply_U_float32', 'apply_U_float64', 'to_complex64', 'to_complex128',
@@ -125,6 +131,7 @@ EXPORTED = [
     'hq_init_state_float32', 'hq_init_state_float64', 'hq_norm2_float32', 'hq_norm2_float64',
     'hq_permute_bits_32', 'hq_permute_bits_64',
     'hq_probabilities_float32', 'hq_probabilities_float64', 'hq_project_float32', 'hq_project_float64',
+    'hq_vdot_float32', 'hq_vdot_float64',
 ]
 
 
@@ -280,3 +287,13 @@ def project(psi_re, psi_im, pos, state, scale=1.0, n_qubits=None):
     rc = _project[ft](_ptr(psi_re), _ptr(psi_im), n, pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                       len(pos), int(state), float(scale))
     _check(rc, 'project')
+
+
+def vdot(a_re, a_im, b_re, b_im):
+    """<a|b> = sum conj(a) b on split planes (double accumulation); returns a Python complex."""
+    ft = _float_dtype(a_re)
+    size = a_re.numel() if hasattr(a_re, 'numel') else a_re.size
+    out = (ctypes.c_double * 2)()
+    rc = _vdot[ft](_ptr(a_re), _ptr(a_im), _ptr(b_re), _ptr(b_im), size, out)
+    _check(rc, 'vdot')
+    return complex(out[0], out[1])

@@ -880,6 +880,26 @@ static int project_entry(T* re, T* im, unsigned n, const unsigned* pos, unsigned
   return 0;
 }
 
+template <typename T>
+static int vdot_entry(const T* are, const T* aim, const T* bre, const T* bim, uint64_t size, double* out) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!are || !aim || !bre || !bim || !out) return fail("vdot: null pointer");
+  if (!is_device_pointer(are) || !is_device_pointer(aim) || !is_device_pointer(bre) || !is_device_pointer(bim))
+    return fail("vdot: device pointers only");
+  void* s1 = nullptr;
+  if (get_scratch(c, 1, 256, &s1)) return 1;
+  HQ_HIP_CHECK(hipMemsetAsync(s1, 0, 2 * sizeof(double), c.stream));
+  const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 16);
+  hipLaunchKernelGGL((vdot_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, are, aim, bre, bim, size,
+                     (double*)s1);
+  HQ_HIP_CHECK(hipGetLastError());
+  HQ_HIP_CHECK(hipMemcpyAsync(out, s1, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
 }  // namespace hq
 
 // -----------------------------------------------------------------------------------
@@ -957,6 +977,15 @@ int hq_project_float32(float* re, float* im, unsigned int n, const unsigned int*
 int hq_project_float64(double* re, double* im, unsigned int n, const unsigned int* pos, unsigned int k,
                        uint64_t state, double scale) {
   return hq::project_entry<double>(re, im, n, pos, k, state, scale);
+}
+
+int hq_vdot_float32(const float* are, const float* aim, const float* bre, const float* bim, uint64_t size,
+                    double* out) {
+  return hq::vdot_entry<float>(are, aim, bre, bim, size, out);
+}
+int hq_vdot_float64(const double* are, const double* aim, const double* bre, const double* bim,
+                    uint64_t size, double* out) {
+  return hq::vdot_entry<double>(are, aim, bre, bim, size, out);
 }
 
 int hq_set_stream(void* hip_stream) {

@@ -718,4 +718,35 @@ project_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t size, cons
   }
 }
 
+// <a|b> = sum conj(a) b on split planes, accumulated in double: out[0] += sum(ar*br + ai*bi),
+// out[1] += sum(ar*bi - ai*br)   (expectation values, simulation.py:1125-1216)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+vdot_kernel(const T* __restrict__ are, const T* __restrict__ aim, const T* __restrict__ bre,
+            const T* __restrict__ bim, const uint64_t size, double* __restrict__ out) {
+  __shared__ double part[2][kBlock / 64];
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  double sr = 0, si = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
+    const double ar = are[i], ai = aim[i], br = bre[i], bi = bim[i];
+    sr += ar * br + ai * bi;
+    si += ar * bi - ai * br;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sr += __shfl_down(sr, o, 64);
+    si += __shfl_down(si, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    part[0][threadIdx.x >> 6] = sr;
+    part[1][threadIdx.x >> 6] = si;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { a += part[0][w]; b += part[1][w]; }
+    atomicAdd(&out[0], a);
+    atomicAdd(&out[1], b);
+  }
+}
+
 }  // namespace hq

@@ -274,3 +274,28 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     else:
         psi = state
     return (psi, info) if kwargs['return_info'] else psi
+
+
+def expectation_value(state, op, qubits_order, complex_type='complex64', **kwargs):
+    """<state| op |state> through the evolution core: the counterpart of
+    ``hybridq.circuit.simulation.expectation_value`` (simulation.py:1125-1216).  `state` is an
+    array of shape (2,)*n, `op` a circuit on a subset of `qubits_order`.  As in the reference
+    the qubits are mapped to the axes of `state` in SORTED label order (its ``simulate`` sorts
+    ``all_qubits()``; ``qubits_order`` is only validated).  op|state> is formed in HBM and the
+    inner product is reduced on the device: no state ever returns to the host."""
+    state = np.asarray(state)
+    n = state.ndim
+    qubits_order = list(qubits_order)
+    if len(qubits_order) != n:
+        raise ValueError("'qubits_order' must have the same number of qubits of 'state'.")
+    op = list(op)
+    if set(all_qubits(op)).difference(qubits_order):
+        raise ValueError("'op' has qubits not included in 'qubits_order'.")
+    kwargs.pop('remove_id_gates', None)
+    kwargs['return_numpy_array'] = False
+    kwargs.pop('return_info', None)
+    qubits = all_qubits([(None, (q,)) for q in qubits_order])
+    out = simulate(op, initial_state=state, complex_type=complex_type, qubits=qubits, **kwargs)
+    ref = EvolutionState(qubits, complex_type=complex_type, initial_state=state, device=out.device)
+    val = core.vdot(ref.planes[0], ref.planes[1], out.planes[0], out.planes[1])
+    return val.real if abs(val.imag) < 100 * np.finfo(np.float64).eps * max(1.0, abs(val.real)) else val

@@ -140,6 +140,14 @@ int hq_project_float32(float *psi_re, float *psi_im, unsigned int n_qubits, cons
 int hq_project_float64(double *psi_re, double *psi_im, unsigned int n_qubits, const unsigned int *pos,
                        unsigned int n_pos, uint64_t state, double scale);
 
+/* <a|b> = sum_i conj(a_i) b_i on split planes, accumulated in double: out[0] = real part,
+ * out[1] = imaginary part (HOST array of 2 doubles; the call synchronises).  Device side of
+ * expectation_value (hybridq/circuit/simulation/simulation.py:1125-1216). */
+int hq_vdot_float32(const float *a_re, const float *a_im, const float *b_re, const float *b_im,
+                    uint64_t size, double *out);
+int hq_vdot_float64(const double *a_re, const double *a_im, const double *b_re, const double *b_im,
+                    uint64_t size, double *out);
+
 #ifdef __cplusplus
 }
 #endif

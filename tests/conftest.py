@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 
+def pytest_sessionstart(session):
+    """Build artefacts are git-ignored: (re)build the HIP library and the CPU oracle when they are
+    missing or stale, so that a fresh checkout can run the suite directly (hipcc cross-compiles
+    gfx950 without a GPU; on the GPU box the prebuilt files arrive with the snapshot)."""
+    import subprocess
+    from hybridq_amd import build as hq_build
+    hq_build.build(force=False)
+    if not os.path.exists(os.path.join(ROOT, 'oracle', 'libhq_oracle.so')):
+        subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'port'])
+    if not os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'hybridq.so')) and os.path.exists('/root/reference/include'):
+        subprocess.call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'ref'])
+
+
 @pytest.fixture(scope='session')
 def oracle_port():
     import subprocess
