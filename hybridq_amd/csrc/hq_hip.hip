@@ -652,8 +652,14 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
     const uint64_t ntiles = 1ull << (n - tile_bits);
     const size_t lds = ((((size_t)1 << s) * 2 + 15) & ~(size_t)15) + ((size_t)1 << tile_bits) * sizeof(E);
     const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
-    hipLaunchKernelGGL((swap_lds_kernel<E>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
-                       tile_bits, ntiles);
+    constexpr int VEC = 16 / sizeof(E);
+    const bool vec = tile_bits >= 10 && reinterpret_cast<uintptr_t>(a) % 16 == 0;
+    if (vec)
+      hipLaunchKernelGGL((swap_lds_kernel<E, VEC>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
+                         tile_bits, ntiles);
+    else
+      hipLaunchKernelGGL((swap_lds_kernel<E, 1>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
+                         tile_bits, ntiles);
     HQ_HIP_CHECK(hipGetLastError());
     return 0;
   }

@@ -543,11 +543,13 @@ struct SwapArg {
   unsigned pos[32];
 };
 
-// One workgroup permutes 2^tile_bits contiguous elements (>= one 2^s chunk) through LDS.
-template <typename E>
+// One workgroup permutes 2^tile_bits contiguous elements (>= one 2^s chunk) through LDS:
+// 16-byte loads into LDS, permuted LDS reads, 16-byte stores (VEC elements per access).
+template <typename E, int VEC>
 __global__ void __launch_bounds__(kBlock)
 swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
                 const uint64_t ntiles) {
+  struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned S = 1u << sa.s, TILE = 1u << tile_bits;
   uint16_t* src = reinterpret_cast<uint16_t*>(smem);          // S entries
@@ -561,10 +563,19 @@ swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
   for (uint64_t tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
     E* g = a + tb * TILE;
     __syncthreads();
-    for (unsigned x = tid; x < TILE; x += kBlock) buf[x] = g[x];
+    for (unsigned x = tid * VEC; x < TILE; x += kBlock * VEC) {
+      *reinterpret_cast<Pack*>(buf + x) = *reinterpret_cast<const Pack*>(g + x);
+    }
     __syncthreads();
-    for (unsigned x = tid; x < TILE; x += kBlock)
-      g[x] = buf[(x & ~(S - 1)) | src[x & (S - 1)]];
+    for (unsigned x = tid * VEC; x < TILE; x += kBlock * VEC) {
+      Pack p;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const unsigned xx = x + c;
+        p.e[c] = buf[(xx & ~(S - 1)) | src[xx & (S - 1)]];
+      }
+      *reinterpret_cast<Pack*>(g + x) = p;
+    }
   }
 }
 
