@@ -75,3 +75,58 @@ def test_full_size_direct_vs_generic(torch_cuda):
         assert np.abs(sa - sb).max() / np.abs(sa).max() < 1e-6, pos
     core.set_apply_mode('auto')
     assert abs(core.norm2(a[0], a[1]) - core.norm2(b[0], b[1])) < 1e-5
+
+
+def test_beyond_32_bit_indices(torch_cuda):
+    """n = 33 (64 GiB of planes, one MI355X holds 288 GB): every index path must be 64-bit.
+    Targets at the top positions through each kernel family, U then U^dagger restores a
+    strided sample; basis-state bookkeeping at indices >= 2^32."""
+    torch = torch_cuda
+    from hybridq_amd import core
+    from hybridq_amd.circuits import haar_unitary
+    free, _ = torch.cuda.mem_get_info()
+    n = 33
+    if free < 1.15 * 8 * (1 << n):
+        pytest.skip('not enough free HBM for n=33')
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(33)
+    re = torch.empty(1 << n, dtype=torch.float32, device='cuda')
+    im = torch.empty(1 << n, dtype=torch.float32, device='cuda')
+    # |b> with a bit above 2^32 set: X on the top qubit moves the 1 by 2^32
+    b = (1 << 32) + 12345
+    core.init_state(re, im, 'basis', b)
+    X = np.array([[0, 1], [1, 0]])
+    core.apply_U(re, im, X, [32])
+    core.sync()
+    assert float(re[12345]) == 1.0 and float(re[b]) == 0.0
+    core.apply_U(re, im, X, [32, 3][:1])
+    core.apply_U(re, im, np.kron(X, X), [31, 32])  # flips bits 31 and 32
+    core.sync()
+    assert float(re[12345 + (1 << 31)]) == 1.0
+    assert abs(core.norm2(re, im) - 1.0) < 1e-6
+    # dense state, round trips at the top of the index
+    core.init_state(re, im, 'plus')
+    for p in (0, 5, 17, 30, 31, 32):
+        core.apply_U(re, im, haar_unitary(2, rng), [p])
+    idx = torch.from_numpy(rng.integers(0, 1 << n, 1 << 15)).cuda()
+    before = torch.stack([re[idx], im[idx]]).double().cpu().numpy()
+    for mode, pos in (('mfma', [32]), ('mfma', [31, 32]), ('mfma', [2, 32]), ('mfma', [0, 16, 32]),
+                      ('mfma', [29, 30, 31, 32]), ('direct', [32]), ('direct', [7, 31, 32]),
+                      ('auto', [3, 9, 28, 31, 32]), ('generic', [30, 32])):
+        U = haar_unitary(1 << len(pos), rng)
+        core.set_apply_mode(mode)
+        core.apply_U(re, im, U, pos)
+        mid = torch.stack([re[idx], im[idx]]).double().cpu().numpy()
+        core.apply_U(re, im, U.conj().T, pos)
+        core.set_apply_mode('auto')
+        after = torch.stack([re[idx], im[idx]]).double().cpu().numpy()
+        assert np.abs(mid - before).max() > 1e-8, (mode, pos)
+        assert np.abs(after - before).max() / np.abs(before).max() < 3e-6, (mode, pos)
+    assert abs(core.norm2(re, im) - 1.0) < 1e-4
+    # low-bit swap and marginal probabilities on the 2^33-element arrays
+    s_before = re[idx].clone()
+    core.swap(re, [1, 0, 2], n)
+    core.swap(re, [1, 0, 2], n)
+    assert bool((re[idx] == s_before).all())
+    p = core.probabilities(re, im, [32], n)
+    assert abs(p.sum() - 1.0) < 1e-4 and p.min() > 0
