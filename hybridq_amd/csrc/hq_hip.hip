@@ -274,7 +274,7 @@ struct MfmaPlan {
 
 template <typename T>
 static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigned n, unsigned k,
-                      MfmaPlan<T>& P) {
+                      MfmaPlan<T>& P, bool for_tile = false) {
   constexpr unsigned CB = Vec<T>::VB;  // vector-component index bits: 2 (f32) / 1 (f64)
   if (k < 1 || k > 4) return false;
   std::vector<T> Us;
@@ -316,7 +316,7 @@ static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigne
   P.ilp = std::max(1, 8 / NL);
   if (NR < 0 || n < CB + na) return false;
   const uint64_t nslots = 1ull << (n - CB - na);
-  if (nslots < (uint64_t)P.ilp * 64) return false;
+  if (nslots < (for_tile ? 16u : (uint64_t)P.ilp * 64)) return false;  // tile mode: one wave iteration
   // roles: -1 = plane, otherwise index into E.  q gets the low address digits first
   // (positions 2..5: a permutation of a contiguous run), then the plane, then the rest.
   constexpr int PLANE = -1;
@@ -837,6 +837,79 @@ static int norm2_entry(const T* re, const T* im, uint64_t size, double* out) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------
+// apply_blocked: a list of gates inside one LDS tile, one HBM pass (device pointers, f32)
+// ---------------------------------------------------------------------------------
+static int apply_blocked_entry(float* re, float* im, unsigned n, const unsigned* tile_pos, unsigned tb,
+                               unsigned n_gates, const float* U_all, const unsigned* pos_all,
+                               const unsigned* k_all) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!re || !im || !tile_pos || (n_gates && (!U_all || !pos_all || !k_all))) return fail("apply_blocked: null pointer");
+  if (n_gates == 0) return 0;
+  if (n > 62 || tb > (unsigned)kBlockedMaxTileBits || tb < 10 || tb > n) return fail("apply_blocked: tile size out of range");
+  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("apply_blocked: device pointers only");
+  if ((reinterpret_cast<uintptr_t>(re) % 32) || (reinterpret_cast<uintptr_t>(im) % 32))
+    return fail("apply_blocked: planes must be 32-byte aligned");
+  BlockedArg ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.tb = tb;
+  int local_of[64];
+  for (int i = 0; i < 64; ++i) local_of[i] = -1;
+  for (unsigned i = 0; i < tb; ++i) {
+    if (tile_pos[i] >= n || (i && tile_pos[i] <= tile_pos[i - 1])) return fail("apply_blocked: tile positions must be ascending and < n");
+    ba.apos[i] = tile_pos[i];
+    local_of[tile_pos[i]] = (int)i;
+  }
+  if (tile_pos[0] != 0 || tile_pos[1] != 1) return fail("apply_blocked: the tile must contain index bits 0 and 1");
+  std::vector<BlockedGate> gates(n_gates);
+  std::vector<float> Atab;
+  const float* Up = U_all;
+  const unsigned* pp = pos_all;
+  for (unsigned g = 0; g < n_gates; ++g) {
+    const unsigned k = k_all[g];
+    if (k < 1 || k > 4) return fail("apply_blocked: gates must have 1..4 targets");
+    unsigned lp[4];
+    for (unsigned j = 0; j < k; ++j) {
+      if (pp[j] >= 64 || local_of[pp[j]] < 0) return fail("apply_blocked: gate target outside the tile");
+      lp[j] = (unsigned)local_of[pp[j]];
+    }
+    if (check_positions(lp, tb, k)) return fail("apply_blocked: duplicate targets");
+    MfmaPlan<float> P;
+    if (!plan_mfma<float>(c, Up, lp, tb, k, P, true)) return fail("apply_blocked: cannot plan an inner gate");
+    BlockedGate& G = gates[g];
+    memset(&G, 0, sizeof(G));
+    G.ro = P.ro;
+    for (int m = 0; m < 4; ++m)
+      if (G.ro.pos[m] >= 31) G.ro.pos[m] = 31;
+    G.a_off = (unsigned)Atab.size();
+    G.kv = (unsigned)(P.kbits * 4 + P.vmask);
+    G.n_addr = P.n_addr;
+    Atab.insert(Atab.end(), P.A.begin(), P.A.end());
+    Up += (size_t)2 << (2 * k);
+    pp += k;
+  }
+  void *dG = nullptr, *dA = nullptr;
+  if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
+  if (arena_upload(c, Atab.data(), Atab.size() * sizeof(float), &dA)) return 1;
+  const size_t lds = ((size_t)2 << tb) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_f32_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const uint64_t ntiles = 1ull << (n - tb);
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * (tb <= 13 ? 2 : 1) * 2);
+  hipLaunchKernelGGL(apply_blocked_f32_kernel, dim3(grid), dim3(kBlock), lds, c.stream, re, im,
+                     (const BlockedGate*)dG, n_gates, (const float*)dA, ba, ntiles);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "blocked";
+  c.last_desc = "apply_blocked_f32_kernel tb=" + std::to_string(tb) + " gates=" + std::to_string(n_gates);
+  return 0;
+}
+
 template <typename T>
 static int probabilities_entry(const T* re, const T* im, unsigned n, const unsigned* pos, unsigned k,
                                double* out) {
@@ -992,6 +1065,12 @@ int hq_vdot_float32(const float* are, const float* aim, const float* bre, const 
 int hq_vdot_float64(const double* are, const double* aim, const double* bre, const double* bim,
                     uint64_t size, double* out) {
   return hq::vdot_entry<double>(are, aim, bre, bim, size, out);
+}
+
+int hq_apply_blocked_float32(float* re, float* im, unsigned int n, const unsigned int* tile_pos,
+                             unsigned int tile_bits, unsigned int n_gates, const float* U_all,
+                             const unsigned int* pos_all, const unsigned int* k_all) {
+  return hq::apply_blocked_entry(re, im, n, tile_pos, tile_bits, n_gates, U_all, pos_all, k_all);
 }
 
 int hq_set_stream(void* hip_stream) {

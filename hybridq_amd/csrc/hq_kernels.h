@@ -286,6 +286,156 @@ apply_mfma_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------
+// apply_blocked (f32): MANY gates in ONE HBM pass.
+//
+// The per-gate kernels above sit at the memory system's ceiling (~3 ms per pass at n = 30),
+// so the remaining lever is fewer passes.  A workgroup stages a tile of 2^TB amplitudes
+// (TB = 13: 2 x 32 KiB of LDS, two workgroups per CU) spanned by TB chosen index bits --
+// the low bits (coalescing) plus any others -- applies a whole LIST of gates whose targets
+// all lie inside those bits with the same role-assigned MFMA scheme as apply_mfma, now
+// reading/writing LDS (ds_read_b128 / ds_write_b128, one workgroup barrier per gate), and
+// streams the tile back.  HBM traffic is one read + one write of the state for the whole
+// list; each inner gate costs MFMA time only (~0.45 ms for k <= 3, ~0.9 ms for k = 4 at
+// n = 30, vs ~3.1 ms for a pass of its own).  The host planner (hybridq_amd/blocking.py)
+// picks the tile bits and the gate lists from the circuit's dependency DAG.
+// ---------------------------------------------------------------------------------
+constexpr int kBlockedMaxTileBits = 14;
+struct BlockedArg {
+  unsigned tb;                          // tile bits
+  unsigned apos[kBlockedMaxTileBits];   // their global index positions, ascending (apos[0..1] = 0,1)
+};
+struct BlockedGate {
+  MfmaRoles ro;      // roles in TILE-LOCAL coordinates (vec position = local bit - 2; unused = 31)
+  unsigned a_off;    // offset (elements) of this gate's A table
+  unsigned kv;       // kbits * 4 + vmask
+  unsigned n_addr;   // number of address digits
+  unsigned pad_;
+};
+
+template <int KBITS, int VMASK>
+__device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float* __restrict__ xi,
+                                                   const BlockedGate& G, const float* __restrict__ A,
+                                                   const unsigned tile_vec_bits) {
+  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
+  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (2 - KV), NSTEP = 1 << NS;
+  constexpr int FMASK = ~VMASK & 3;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, j = lane & 15;
+  const MfmaRoles& ro = G.ro;
+  float a[NRB][NSTEP];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
+  const unsigned lane_off = ((q & 1) ? ro.q_off[0] : 0u) | ((q & 2) ? ro.q_off[1] : 0u);
+  const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
+  unsigned off[NL], pl[NL];
+#pragma unroll
+  for (int ld = 0; ld < NL; ++ld) {
+    unsigned o = 0;
+#pragma unroll
+    for (int b = 0; b < NR; ++b)
+      if ((ld >> b) & 1) o |= ro.r_off[b];
+    off[ld] = o;
+    pl[ld] = ro.r_plane >= 0 ? ((ld >> ro.r_plane) & 1u) : 0u;
+  }
+  const unsigned niter = (1u << (tile_vec_bits - G.n_addr)) >> 4;  // 16 slots per wave iteration
+  for (unsigned it = wave; it < niter; it += kBlock / 64) {
+    unsigned v = it * 16 + j;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const unsigned lo = (1u << ro.pos[m]) - 1;  // unused digits carry 31: no-op
+      v = ((v & ~lo) << 1) | (v & lo);
+    }
+    v |= lane_off;
+    f32x4* ptr[NL];
+    f32x4 x[NL];
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      ptr[ld] = reinterpret_cast<f32x4*>((lane_plane | pl[ld]) ? xi : xr) + (v | off[ld]);
+      x[ld] = *ptr[ld];
+    }
+    f32x4 acc[NCB][NRB];
+#pragma unroll
+    for (int cf = 0; cf < NCB; ++cf)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const int ck = s & ((1 << KV) - 1), ld = s >> KV;
+#pragma unroll
+      for (int cf = 0; cf < NCB; ++cf) {
+        const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+          acc[cf][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][s], x[ld][comp], acc[cf][rb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      f32x4 y;
+#pragma unroll
+      for (int comp = 0; comp < 4; ++comp) {
+        const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
+        const int so = ck | (ld << KV);
+        y[comp] = acc[cf][so >> 2][so & 3];
+      }
+      *ptr[ld] = y;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+apply_blocked_f32_kernel(float* __restrict__ re, float* __restrict__ im,
+                         const BlockedGate* __restrict__ gates, const unsigned ngates,
+                         const float* __restrict__ Atab, const BlockedArg ba, const uint64_t ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* xr = reinterpret_cast<float*>(smem);
+  float* xi = xr + (1u << ba.tb);
+  const unsigned tid = threadIdx.x;
+  const unsigned tvb = ba.tb - 2, nvec = 1u << tvb;
+  f32x4* __restrict__ vre = reinterpret_cast<f32x4*>(re);
+  f32x4* __restrict__ vim = reinterpret_cast<f32x4*>(im);
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint64_t base = tile;  // in 16-byte vector units: tile positions minus the two component bits
+    for (unsigned m = 2; m < ba.tb; ++m) {
+      const uint64_t lo = (1ull << (ba.apos[m] - 2)) - 1;
+      base = ((base & ~lo) << 1) | (base & lo);
+    }
+    for (unsigned e = tid; e < nvec; e += kBlock) {
+      uint64_t g = base;
+      for (unsigned m = 2; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - 2)) & 1u) << (ba.apos[m] - 2);
+      reinterpret_cast<f32x4*>(xr)[e] = vre[g];
+      reinterpret_cast<f32x4*>(xi)[e] = vim[g];
+    }
+    __syncthreads();
+    for (unsigned gi = 0; gi < ngates; ++gi) {
+      const BlockedGate& G = gates[gi];
+      const float* A = Atab + G.a_off;
+      switch (G.kv) {
+        case 16: blocked_inner_gate<4, 0>(xr, xi, G, A, tvb); break;
+        case 17: blocked_inner_gate<4, 1>(xr, xi, G, A, tvb); break;
+        case 18: blocked_inner_gate<4, 2>(xr, xi, G, A, tvb); break;
+        case 19: blocked_inner_gate<4, 3>(xr, xi, G, A, tvb); break;
+        case 20: blocked_inner_gate<5, 0>(xr, xi, G, A, tvb); break;
+        case 21: blocked_inner_gate<5, 1>(xr, xi, G, A, tvb); break;
+        case 22: blocked_inner_gate<5, 2>(xr, xi, G, A, tvb); break;
+        case 23: blocked_inner_gate<5, 3>(xr, xi, G, A, tvb); break;
+        default: break;
+      }
+      __syncthreads();
+    }
+    for (unsigned e = tid; e < nvec; e += kBlock) {
+      uint64_t g = base;
+      for (unsigned m = 2; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - 2)) & 1u) << (ba.apos[m] - 2);
+      vre[g] = reinterpret_cast<f32x4*>(xr)[e];
+      vim[g] = reinterpret_cast<f32x4*>(xi)[e];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // apply_generic (LDS tile)
 // ---------------------------------------------------------------------------------
 constexpr int kMaxK = 10;

@@ -544,3 +544,40 @@ def test_expectation_value(torch_cuda, ct):
     assert isinstance(v, float) and abs(v - (t * sign).sum()) < 1e-12
     with pytest.raises(ValueError):
         expectation_value(psi.reshape((2,) * n), [(z, (99,))], qubits_order=list(range(n)))
+
+
+def test_apply_blocked_matches_gate_by_gate(torch_cuda, oracle_port):
+    """hq_apply_blocked_float32: a list of k<=4 gates inside one LDS tile in ONE pass == the
+    same gates applied one by one by the oracle (non-unitary U, targets in the vector
+    components, in the low bits and among the high tile bits; several tile sizes)."""
+    from hybridq_amd import core
+    from oracle.binding import aligned_empty
+    torch = torch_cuda
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(21)
+    ft = np.dtype('float32')
+    for n, tb, ngates in ((18, 13, 14), (17, 14, 9), (16, 13, 30), (14, 10, 6), (13, 13, 5), (20, 12, 8)):
+        high = np.sort(rng.permutation(np.arange(5, n))[:tb - 5]) if n > tb else np.arange(5, n)
+        tile = np.concatenate([np.arange(5), high]).astype(np.uint32)
+        assert len(tile) == tb
+        gates = []
+        for _ in range(ngates):
+            k = int(rng.integers(1, 5))
+            pos = rng.permutation(tile)[:k]
+            gates.append((_rand_U(rng, k) * (1.0 if k > 1 else 1.3), pos))
+        re, im = _rand_state(rng, n, ft)
+        pl = aligned_empty((2, 1 << n), ft)
+        pl[0], pl[1] = re, im
+        for U, pos in gates:
+            assert oracle_port.apply_U(pl[0], pl[1], U, pos) == 0
+        dre, dim_ = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+        core.apply_blocked(dre, dim_, tile, gates)
+        core.sync()
+        assert core.last_kernel() == 'blocked'
+        err = _relerr(dre.cpu().numpy(), dim_.cpu().numpy(), pl[0], pl[1])
+        assert err <= 5e-6, (n, tb, ngates, err)
+    # argument validation
+    with pytest.raises(core.HQError):
+        core.apply_blocked(dre, dim_, np.arange(2, 15), gates[:1])  # tile without bits 0, 1
+    with pytest.raises(core.HQError):
+        core.apply_blocked(dre, dim_, np.arange(12), [(np.eye(2), [15])])  # target outside the tile
