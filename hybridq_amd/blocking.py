@@ -1,0 +1,121 @@
+"""Cache-blocked scheduling: many gates per HBM pass (driver side of ``hq_apply_blocked_*``).
+
+Every k <= 4 gate kernel already runs at the memory system's ceiling (one pass over the
+state, ~3 ms at n = 30), so the remaining lever is FEWER passes.  A blocked pass stages
+tiles of 2^tile_bits amplitudes in LDS -- the index bits of a tile are the low
+``low_bits`` positions (coalescing) plus ``tile_bits - low_bits`` freely chosen ones --
+and applies every gate of a list whose targets lie inside those bits before the tile goes
+back to HBM.  This module decides which bits and which gates:
+
+  * gates are list-scheduled over their dependency DAG (per-qubit program order), so a pass
+    may run arbitrarily far ahead on the qubits it holds;
+  * the free tile positions are chosen greedily: seed with the ready gates in program
+    order while they fit, then keep absorbing whatever becomes ready inside the tile, and
+    spend spare capacity on the ready gate that needs the fewest new positions;
+  * the gates of a pass are fused (``fusion.fuse``) up to ``inner_max`` qubits, because an
+    inner gate costs matrix-core time only (k <= 3: ~0.75 ms, k = 4: ~1.3 ms at n = 30);
+  * passes that would hold fewer than ``min_gates`` gates are emitted as plain gates.
+
+There is no reference counterpart (the reference applies one fused gate per pass,
+hybridq/circuit/simulation/simulation.py:522-646); results are identical up to rounding.
+"""
+from collections import deque
+
+import numpy as np
+
+from .fusion import fuse
+
+
+def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_gates=3):
+    """Schedule `gates` ([(U, qubits), ...]) given the placement ``pos_of[qubit] = position``.
+
+    Returns a list of ops:
+        ('B', tile_pos uint32[tile_bits] ascending, [(U, positions LSB-first), ...])
+        ('G', U, positions LSB-first)"""
+    tile_bits = min(tile_bits, n)
+    low_bits = min(low_bits, tile_bits)
+    gq = [tuple(qs) for _, qs in gates]
+    qubits = sorted(pos_of, key=lambda q: pos_of[q])
+    queues = {q: deque() for q in qubits}
+    for gi, qs in enumerate(gq):
+        for q in qs:
+            queues[q].append(gi)
+    done = 0
+    ops = []
+    low = set(range(low_bits))
+
+    def heads():
+        return sorted({queues[q][0] for q in qubits if queues[q]})
+
+    def ready(gi):
+        return all(queues[q][0] == gi for q in gq[gi])
+
+    def gpos(gi):
+        return {pos_of[q] for q in gq[gi]}
+
+    def take(gi, chosen):
+        chosen.append(gi)
+        for q in gq[gi]:
+            queues[q].popleft()
+
+    while done < len(gates):
+        S = set(low)
+        chosen = []
+        progress = True
+        while progress:
+            progress = False
+            # everything ready that already fits
+            for gi in heads():
+                if ready(gi) and gpos(gi) <= S:
+                    take(gi, chosen)
+                    progress = True
+            if progress:
+                continue
+            # spend spare capacity on the ready gate that needs the fewest new positions
+            best, best_new = None, None
+            for gi in heads():
+                if not ready(gi) or len(gq[gi]) > 4:
+                    continue
+                new = gpos(gi) - S
+                if len(S) + len(new) <= tile_bits and (best is None or len(new) < len(best_new)):
+                    best, best_new = gi, new
+            if best is not None:
+                S |= best_new
+                take(best, chosen)
+                progress = True
+        if not chosen:  # a gate that does not fit any tile (k > 4 or > tile_bits): run it on its own
+            gi = next(g for g in heads() if ready(g))
+            take(gi, chosen)
+            ops.append(('G', np.asarray(gates[gi][0]), [pos_of[q] for q in reversed(gq[gi])]))
+            done += 1
+            continue
+        done += len(chosen)
+        if len(chosen) < min_gates:
+            for gi in chosen:
+                ops.append(('G', np.asarray(gates[gi][0]), [pos_of[q] for q in reversed(gq[gi])]))
+            continue
+        # pad the tile with the lowest unused positions (any bits do; low ones coalesce best)
+        p = 0
+        while len(S) < tile_bits:
+            if p not in S:
+                S.add(p)
+            p += 1
+        if inner_max:
+            inner = fuse([gates[gi] for gi in chosen], inner_max, complex_type='complex64')
+        else:
+            inner = [(np.asarray(gates[gi][0]), gq[gi]) for gi in chosen]
+        ops.append(('B', np.asarray(sorted(S), dtype=np.uint32),
+                    [(U, [pos_of[q] for q in reversed(qs)]) for U, qs in inner]))
+    return ops
+
+
+def blocked_stats(ops):
+    nb = sum(1 for op in ops if op[0] == 'B')
+    ng = sum(1 for op in ops if op[0] == 'G')
+    inner = [len(op[2]) for op in ops if op[0] == 'B']
+    ks = {}
+    for op in ops:
+        if op[0] == 'B':
+            for _, p in op[2]:
+                ks[len(p)] = ks.get(len(p), 0) + 1
+    return {'blocked_passes': nb, 'plain_gates': ng, 'inner_gates': int(sum(inner)), 'inner_k_histogram': ks}

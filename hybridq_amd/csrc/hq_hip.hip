@@ -896,14 +896,22 @@ static int apply_blocked_entry(float* re, float* im, unsigned n, const unsigned*
   const size_t lds = ((size_t)2 << tb) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_f32_kernel,
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_f32_kernel<256>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_f32_kernel<512>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   const uint64_t ntiles = 1ull << (n - tb);
-  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * (tb <= 13 ? 2 : 1) * 2);
-  hipLaunchKernelGGL(apply_blocked_f32_kernel, dim3(grid), dim3(kBlock), lds, c.stream, re, im,
-                     (const BlockedGate*)dG, n_gates, (const float*)dA, ba, ntiles);
+  const unsigned per_cu = tb <= 12 ? 4 : (tb == 13 ? 2 : 1);
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
+  static int block_threads = getenv("HQ_BLOCKED_THREADS") ? atoi(getenv("HQ_BLOCKED_THREADS")) : 512;
+  if (block_threads == 256)
+    hipLaunchKernelGGL(apply_blocked_f32_kernel<256>, dim3(grid), dim3(256), lds, c.stream, re, im,
+                       (const BlockedGate*)dG, n_gates, (const float*)dA, ba, ntiles);
+  else
+    hipLaunchKernelGGL(apply_blocked_f32_kernel<512>, dim3(grid), dim3(512), lds, c.stream, re, im,
+                       (const BlockedGate*)dG, n_gates, (const float*)dA, ba, ntiles);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "blocked";
   c.last_desc = "apply_blocked_f32_kernel tb=" + std::to_string(tb) + " gates=" + std::to_string(n_gates);

@@ -312,7 +312,7 @@ struct BlockedGate {
   unsigned pad_;
 };
 
-template <int KBITS, int VMASK>
+template <int KBITS, int VMASK, int BLOCK>
 __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float* __restrict__ xi,
                                                    const BlockedGate& G, const float* __restrict__ A,
                                                    const unsigned tile_vec_bits) {
@@ -340,7 +340,7 @@ __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float
     pl[ld] = ro.r_plane >= 0 ? ((ld >> ro.r_plane) & 1u) : 0u;
   }
   const unsigned niter = (1u << (tile_vec_bits - G.n_addr)) >> 4;  // 16 slots per wave iteration
-  for (unsigned it = wave; it < niter; it += kBlock / 64) {
+  for (unsigned it = wave; it < niter; it += BLOCK / 64) {
     unsigned v = it * 16 + j;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -385,7 +385,8 @@ __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float
   }
 }
 
-__global__ void __launch_bounds__(kBlock)
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 apply_blocked_f32_kernel(float* __restrict__ re, float* __restrict__ im,
                          const BlockedGate* __restrict__ gates, const unsigned ngates,
                          const float* __restrict__ Atab, const BlockedArg ba, const uint64_t ntiles) {
@@ -402,7 +403,7 @@ apply_blocked_f32_kernel(float* __restrict__ re, float* __restrict__ im,
       const uint64_t lo = (1ull << (ba.apos[m] - 2)) - 1;
       base = ((base & ~lo) << 1) | (base & lo);
     }
-    for (unsigned e = tid; e < nvec; e += kBlock) {
+    for (unsigned e = tid; e < nvec; e += BLOCK) {
       uint64_t g = base;
       for (unsigned m = 2; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - 2)) & 1u) << (ba.apos[m] - 2);
       reinterpret_cast<f32x4*>(xr)[e] = vre[g];
@@ -413,19 +414,19 @@ apply_blocked_f32_kernel(float* __restrict__ re, float* __restrict__ im,
       const BlockedGate& G = gates[gi];
       const float* A = Atab + G.a_off;
       switch (G.kv) {
-        case 16: blocked_inner_gate<4, 0>(xr, xi, G, A, tvb); break;
-        case 17: blocked_inner_gate<4, 1>(xr, xi, G, A, tvb); break;
-        case 18: blocked_inner_gate<4, 2>(xr, xi, G, A, tvb); break;
-        case 19: blocked_inner_gate<4, 3>(xr, xi, G, A, tvb); break;
-        case 20: blocked_inner_gate<5, 0>(xr, xi, G, A, tvb); break;
-        case 21: blocked_inner_gate<5, 1>(xr, xi, G, A, tvb); break;
-        case 22: blocked_inner_gate<5, 2>(xr, xi, G, A, tvb); break;
-        case 23: blocked_inner_gate<5, 3>(xr, xi, G, A, tvb); break;
+        case 16: blocked_inner_gate<4, 0, BLOCK>(xr, xi, G, A, tvb); break;
+        case 17: blocked_inner_gate<4, 1, BLOCK>(xr, xi, G, A, tvb); break;
+        case 18: blocked_inner_gate<4, 2, BLOCK>(xr, xi, G, A, tvb); break;
+        case 19: blocked_inner_gate<4, 3, BLOCK>(xr, xi, G, A, tvb); break;
+        case 20: blocked_inner_gate<5, 0, BLOCK>(xr, xi, G, A, tvb); break;
+        case 21: blocked_inner_gate<5, 1, BLOCK>(xr, xi, G, A, tvb); break;
+        case 22: blocked_inner_gate<5, 2, BLOCK>(xr, xi, G, A, tvb); break;
+        case 23: blocked_inner_gate<5, 3, BLOCK>(xr, xi, G, A, tvb); break;
         default: break;
       }
       __syncthreads();
     }
-    for (unsigned e = tid; e < nvec; e += kBlock) {
+    for (unsigned e = tid; e < nvec; e += BLOCK) {
       uint64_t g = base;
       for (unsigned m = 2; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - 2)) & 1u) << (ba.apos[m] - 2);
       vre[g] = reinterpret_cast<f32x4*>(xr)[e];

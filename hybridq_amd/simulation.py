@@ -200,7 +200,9 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     ``max_largest_intermediate`` (default 2**36 amplitudes: one MI355X holds n=34 in
     complex64), ``compress`` (max qubits of a fused gate, default 4 like simulation.py:314;
     0 applies the gates as given; a dict may carry ``max_n_qubits`` plus the keyword
-    arguments of ``fusion.fuse``), ``device``.  ``simplify`` (the reference's commuting-gate
+    arguments of ``fusion.fuse``), ``device``, ``blocked`` (default False; True or a dict of
+    ``blocking.plan_blocked`` options: apply many gates per HBM pass through LDS tiles,
+    complex64 only, n >= 14 -- see hybridq_amd/blocking.py).  ``simplify`` (the reference's commuting-gate
     reordering / inverse cancellation, circuit/utils.py:825) is a host-side IR transform
     upstream of this path and is not reproduced: gates are fused in the order given.
     """
@@ -229,10 +231,19 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
     gates, run = [], []
 
+    blocked = kwargs.get('blocked', False)
+    use_blocked = bool(blocked) and ctype == np.dtype('complex64') and n >= 14
+    pos_of = {q: n - x - 1 for x, q in enumerate(qubits)}  # simulation.py:512 (never permuted here)
+
     def flush():
         if not run:
             return
-        if comp_n:
+        if use_blocked:
+            # many gates per HBM pass (hybridq_amd.blocking); inner fusion replaces `compress`
+            from .blocking import plan_blocked
+            opts = blocked if isinstance(blocked, dict) else {}
+            gates.extend(plan_blocked([(U, qs) for qs, U in run], pos_of, n, **opts))
+        elif comp_n:
             from .fusion import fuse
             gates.extend((qs, U) for U, qs in fuse([(U, qs) for qs, U in run], comp_n, complex_type=ctype, **comp_kw))
         else:
@@ -255,15 +266,24 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     info = {}
     core.sync()
     t0 = time.perf_counter()  # simulation.py:519
+    n_passes = 0
     for g in gates:
         if _is_functional(g):
             state.apply_functional(g)
+        elif isinstance(g[0], str):  # ops of the blocked planner, positions already physical
+            n_passes += 1
+            if g[0] == 'B':
+                core.apply_blocked(state.planes[0], state.planes[1], g[1], g[2], n)
+            else:
+                core.apply_U(state.planes[0], state.planes[1], g[1], g[2], n)
         else:
+            n_passes += 1
             state.apply(g[1], g[0])
     core.sync()  # the ONLY synchronisation of the loop
     t1 = time.perf_counter()  # simulation.py:666
     info['runtime (s)'] = t1 - t0
     info['n_gates'] = len(gates)  # apply_U calls issued (after fusion)
+    info['n_passes'] = n_passes  # passes over the state (blocked passes count once)
     info['n_gates_given'] = n_given
     info['n_qubits'] = n
 

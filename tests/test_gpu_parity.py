@@ -581,3 +581,39 @@ def test_apply_blocked_matches_gate_by_gate(torch_cuda, oracle_port):
         core.apply_blocked(dre, dim_, np.arange(2, 15), gates[:1])  # tile without bits 0, 1
     with pytest.raises(core.HQError):
         core.apply_blocked(dre, dim_, np.arange(12), [(np.eye(2), [15])])  # target outside the tile
+
+
+def test_simulate_blocked_matches_oracle(torch_cuda, oracle_port):
+    """simulate(blocked=True): the cache-blocked schedule (many gates per LDS-tile pass, inner
+    fusion) gives the same state as gate-by-gate evolution; far fewer passes than gates."""
+    import oracle
+    from hybridq_amd.blocking import blocked_stats, plan_blocked
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    from hybridq_amd.simulation import FunctionalGate, simulate
+    for n, gates in ((18, rqc_1q2q(18, depth=12, seed=3)), (16, random_dense(16, 120, kmax=4, seed=4)),
+                     (20, rqc_1q2q(20, depth=10, seed=5))):
+        exp = oracle.evolve_tensordot(gates, n)
+        for opts in (True, {'tile_bits': 12, 'low_bits': 4, 'inner_max': 4}, {'tile_bits': 14, 'inner_max': 0}):
+            psi, info = simulate(gates, initial_state='0' * n, complex_type='complex64', blocked=opts,
+                                 return_info=True, qubits=list(range(n)))
+            err = np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max()
+            assert err < 5e-6, (n, opts, err)
+            assert info['n_passes'] < len(gates) / 3
+    # every gate is scheduled exactly once and dependencies are kept (pure planner check)
+    n = 22
+    gates = rqc_1q2q(n, depth=16, seed=6)
+    ops = plan_blocked(gates, {q: n - 1 - q for q in range(n)}, n, inner_max=0)
+    st = blocked_stats(ops)
+    assert st['inner_gates'] + st['plain_gates'] == len(gates)
+    for op in ops:
+        if op[0] == 'B':
+            tile = set(int(p) for p in op[1])
+            assert len(tile) == 13 and {0, 1} <= tile
+            assert all(set(pos) <= tile for _, pos in op[2])
+    # a functional gate cuts the schedule
+    seen = []
+    fg = FunctionalGate((0,), lambda psi, order: (seen.append(1) or psi, order))
+    g = rqc_1q2q(16, depth=6, seed=7)
+    psi = simulate(g[:50] + [fg] + g[50:], initial_state='0' * 16, blocked=True, qubits=list(range(16)))
+    exp = oracle.evolve_tensordot(g, 16)
+    assert seen and np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max() < 5e-6
