@@ -9,9 +9,9 @@ back to HBM.  This module decides which bits and which gates:
 
   * gates are list-scheduled over their dependency DAG (per-qubit program order), so a pass
     may run arbitrarily far ahead on the qubits it holds;
-  * the free tile positions are chosen greedily: seed with the ready gates in program
-    order while they fit, then keep absorbing whatever becomes ready inside the tile, and
-    spend spare capacity on the ready gate that needs the fewest new positions;
+  * the free tile positions are chosen greedily: absorb whatever is ready inside the tile,
+    spend spare capacity on the ready gate that needs the fewest new positions, repeat;
+    several visiting orders are tried per pass and the one absorbing most gates wins;
   * the gates of a pass are fused (``fusion.fuse``) up to ``inner_max`` qubits, because an
     inner gate costs matrix-core time only (k <= 3: ~0.75 ms, k = 4: ~1.3 ms at n = 30);
   * passes that would hold fewer than ``min_gates`` gates are emitted as plain gates.
@@ -26,15 +26,20 @@ import numpy as np
 from .fusion import fuse
 
 
-def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_gates=3):
+def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_gates=3, tries=16, seed=0):
     """Schedule `gates` ([(U, qubits), ...]) given the placement ``pos_of[qubit] = position``.
 
     Returns a list of ops:
         ('B', tile_pos uint32[tile_bits] ascending, [(U, positions LSB-first), ...])
-        ('G', U, positions LSB-first)"""
+        ('G', U, positions LSB-first)
+    ``tries`` > 1: each pass is grown from several (seeded, deterministic) visiting orders of
+    the ready gates and the one that absorbs the most gates is kept (n=30 depth-40 circuit:
+    34 -> 30 passes for 16 tries, ~0.2 s of host time)."""
+    import random
     tile_bits = min(tile_bits, n)
     low_bits = min(low_bits, tile_bits)
     gq = [tuple(qs) for _, qs in gates]
+    gp = [frozenset(pos_of[q] for q in qs) for qs in gq]
     qubits = sorted(pos_of, key=lambda q: pos_of[q])
     queues = {q: deque() for q in qubits}
     for gi, qs in enumerate(gq):
@@ -42,60 +47,74 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_ga
             queues[q].append(gi)
     done = 0
     ops = []
-    low = set(range(low_bits))
+    low = frozenset(range(low_bits))
+    rnd = random.Random(seed)
 
-    def heads():
-        return sorted({queues[q][0] for q in qubits if queues[q]})
-
-    def ready(gi):
-        return all(queues[q][0] == gi for q in gq[gi])
-
-    def gpos(gi):
-        return {pos_of[q] for q in gq[gi]}
-
-    def take(gi, chosen):
-        chosen.append(gi)
-        for q in gq[gi]:
-            queues[q].popleft()
-
-    while done < len(gates):
+    def grow(queues, order_key):
+        """One candidate pass: returns (chosen gate indices in execution order, tile set, queues after)."""
+        queues = {q: deque(v) for q, v in queues.items()}
         S = set(low)
         chosen = []
+
+        def heads():
+            return sorted({queues[q][0] for q in qubits if queues[q]}, key=order_key)
+
+        def ready(gi):
+            return all(queues[q][0] == gi for q in gq[gi])
+
+        def take(gi):
+            chosen.append(gi)
+            for q in gq[gi]:
+                queues[q].popleft()
+
         progress = True
         while progress:
             progress = False
-            # everything ready that already fits
-            for gi in heads():
-                if ready(gi) and gpos(gi) <= S:
-                    take(gi, chosen)
+            for gi in heads():  # everything ready that already fits
+                if len(gq[gi]) <= 4 and ready(gi) and gp[gi] <= S:
+                    take(gi)
                     progress = True
             if progress:
                 continue
-            # spend spare capacity on the ready gate that needs the fewest new positions
-            best, best_new = None, None
+            best, best_new = None, None  # spend spare capacity on the cheapest ready gate
             for gi in heads():
                 if not ready(gi) or len(gq[gi]) > 4:
                     continue
-                new = gpos(gi) - S
+                new = gp[gi] - S
                 if len(S) + len(new) <= tile_bits and (best is None or len(new) < len(best_new)):
                     best, best_new = gi, new
             if best is not None:
                 S |= best_new
-                take(best, chosen)
+                take(best)
                 progress = True
-        if not chosen:  # a gate that does not fit any tile (k > 4 or > tile_bits): run it on its own
-            gi = next(g for g in heads() if ready(g))
-            take(gi, chosen)
+        return chosen, S, queues
+
+    while done < len(gates):
+        best = None
+        for t in range(max(1, tries)):
+            if t == 0:
+                key = lambda g: g  # noqa: E731  (program order)
+            else:
+                r = {}
+                key = lambda g, r=r: r.setdefault(g, rnd.random())  # noqa: E731
+            cand = grow(queues, key)
+            if best is None or len(cand[0]) > len(best[0]):
+                best = cand
+        chosen, S, new_queues = best
+        if not chosen:  # a gate that fits no tile (k > 4): run it on its own
+            gi = min(queues[q][0] for q in qubits if queues[q] and all(queues[x][0] == queues[q][0] for x in gq[queues[q][0]]))
+            for q in gq[gi]:
+                queues[q].popleft()
             ops.append(('G', np.asarray(gates[gi][0]), [pos_of[q] for q in reversed(gq[gi])]))
             done += 1
             continue
+        queues = new_queues
         done += len(chosen)
         if len(chosen) < min_gates:
             for gi in chosen:
                 ops.append(('G', np.asarray(gates[gi][0]), [pos_of[q] for q in reversed(gq[gi])]))
             continue
-        # pad the tile with the lowest unused positions (any bits do; low ones coalesce best)
-        p = 0
+        p = 0  # pad the tile with the lowest unused positions (any bits do; low ones coalesce best)
         while len(S) < tile_bits:
             if p not in S:
                 S.add(p)
