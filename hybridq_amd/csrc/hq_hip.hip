@@ -41,6 +41,7 @@ struct Context {
   size_t scratch_size[3] = {0, 0, 0};
   bool attr_set = false;
   bool env_read = false;
+  int device = -1;  // device that owns the arena / scratch buffers (one device per process)
 };
 
 static Context& ctx() {
@@ -77,7 +78,21 @@ static void read_env(Context& c) {
   if (const char* e = getenv("HQ_NONTEMPORAL")) c.nontemporal = atoi(e) < 0 ? -1 : (atoi(e) != 0);
 }
 
+// The library keeps its upload arena and scratch buffers on ONE device: the design is one
+// process per GPU (hybridq_amd.dist).  Using a second device from the same process is refused
+// loudly instead of silently reading another device's memory.
+static int check_device(Context& c) {
+  int dev = -1;
+  HQ_HIP_CHECK(hipGetDevice(&dev));
+  if (c.device < 0) c.device = dev;
+  if (dev != c.device)
+    return fail("libhq_hip is bound to device " + std::to_string(c.device) + " but the current device is " +
+                std::to_string(dev) + ": use one process per GPU");
+  return 0;
+}
+
 static int get_scratch(Context& c, int slot, size_t bytes, void** out) {
+  if (check_device(c)) return 1;
   if (c.scratch_size[slot] < bytes) {
     if (c.scratch[slot]) {
       HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
@@ -97,6 +112,7 @@ static int get_scratch(Context& c, int slot, size_t bytes, void** out) {
 // transfer is asynchronous on the stream.
 static int arena_upload(Context& c, const void* host, size_t bytes, void** dev) {
   const size_t kArena = 64u << 20;
+  if (check_device(c)) return 1;
   if (!c.arena_host) {
     HQ_HIP_CHECK(hipHostMalloc((void**)&c.arena_host, kArena, hipHostMallocDefault));
     HQ_HIP_CHECK(hipMalloc((void**)&c.arena_dev, kArena));

@@ -368,7 +368,11 @@ __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float
         const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
+#ifdef HQ_EXP_NO_MFMA  // experiment: LDS traffic only
+          acc[cf][rb] += x[ld][comp] * a[rb][s];
+#else
           acc[cf][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][s], x[ld][comp], acc[cf][rb], 0, 0, 0);
+#endif
       }
     }
 #pragma unroll
@@ -380,7 +384,11 @@ __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float
         const int so = ck | (ld << KV);
         y[comp] = acc[cf][so >> 2][so & 3];
       }
+#ifdef HQ_EXP_NO_WRITE  // experiment: keep the result alive without the LDS store
+      asm volatile("" ::"v"(y));
+#else
       *ptr[ld] = y;
+#endif
     }
   }
 }

@@ -32,10 +32,13 @@ def run(tile, gates, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-for tb, hi in ((13, [7, 9, 12, 15, 18, 21, 25, 28]), (12, [9, 12, 15, 18, 21, 25, 28])):
+import itertools
+for (tb, hi), dm in itertools.product(((13, [7, 9, 12, 15, 18, 21, 25, 28]),), ('dummy=auto', 'dummy=comp', 'dummy=low')):
+    core.set_apply_mode(dm)
+    print(dm)
     tile = np.array(list(range(tb - len(hi))) + hi, dtype=np.uint32)
-    for k in (2, 4):
-        for ng in (1, 8, 16):
+    for k in (1, 2, 3):
+        for ng in (8, 16):
             gates = [(haar_unitary(1 << k, rng), rng.permutation(tile)[:k]) for _ in range(ng)]
             ms = run(tile, gates)
             print(f'tb={tb} tile_hi={hi[:3]}.. k={k} gates={ng:2d}  {ms:8.3f} ms  ({ms / ng:6.3f} ms/gate)', flush=True)
