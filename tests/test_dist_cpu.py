@@ -202,3 +202,43 @@ def test_plan_restore_properties():
                         cur[at[a]], cur[at[b]] = b, a
             assert all(cur[q] == n - 1 - q for q in qubits) and final == cur
             assert sum(op[0] == 'X' for op in ops) <= 3
+
+
+def _dm_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import golden_util as gu
+        from hybridq_amd.dist import ShardedEvolution
+        from hybridq_amd.dm import Kraus, to_statevector_circuit
+        z = gu.load('e2e_dm_circuit.npz')
+        circuit = []
+        for i, kind in enumerate(bytes(z['kinds']).decode()):
+            qs = tuple(int(q) for q in z[f'q{i}'])
+            circuit.append(Kraus(list(z[f'L{i}']), qs, s=z[f's{i}']) if kind == 'K' else (z[f'U{i}'], qs))
+        n = int(z['n_qubits'])
+        sv = to_statevector_circuit(circuit)
+        labels = [(0, q) for q in range(n)] + [(1, q) for q in range(n)]
+        sh = ShardedEvolution(2 * n, complex_type='complex128', initial_state='0' * (2 * n), qubits=labels,
+                              backend=CpuBackend(np.float64))
+        sh.simulate(sv, compress=4)
+        rho = sh.state_numpy()
+        if rank == 0:
+            np.save(os.path.join(out_dir, 'rho.npy'), rho)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_density_matrix_config5_shape(tmp_path):
+    """BASELINE config 5 in miniature: a noisy 6-qubit circuit = 12-qubit state vector with
+    tuple qubit labels (0,q)/(1,q) and non-unitary fused gates, sharded over 4 ranks."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import golden_util as gu
+    mp.spawn(_dm_worker, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    rho = np.load(os.path.join(str(tmp_path), 'rho.npy'))
+    exp = gu.load('e2e_dm_circuit.npz')['rho']
+    assert np.abs(rho - exp).max() / np.abs(exp).max() < 5e-6
