@@ -300,6 +300,11 @@ apply_mfma_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
 // picks the tile bits and the gate lists from the circuit's dependency DAG.
 // ---------------------------------------------------------------------------------
 constexpr int kBlockedMaxTileBits = 14;
+// LDS layout of a tile plane: 16-byte vector v lives at slot v ^ ((v >> 4) & 15).  The XOR
+// spreads the stride-2/4/8/16 vector patterns that inner gates with low tile-local targets
+// produce over all 16 vector slots of a 256-byte bank row (PMC before: 37-47 % of the LDS
+// cycles of the blocked kernel were bank conflicts).
+__device__ __forceinline__ unsigned blocked_swz(unsigned v) { return v ^ ((v >> 4) & 15u); }
 struct BlockedArg {
   unsigned tb;                          // tile bits
   unsigned apos[kBlockedMaxTileBits];   // their global index positions, ascending (apos[0..1] = 0,1)
@@ -352,7 +357,7 @@ __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float
     f32x4 x[NL];
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
-      ptr[ld] = reinterpret_cast<f32x4*>((lane_plane | pl[ld]) ? xi : xr) + (v | off[ld]);
+      ptr[ld] = reinterpret_cast<f32x4*>((lane_plane | pl[ld]) ? xi : xr) + blocked_swz(v | off[ld]);
       x[ld] = *ptr[ld];
     }
     f32x4 acc[NCB][NRB];
@@ -414,8 +419,8 @@ apply_blocked_f32_kernel(float* __restrict__ re, float* __restrict__ im,
     for (unsigned e = tid; e < nvec; e += BLOCK) {
       uint64_t g = base;
       for (unsigned m = 2; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - 2)) & 1u) << (ba.apos[m] - 2);
-      reinterpret_cast<f32x4*>(xr)[e] = vre[g];
-      reinterpret_cast<f32x4*>(xi)[e] = vim[g];
+      reinterpret_cast<f32x4*>(xr)[blocked_swz(e)] = vre[g];
+      reinterpret_cast<f32x4*>(xi)[blocked_swz(e)] = vim[g];
     }
     __syncthreads();
     for (unsigned gi = 0; gi < ngates; ++gi) {
@@ -437,8 +442,8 @@ apply_blocked_f32_kernel(float* __restrict__ re, float* __restrict__ im,
     for (unsigned e = tid; e < nvec; e += BLOCK) {
       uint64_t g = base;
       for (unsigned m = 2; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - 2)) & 1u) << (ba.apos[m] - 2);
-      vre[g] = reinterpret_cast<f32x4*>(xr)[e];
-      vim[g] = reinterpret_cast<f32x4*>(xi)[e];
+      vre[g] = reinterpret_cast<f32x4*>(xr)[blocked_swz(e)];
+      vim[g] = reinterpret_cast<f32x4*>(xi)[blocked_swz(e)];
     }
     __syncthreads();
   }
