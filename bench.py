@@ -48,8 +48,29 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU
+    boxes expose 256 hardware threads but a 16-CPU quota; 256 OpenMP threads on that run the
+    reference 15x SLOWER than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(gates, n, seconds, complex_type):
     """Time the reference C++ core (or the port) on a bounded prefix of the same circuit."""
+    import ctypes
     import oracle
     from oracle.binding import aligned_empty
     try:
@@ -67,6 +88,11 @@ def cpu_baseline(gates, n, seconds, complex_type):
     if n_cpu != n:  # same generator, fewer qubits (host RAM too small for the full state)
         from hybridq_amd.circuits import rqc_1q2q
         gates = rqc_1q2q(n_cpu, depth=40, seed=n)
+    threads = int(os.environ.get('OMP_NUM_THREADS', usable_cpus()))
+    try:
+        ctypes.CDLL('libgomp.so.1').omp_set_num_threads(threads)
+    except OSError:
+        pass
     planes = aligned_empty((2, 1 << n_cpu), ft)
     planes[:] = 0
     planes[0, 0] = 1
@@ -74,8 +100,6 @@ def cpu_baseline(gates, n, seconds, complex_type):
     _, info = oracle.evolve_reference_protocol(lib, gates, n_cpu, complex_type=complex_type, planes=planes,
                                                warmup_gates=warm, max_seconds=seconds, to_complex=False)
     gps = info['n_gates'] / info['runtime (s)']
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
-    threads = int(os.environ.get('OMP_NUM_THREADS', cores))
     return {
         'value': gps * (1 << n_cpu),
         'unit': 'amplitudes/s',
