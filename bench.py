@@ -331,15 +331,16 @@ def main():
             'logical_amplitudes_per_s': len(gates) / el * float(1 << n),
             'host_fusion_seconds_untimed': t_fuse,
         }
-    if rank == 0 and not sharded_path and not args.no_fused and args.dtype == 'complex64':
+    if rank == 0 and not sharded_path and not args.no_fused:
         # Cache-blocked execution (hybridq_amd/blocking.py): many gates per HBM pass through
         # LDS tiles.  Same circuit and state; scheduling is host work done before the clock,
         # like fusion.  "logical" rates count the ORIGINAL gate applications.
         from hybridq_amd.blocking import blocked_stats, plan_blocked
         t_p = time.perf_counter()
-        bops = plan_blocked(gates, state.map, n)
+        tb = 13 if args.dtype == 'complex64' else 12  # 64 KiB of LDS per tile
+        bops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, complex_type=args.dtype)
         t_plan = time.perf_counter() - t_p
-        packed = [('B', op[1], core.pack_blocked(op[2])) if op[0] == 'B' else op for op in bops]
+        packed = [('B', op[1], core.pack_blocked(op[2], args.dtype)) if op[0] == 'B' else op for op in bops]
 
         def run_blocked():
             for op in packed:
@@ -356,7 +357,7 @@ def main():
         barrier()
         elb = (time.perf_counter() - t0b) / args.steps
         st = blocked_stats(bops)
-        result['blocked'] = dict(st, tile_bits=13, ms_per_step=1e3 * elb,
+        result['blocked'] = dict(st, tile_bits=tb, ms_per_step=1e3 * elb,
                                  logical_gate_apps_per_s=len(gates) / elb,
                                  logical_amplitudes_per_s=len(gates) / elb * float(1 << n),
                                  host_planning_seconds_untimed=t_plan)

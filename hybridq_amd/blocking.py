@@ -26,7 +26,8 @@ import numpy as np
 from .fusion import fuse
 
 
-def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_gates=3, tries=16, seed=0):
+def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_gates=3, tries=16, seed=0,
+                 complex_type='complex64'):
     """Schedule `gates` ([(U, qubits), ...]) given the placement ``pos_of[qubit] = position``.
 
     Returns a list of ops:
@@ -120,7 +121,7 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_ga
                 S.add(p)
             p += 1
         if inner_max:
-            inner = fuse([gates[gi] for gi in chosen], inner_max, complex_type='complex64')
+            inner = fuse([gates[gi] for gi in chosen], inner_max, complex_type=complex_type)
         else:
             inner = [(np.asarray(gates[gi][0]), gq[gi]) for gi in chosen]
         ops.append(('B', np.asarray(sorted(S), dtype=np.uint32),

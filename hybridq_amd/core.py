@@ -122,9 +122,13 @@ _vdot = {
                                             ctypes.POINTER(ctypes.c_double)) for b in (32, 64)
 }
 
-_apply_blocked = _define_function(_lib, 'hq_apply_blocked_float32', ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                  ctypes.c_uint, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint, ctypes.c_uint,
-                                  ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
+_apply_blocked = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_apply_blocked_float{b}', ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p,
+                                            ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
+    for b in (32, 64)
+}
 
 #: symbols the C header include/hq_hip.h declares (checked by tests/test_abi.py)
 EXPORTED = [
@@ -135,7 +139,7 @@ EXPORTED = [
     'hq_init_state_float32', 'hq_init_state_float64', 'hq_norm2_float32', 'hq_norm2_float64',
     'hq_permute_bits_32', 'hq_permute_bits_64',
     'hq_probabilities_float32', 'hq_probabilities_float64', 'hq_project_float32', 'hq_project_float64',
-    'hq_vdot_float32', 'hq_vdot_float64', 'hq_apply_blocked_float32',
+    'hq_vdot_float32', 'hq_vdot_float64', 'hq_apply_blocked_float32', 'hq_apply_blocked_float64',
 ]
 
 
@@ -303,9 +307,9 @@ def vdot(a_re, a_im, b_re, b_im):
     return complex(out[0], out[1])
 
 
-def pack_blocked(gates):
-    """[(U, pos), ...] -> (U_all, pos_all, k_all) arrays for apply_blocked (complex64)."""
-    U_all = np.concatenate([np.ascontiguousarray(U, dtype=np.complex64).reshape(-1) for U, _ in gates])
+def pack_blocked(gates, complex_type='complex64'):
+    """[(U, pos), ...] -> (U_all, pos_all, k_all) arrays for apply_blocked."""
+    U_all = np.concatenate([np.ascontiguousarray(U, dtype=complex_type).reshape(-1) for U, _ in gates])
     pos_all = np.concatenate([np.asarray(p, dtype=np.uint32).reshape(-1) for _, p in gates])
     k_all = np.asarray([len(p) for _, p in gates], dtype=np.uint32)
     return np.ascontiguousarray(U_all), np.ascontiguousarray(pos_all), k_all
@@ -313,11 +317,15 @@ def pack_blocked(gates):
 
 def apply_blocked(psi_re, psi_im, tile_pos, gates=None, n_qubits=None, packed=None):
     """Apply a list of k <= 4 gates whose targets all lie in `tile_pos` in ONE pass over the
-    state (complex64, device tensors).  `gates`: [(U, pos)] with GLOBAL positions, pos[0] = LSB."""
+    state (device tensors).  `gates`: [(U, pos)] with GLOBAL positions, pos[0] = LSB."""
+    ft = _float_dtype(psi_re)
+    ctype = np.dtype('complex64') if ft == np.dtype('float32') else np.dtype('complex128')
     tile_pos = np.ascontiguousarray(tile_pos, dtype=np.uint32)
-    U_all, pos_all, k_all = packed if packed is not None else pack_blocked(gates)
+    U_all, pos_all, k_all = packed if packed is not None else pack_blocked(gates, ctype)
+    if U_all.dtype != ctype:
+        raise ValueError('packed matrices do not match the precision of the planes')
     n = _n_qubits(psi_re) if n_qubits is None else int(n_qubits)
     U32P = ctypes.POINTER(ctypes.c_uint32)
-    rc = _apply_blocked(_ptr(psi_re), _ptr(psi_im), n, tile_pos.ctypes.data_as(U32P), len(tile_pos), len(k_all),
-                        U_all.ctypes.data, pos_all.ctypes.data_as(U32P), k_all.ctypes.data_as(U32P))
+    rc = _apply_blocked[ft](_ptr(psi_re), _ptr(psi_im), n, tile_pos.ctypes.data_as(U32P), len(tile_pos),
+                            len(k_all), U_all.ctypes.data, pos_all.ctypes.data_as(U32P), k_all.ctypes.data_as(U32P))
     _check(rc, 'apply_blocked')

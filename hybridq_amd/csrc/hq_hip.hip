@@ -856,15 +856,18 @@ static int norm2_entry(const T* re, const T* im, uint64_t size, double* out) {
 // ---------------------------------------------------------------------------------
 // apply_blocked: a list of gates inside one LDS tile, one HBM pass (device pointers, f32)
 // ---------------------------------------------------------------------------------
-static int apply_blocked_entry(float* re, float* im, unsigned n, const unsigned* tile_pos, unsigned tb,
-                               unsigned n_gates, const float* U_all, const unsigned* pos_all,
+template <typename T>
+static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_pos, unsigned tb,
+                               unsigned n_gates, const T* U_all, const unsigned* pos_all,
                                const unsigned* k_all) {
+  constexpr unsigned CB = Vec<T>::VB;
+  const unsigned max_tb = sizeof(T) == 4 ? kBlockedMaxTileBits : kBlockedMaxTileBits - 1;  // 128 KiB of LDS
   Context& c = ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   read_env(c);
   if (!re || !im || !tile_pos || (n_gates && (!U_all || !pos_all || !k_all))) return fail("apply_blocked: null pointer");
   if (n_gates == 0) return 0;
-  if (n > 62 || tb > (unsigned)kBlockedMaxTileBits || tb < 10 || tb > n) return fail("apply_blocked: tile size out of range");
+  if (n > 62 || tb > max_tb || tb < 10 || tb > n) return fail("apply_blocked: tile size out of range");
   if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("apply_blocked: device pointers only");
   if ((reinterpret_cast<uintptr_t>(re) % 32) || (reinterpret_cast<uintptr_t>(im) % 32))
     return fail("apply_blocked: planes must be 32-byte aligned");
@@ -878,10 +881,11 @@ static int apply_blocked_entry(float* re, float* im, unsigned n, const unsigned*
     ba.apos[i] = tile_pos[i];
     local_of[tile_pos[i]] = (int)i;
   }
-  if (tile_pos[0] != 0 || tile_pos[1] != 1) return fail("apply_blocked: the tile must contain index bits 0 and 1");
+  for (unsigned b = 0; b < CB; ++b)
+    if (tile_pos[b] != b) return fail("apply_blocked: the tile must contain the vector-component index bits (0,1 for f32; 0 for f64)");
   std::vector<BlockedGate> gates(n_gates);
-  std::vector<float> Atab;
-  const float* Up = U_all;
+  std::vector<T> Atab;
+  const T* Up = U_all;
   const unsigned* pp = pos_all;
   for (unsigned g = 0; g < n_gates; ++g) {
     const unsigned k = k_all[g];
@@ -892,8 +896,8 @@ static int apply_blocked_entry(float* re, float* im, unsigned n, const unsigned*
       lp[j] = (unsigned)local_of[pp[j]];
     }
     if (check_positions(lp, tb, k)) return fail("apply_blocked: duplicate targets");
-    MfmaPlan<float> P;
-    if (!plan_mfma<float>(c, Up, lp, tb, k, P, true)) return fail("apply_blocked: cannot plan an inner gate");
+    MfmaPlan<T> P;
+    if (!plan_mfma<T>(c, Up, lp, tb, k, P, true)) return fail("apply_blocked: cannot plan an inner gate");
     BlockedGate& G = gates[g];
     memset(&G, 0, sizeof(G));
     G.ro = P.ro;
@@ -908,29 +912,35 @@ static int apply_blocked_entry(float* re, float* im, unsigned n, const unsigned*
   }
   void *dG = nullptr, *dA = nullptr;
   if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
-  if (arena_upload(c, Atab.data(), Atab.size() * sizeof(float), &dA)) return 1;
-  const size_t lds = ((size_t)2 << tb) * sizeof(float);
+  if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
+  const size_t lds = ((size_t)2 << tb) * sizeof(T);
   static bool attr_done = false;
   if (!attr_done) {
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_f32_kernel<256>,
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<float, 256>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_f32_kernel<512>,
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<float, 512>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<double, 256>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<double, 512>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   const uint64_t ntiles = 1ull << (n - tb);
-  const unsigned per_cu = tb <= 12 ? 4 : (tb == 13 ? 2 : 1);
-  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
+  const size_t per_cu = std::max<size_t>(1, (160 * 1024) / lds);
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * std::min<size_t>(per_cu, 4));
   static int block_threads = getenv("HQ_BLOCKED_THREADS") ? atoi(getenv("HQ_BLOCKED_THREADS")) : 512;
   if (block_threads == 256)
-    hipLaunchKernelGGL(apply_blocked_f32_kernel<256>, dim3(grid), dim3(256), lds, c.stream, re, im,
-                       (const BlockedGate*)dG, n_gates, (const float*)dA, ba, ntiles);
+    hipLaunchKernelGGL((apply_blocked_kernel<T, 256>), dim3(grid), dim3(256), lds, c.stream, re, im,
+                       (const BlockedGate*)dG, n_gates, (const T*)dA, ba, ntiles);
   else
-    hipLaunchKernelGGL(apply_blocked_f32_kernel<512>, dim3(grid), dim3(512), lds, c.stream, re, im,
-                       (const BlockedGate*)dG, n_gates, (const float*)dA, ba, ntiles);
+    hipLaunchKernelGGL((apply_blocked_kernel<T, 512>), dim3(grid), dim3(512), lds, c.stream, re, im,
+                       (const BlockedGate*)dG, n_gates, (const T*)dA, ba, ntiles);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "blocked";
-  c.last_desc = "apply_blocked_f32_kernel tb=" + std::to_string(tb) + " gates=" + std::to_string(n_gates);
+  c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(block_threads == 256 ? 256 : 512) + "> tb=" + std::to_string(tb) + " gates=" +
+                std::to_string(n_gates);
   return 0;
 }
 
@@ -1094,7 +1104,12 @@ int hq_vdot_float64(const double* are, const double* aim, const double* bre, con
 int hq_apply_blocked_float32(float* re, float* im, unsigned int n, const unsigned int* tile_pos,
                              unsigned int tile_bits, unsigned int n_gates, const float* U_all,
                              const unsigned int* pos_all, const unsigned int* k_all) {
-  return hq::apply_blocked_entry(re, im, n, tile_pos, tile_bits, n_gates, U_all, pos_all, k_all);
+  return hq::apply_blocked_entry<float>(re, im, n, tile_pos, tile_bits, n_gates, U_all, pos_all, k_all);
+}
+int hq_apply_blocked_float64(double* re, double* im, unsigned int n, const unsigned int* tile_pos,
+                             unsigned int tile_bits, unsigned int n_gates, const double* U_all,
+                             const unsigned int* pos_all, const unsigned int* k_all) {
+  return hq::apply_blocked_entry<double>(re, im, n, tile_pos, tile_bits, n_gates, U_all, pos_all, k_all);
 }
 
 int hq_set_stream(void* hip_stream) {

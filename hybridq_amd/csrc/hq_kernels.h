@@ -286,11 +286,11 @@ apply_mfma_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------
-// apply_blocked (f32): MANY gates in ONE HBM pass.
+// apply_blocked (f32 and f64): MANY gates in ONE HBM pass.
 //
 // The per-gate kernels above sit at the memory system's ceiling (~3 ms per pass at n = 30),
 // so the remaining lever is fewer passes.  A workgroup stages a tile of 2^TB amplitudes
-// (TB = 13: 2 x 32 KiB of LDS, two workgroups per CU) spanned by TB chosen index bits --
+// (TB = 13 for f32, 12 for f64: 2 x 32 KiB of LDS, two workgroups per CU) spanned by TB chosen index bits --
 // the low bits (coalescing) plus any others -- applies a whole LIST of gates whose targets
 // all lie inside those bits with the same role-assigned MFMA scheme as apply_mfma, now
 // reading/writing LDS (ds_read_b128 / ds_write_b128, one workgroup barrier per gate), and
@@ -307,27 +307,30 @@ constexpr int kBlockedMaxTileBits = 14;
 __device__ __forceinline__ unsigned blocked_swz(unsigned v) { return v ^ ((v >> 4) & 15u); }
 struct BlockedArg {
   unsigned tb;                          // tile bits
-  unsigned apos[kBlockedMaxTileBits];   // their global index positions, ascending (apos[0..1] = 0,1)
+  unsigned apos[kBlockedMaxTileBits];   // their global index positions, ascending (component bits first: 0,1 / 0)
 };
 struct BlockedGate {
-  MfmaRoles ro;      // roles in TILE-LOCAL coordinates (vec position = local bit - 2; unused = 31)
+  MfmaRoles ro;      // roles in TILE-LOCAL coordinates (vec position = local bit - #component bits; unused = 31)
   unsigned a_off;    // offset (elements) of this gate's A table
   unsigned kv;       // kbits * 4 + vmask
   unsigned n_addr;   // number of address digits
   unsigned pad_;
 };
 
-template <int KBITS, int VMASK, int BLOCK>
-__device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float* __restrict__ xi,
-                                                   const BlockedGate& G, const float* __restrict__ A,
+template <typename T, int KBITS, int VMASK, int BLOCK>
+__device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __restrict__ xi,
+                                                   const BlockedGate& G, const T* __restrict__ A,
                                                    const unsigned tile_vec_bits) {
+  using V = typename Vec<T>::type;
+  using Acc = typename Mfma<T>::acc;
+  constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
-  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (2 - KV), NSTEP = 1 << NS;
-  constexpr int FMASK = ~VMASK & 3;
+  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS;
+  constexpr int FMASK = ~VMASK & (NCOMP - 1);
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned q = lane >> 4, j = lane & 15;
   const MfmaRoles& ro = G.ro;
-  float a[NRB][NSTEP];
+  T a[NRB][NSTEP];
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -353,18 +356,18 @@ __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float
       v = ((v & ~lo) << 1) | (v & lo);
     }
     v |= lane_off;
-    f32x4* ptr[NL];
-    f32x4 x[NL];
+    V* ptr[NL];
+    V x[NL];
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
-      ptr[ld] = reinterpret_cast<f32x4*>((lane_plane | pl[ld]) ? xi : xr) + blocked_swz(v | off[ld]);
+      ptr[ld] = reinterpret_cast<V*>((lane_plane | pl[ld]) ? xi : xr) + blocked_swz(v | off[ld]);
       x[ld] = *ptr[ld];
     }
-    f32x4 acc[NCB][NRB];
+    Acc acc[NCB][NRB];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf)
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Acc{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       const int ck = s & ((1 << KV) - 1), ld = s >> KV;
@@ -376,15 +379,15 @@ __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float
 #ifdef HQ_EXP_NO_MFMA  // experiment: LDS traffic only
           acc[cf][rb] += x[ld][comp] * a[rb][s];
 #else
-          acc[cf][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][s], x[ld][comp], acc[cf][rb], 0, 0, 0);
+          acc[cf][rb] = Mfma<T>::run(a[rb][s], x[ld][comp], acc[cf][rb]);
 #endif
       }
     }
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
-      f32x4 y;
+      V y;
 #pragma unroll
-      for (int comp = 0; comp < 4; ++comp) {
+      for (int comp = 0; comp < NCOMP; ++comp) {
         const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
         const int so = ck | (ld << KV);
         y[comp] = acc[cf][so >> 2][so & 3];
@@ -398,52 +401,60 @@ __device__ __forceinline__ void blocked_inner_gate(float* __restrict__ xr, float
   }
 }
 
-template <int BLOCK>
+template <typename T, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-apply_blocked_f32_kernel(float* __restrict__ re, float* __restrict__ im,
-                         const BlockedGate* __restrict__ gates, const unsigned ngates,
-                         const float* __restrict__ Atab, const BlockedArg ba, const uint64_t ntiles) {
+apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* __restrict__ gates,
+                     const unsigned ngates, const T* __restrict__ Atab, const BlockedArg ba,
+                     const uint64_t ntiles) {
+  using V = typename Vec<T>::type;
+  constexpr unsigned CB = Vec<T>::VB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* xr = reinterpret_cast<float*>(smem);
-  float* xi = xr + (1u << ba.tb);
+  T* xr = reinterpret_cast<T*>(smem);
+  T* xi = xr + (1u << ba.tb);
   const unsigned tid = threadIdx.x;
-  const unsigned tvb = ba.tb - 2, nvec = 1u << tvb;
-  f32x4* __restrict__ vre = reinterpret_cast<f32x4*>(re);
-  f32x4* __restrict__ vim = reinterpret_cast<f32x4*>(im);
+  const unsigned tvb = ba.tb - CB, nvec = 1u << tvb;
+  V* __restrict__ vre = reinterpret_cast<V*>(re);
+  V* __restrict__ vim = reinterpret_cast<V*>(im);
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    uint64_t base = tile;  // in 16-byte vector units: tile positions minus the two component bits
-    for (unsigned m = 2; m < ba.tb; ++m) {
-      const uint64_t lo = (1ull << (ba.apos[m] - 2)) - 1;
+    uint64_t base = tile;  // in 16-byte vector units: tile positions minus the component bits
+    for (unsigned m = CB; m < ba.tb; ++m) {
+      const uint64_t lo = (1ull << (ba.apos[m] - CB)) - 1;
       base = ((base & ~lo) << 1) | (base & lo);
     }
     for (unsigned e = tid; e < nvec; e += BLOCK) {
       uint64_t g = base;
-      for (unsigned m = 2; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - 2)) & 1u) << (ba.apos[m] - 2);
-      reinterpret_cast<f32x4*>(xr)[blocked_swz(e)] = vre[g];
-      reinterpret_cast<f32x4*>(xi)[blocked_swz(e)] = vim[g];
+      for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+      reinterpret_cast<V*>(xr)[blocked_swz(e)] = vre[g];
+      reinterpret_cast<V*>(xi)[blocked_swz(e)] = vim[g];
     }
     __syncthreads();
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedGate& G = gates[gi];
-      const float* A = Atab + G.a_off;
+      const T* A = Atab + G.a_off;
       switch (G.kv) {
-        case 16: blocked_inner_gate<4, 0, BLOCK>(xr, xi, G, A, tvb); break;
-        case 17: blocked_inner_gate<4, 1, BLOCK>(xr, xi, G, A, tvb); break;
-        case 18: blocked_inner_gate<4, 2, BLOCK>(xr, xi, G, A, tvb); break;
-        case 19: blocked_inner_gate<4, 3, BLOCK>(xr, xi, G, A, tvb); break;
-        case 20: blocked_inner_gate<5, 0, BLOCK>(xr, xi, G, A, tvb); break;
-        case 21: blocked_inner_gate<5, 1, BLOCK>(xr, xi, G, A, tvb); break;
-        case 22: blocked_inner_gate<5, 2, BLOCK>(xr, xi, G, A, tvb); break;
-        case 23: blocked_inner_gate<5, 3, BLOCK>(xr, xi, G, A, tvb); break;
-        default: break;
+        case 16: blocked_inner_gate<T, 4, 0, BLOCK>(xr, xi, G, A, tvb); break;
+        case 17: blocked_inner_gate<T, 4, 1, BLOCK>(xr, xi, G, A, tvb); break;
+        case 20: blocked_inner_gate<T, 5, 0, BLOCK>(xr, xi, G, A, tvb); break;
+        case 21: blocked_inner_gate<T, 5, 1, BLOCK>(xr, xi, G, A, tvb); break;
+        default:
+          if constexpr (CB == 2) {
+            switch (G.kv) {
+              case 18: blocked_inner_gate<T, 4, 2, BLOCK>(xr, xi, G, A, tvb); break;
+              case 19: blocked_inner_gate<T, 4, 3, BLOCK>(xr, xi, G, A, tvb); break;
+              case 22: blocked_inner_gate<T, 5, 2, BLOCK>(xr, xi, G, A, tvb); break;
+              case 23: blocked_inner_gate<T, 5, 3, BLOCK>(xr, xi, G, A, tvb); break;
+              default: break;
+            }
+          }
+          break;
       }
       __syncthreads();
     }
     for (unsigned e = tid; e < nvec; e += BLOCK) {
       uint64_t g = base;
-      for (unsigned m = 2; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - 2)) & 1u) << (ba.apos[m] - 2);
-      vre[g] = reinterpret_cast<f32x4*>(xr)[blocked_swz(e)];
-      vim[g] = reinterpret_cast<f32x4*>(xi)[blocked_swz(e)];
+      for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+      vre[g] = reinterpret_cast<V*>(xr)[blocked_swz(e)];
+      vim[g] = reinterpret_cast<V*>(xi)[blocked_swz(e)];
     }
     __syncthreads();
   }

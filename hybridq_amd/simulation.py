@@ -202,7 +202,7 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     0 applies the gates as given; a dict may carry ``max_n_qubits`` plus the keyword
     arguments of ``fusion.fuse``), ``device``, ``blocked`` (default False; True or a dict of
     ``blocking.plan_blocked`` options: apply many gates per HBM pass through LDS tiles,
-    complex64 only, n >= 14 -- see hybridq_amd/blocking.py).  ``simplify`` (the reference's commuting-gate
+    n >= 14 -- see hybridq_amd/blocking.py).  ``simplify`` (the reference's commuting-gate
     reordering / inverse cancellation, circuit/utils.py:825) is a host-side IR transform
     upstream of this path and is not reproduced: gates are fused in the order given.
     """
@@ -232,7 +232,7 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     gates, run = [], []
 
     blocked = kwargs.get('blocked', False)
-    use_blocked = bool(blocked) and ctype == np.dtype('complex64') and n >= 14
+    use_blocked = bool(blocked) and n >= 14
     pos_of = {q: n - x - 1 for x, q in enumerate(qubits)}  # simulation.py:512 (never permuted here)
 
     def flush():
@@ -241,7 +241,10 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
         if use_blocked:
             # many gates per HBM pass (hybridq_amd.blocking); inner fusion replaces `compress`
             from .blocking import plan_blocked
-            opts = blocked if isinstance(blocked, dict) else {}
+            opts = dict(blocked) if isinstance(blocked, dict) else {}
+            opts.setdefault('tile_bits', 13 if ctype == np.dtype('complex64') else 12)  # 64 KiB of LDS
+            opts.setdefault('low_bits', 5 if ctype == np.dtype('complex64') else 4)
+            opts.setdefault('complex_type', ctype)
             gates.extend(plan_blocked([(U, qs) for qs, U in run], pos_of, n, **opts))
         elif comp_n:
             from .fusion import fuse

@@ -148,16 +148,20 @@ int hq_vdot_float32(const float *a_re, const float *a_im, const float *b_re, con
 int hq_vdot_float64(const double *a_re, const double *a_im, const double *b_re, const double *b_im,
                     uint64_t size, double *out);
 
-/* Many gates in ONE HBM pass (complex64, device pointers): the state is processed in tiles of
- * 2^tile_bits amplitudes spanned by the index bits tile_pos[0..tile_bits) (ascending, must
- * start with 0, 1; 10 <= tile_bits <= 14; 13 = 64 KiB of LDS).  Each tile is staged in LDS,
- * the n_gates gates are applied to it in order, and it is written back.  Gate g has k_all[g]
- * (1..4) targets; its positions (GLOBAL index bits, all members of tile_pos, pos[0] = LSB of
- * the matrix index as in apply_U) and its row-major interleaved matrix are the next entries
- * of pos_all / U_all.  Result identical to calling apply_U_float32 gate by gate. */
+/* Many gates in ONE HBM pass (device pointers): the state is processed in tiles of
+ * 2^tile_bits amplitudes spanned by the index bits tile_pos[0..tile_bits) (ascending; must
+ * start with the vector-component bits: 0,1 for float32, 0 for float64; 10 <= tile_bits <= 14
+ * (float32) / 13 (float64); 64 KiB of LDS = 13 / 12).  Each tile is staged in LDS, the n_gates
+ * gates are applied to it in order, and it is written back.  Gate g has k_all[g] (1..4)
+ * targets; its positions (GLOBAL index bits, all members of tile_pos, pos[0] = LSB of the
+ * matrix index as in apply_U) and its row-major interleaved matrix are the next entries of
+ * pos_all / U_all.  Result identical to calling apply_U_* gate by gate. */
 int hq_apply_blocked_float32(float *psi_re, float *psi_im, unsigned int n_qubits,
                              const unsigned int *tile_pos, unsigned int tile_bits, unsigned int n_gates,
                              const float *U_all, const unsigned int *pos_all, const unsigned int *k_all);
+int hq_apply_blocked_float64(double *psi_re, double *psi_im, unsigned int n_qubits,
+                             const unsigned int *tile_pos, unsigned int tile_bits, unsigned int n_gates,
+                             const double *U_all, const unsigned int *pos_all, const unsigned int *k_all);
 
 #ifdef __cplusplus
 }
