@@ -216,6 +216,10 @@ class HipBackend:
     def apply(self, planes, U, pos, m):
         self.core.apply_U(planes[0], planes[1], U, pos, m)
 
+    def apply_blocked(self, planes, tile_pos, gates, m):
+        """gates: [(U, local positions)] all inside tile_pos: one LDS-tile pass (blocking.py)."""
+        self.core.apply_blocked(planes[0], planes[1], tile_pos, gates, m)
+
     def permute(self, src, dst, perm, m):
         self.core.permute_bits(src[0], dst[0], perm, m)
         self.core.permute_bits(src[1], dst[1], perm, m)
@@ -291,11 +295,13 @@ class ShardedEvolution:
             raise ValueError("sharded initial states: '0'/'1' strings or all '+'")
 
     # -- planning ----------------------------------------------------------------
-    def plan(self, gates, compress=0):
+    def plan(self, gates, compress=0, blocked=False):
         """Schedule `gates` ([(U, qubits), ...]) from the CURRENT qubit placement.  Returns
         the op list for run(); the matrices are cast once here.  ``compress`` > 0 first fuses
         the circuit into <= compress-qubit gates (hybridq_amd.fusion, the reference's default
-        is 4): fewer local passes, same exchanges."""
+        is 4): fewer local passes, same exchanges.  ``blocked`` (True or a dict of
+        ``blocking.plan_blocked`` options) re-schedules every run of local gates between two
+        exchanges as cache-blocked passes (many gates per HBM pass, 'B' ops)."""
         if compress:
             from .fusion import fuse
             gates = fuse(gates, compress, complex_type=self.complex_type)
@@ -312,15 +318,47 @@ class ShardedEvolution:
             else:
                 sched.append(op)
         self._planned_final_pos = final_pos
+        if blocked and self.m >= 14:
+            from .blocking import plan_blocked
+            opts = dict(blocked) if isinstance(blocked, dict) else {}
+            c64 = self.complex_type == np.dtype('complex64')
+            opts.setdefault('tile_bits', 13 if c64 else 12)
+            opts.setdefault('low_bits', 5 if c64 else 4)
+            opts.setdefault('complex_type', self.complex_type)
+            out, run = [], []
+
+            def flush():
+                if run:
+                    ident = {p: p for p in range(self.m)}  # "qubits" of the sub-plan are local positions
+                    for op in plan_blocked([(U, tuple(int(p) for p in reversed(pos))) for U, pos in run], ident,
+                                           self.m, **opts):
+                        if op[0] == 'B':
+                            out.append(('B', op[1], [(np.ascontiguousarray(U, dtype=self.complex_type),
+                                                      np.asarray(p, dtype=np.uint32)) for U, p in op[2]]))
+                        else:
+                            out.append(('G', np.ascontiguousarray(op[1], dtype=self.complex_type),
+                                        np.asarray(op[2], dtype=np.uint32)))
+                    run.clear()
+
+            for op in sched:
+                if op[0] == 'G':
+                    run.append((op[1], op[2]))
+                else:
+                    flush()
+                    out.append(op)
+            flush()
+            sched = out
         return sched
 
     def run(self, schedule, update_map=True):
         be = self.backend
         for op in schedule:
-            if op[0] != 'G' and self.bufs[1 - self.cur] is None:
+            if op[0] in ('P', 'X') and self.bufs[1 - self.cur] is None:
                 self.bufs[1 - self.cur] = be.empty_planes(self.m)
             if op[0] == 'G':
                 be.apply(self.bufs[self.cur], op[1], op[2], self.m)
+            elif op[0] == 'B':
+                be.apply_blocked(self.bufs[self.cur], op[1], op[2], self.m)
             elif op[0] == 'P':
                 be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m)
                 self.cur = 1 - self.cur
@@ -330,8 +368,8 @@ class ShardedEvolution:
         if update_map:
             self.pos = dict(self._planned_final_pos)
 
-    def simulate(self, gates, compress=0):
-        self.run(self.plan(gates, compress=compress))
+    def simulate(self, gates, compress=0, blocked=False):
+        self.run(self.plan(gates, compress=compress, blocked=blocked))
         return self
 
     def restore_order(self):

@@ -45,6 +45,12 @@ class CpuBackend:
     def apply(self, planes, U, pos, m):
         assert self.lib.apply_U(planes[0].numpy(), planes[1].numpy(), U, pos, m) == 0
 
+    def apply_blocked(self, planes, tile_pos, gates, m):
+        tile = set(int(p) for p in tile_pos)
+        for U, pos in gates:  # same result as one LDS-tile pass: the gates one by one
+            assert set(int(p) for p in pos) <= tile
+            self.apply(planes, U, pos, m)
+
     def permute(self, src, dst, perm, m):
         x = np.arange(1 << m, dtype=np.int64)
         y = np.zeros_like(x)
@@ -110,14 +116,23 @@ def _worker(rank, world, port, n, seed, ct, out_dir):
         dist.all_gather(parts, loc)
         raw = np.concatenate([p[0].numpy() + 1j * p[1].numpy() for p in parts])
         nrm = sh.norm2()
+        nb = -1
+        psi4 = psi
+        if sh.m >= 14:  # cache-blocked local passes between the exchanges (blocking.py)
+            sh4 = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, backend=CpuBackend(ft))
+            sched4 = sh4.plan(gates, blocked=True)
+            nb = sum(1 for op in sched4 if op[0] == 'B')
+            sh4.run(sched4)
+            psi4 = sh4.state_numpy()
         if rank == 0:
             np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psi2=psi2, n_x=n_x, n_p=n_p, nrm=nrm, raw=raw,
-                     moved=moved)
+                     moved=moved, psi4=psi4, nb=nb)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n,ct', [(2, 10, 'complex128'), (4, 11, 'complex128'), (2, 12, 'complex64')])
+@pytest.mark.parametrize('world,n,ct', [(2, 10, 'complex128'), (4, 11, 'complex128'), (2, 12, 'complex64'),
+                                        (2, 15, 'complex64')])
 def test_sharded_matches_single_process(tmp_path, world, n, ct):
     import torch.multiprocessing as mp
     import oracle
@@ -132,6 +147,8 @@ def test_sharded_matches_single_process(tmp_path, world, n, ct):
     assert int(out['n_x']) >= 1  # the circuit really needed exchanges
     assert abs(float(out['nrm']) - float(np.vdot(exp, exp).real)) < 1e-5 * float(np.vdot(exp, exp).real)
     assert np.abs(out['raw'] - exp).max() / np.abs(exp).max() < tol  # fused + restore_order
+    assert np.abs(out['psi4'] - exp).max() / np.abs(exp).max() < tol  # blocked local passes
+    assert (int(out['nb']) >= 1) == (n - int(np.log2(world)) >= 14)
     g2 = random_dense(n, 25, kmax=3, seed=seed + 2)
     exp2 = oracle.evolve_tensordot(g2, n, initial_state=np.full(1 << n, 2.0**(-n / 2)))
     assert np.abs(out['psi2'] - exp2).max() / np.abs(exp2).max() < tol

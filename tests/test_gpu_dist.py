@@ -49,8 +49,15 @@ def _worker(rank, world, port, n, ct, out_dir):
         sched = sh.plan(gates)
         sh.run(sched)
         psi = sh.state_numpy()
+        # same circuit, cache-blocked local passes between the exchanges, then canonical order
+        shb = ShardedEvolution(n + 2, complex_type=ct, initial_state='0' * (n + 2), backend=HostStagedExchange(ft))
+        gb = rqc_1q2q(n + 2, depth=8, seed=13)
+        schedb = shb.plan(gb, blocked=True)
+        shb.run(schedb)
+        psib = shb.state_numpy()
+        nb = sum(1 for op in schedb if op[0] == 'B')
         if rank == 0:
-            np.savez(os.path.join(out_dir, 'out.npz'), psi=psi,
+            np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psib=psib, nb=nb,
                      n_x=sum(1 for op in sched if op[0] == 'X'), n_p=sum(1 for op in sched if op[0] == 'P'))
     finally:
         dist.destroy_process_group()
@@ -68,3 +75,6 @@ def test_sharded_hip_backend_two_ranks_one_gpu(torch_cuda, tmp_path, world, n, c
     tol = 1e-6 if ct == 'complex64' else 1e-12
     assert np.abs(out['psi'] - exp).max() / np.abs(exp).max() < tol
     assert int(out['n_x']) >= 1
+    expb = oracle.evolve_tensordot(rqc_1q2q(n + 2, depth=8, seed=13), n + 2)
+    assert np.abs(out['psib'] - expb).max() / np.abs(expb).max() < 5 * tol
+    assert int(out['nb']) >= 1  # blocked passes were really used
