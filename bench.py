@@ -175,6 +175,7 @@ def main():
         for _ in range(max(1, args.warmup) + args.steps):
             schedules.append(sharded.plan(gates))
             sharded.pos = dict(sharded._planned_final_pos)
+        pos_after_main = dict(sharded.pos)
         sharded.pos = pos0
         n_exchanges = sum(1 for op in schedules[-1] if op[0] == 'X')
         n_permutes = sum(1 for op in schedules[-1] if op[0] == 'P')
@@ -259,6 +260,32 @@ def main():
         tp = (time.perf_counter() - t0p) / (2 * reps)
         shard_bytes = 2 * (1 << n_local) * ft.itemsize
         chunk_bytes = shard_bytes // max(world, 1)
+        # cache-blocked local passes between the exchanges (same circuit; reported separately)
+        if n_local >= 14 and not args.no_fused:
+            sharded.pos = dict(pos_after_main)
+            bsched = []
+            for _ in range(1 + args.steps):
+                bsched.append(sharded.plan(gates, blocked=True))
+                sharded.pos = dict(sharded._planned_final_pos)
+            sharded.run(bsched[0], update_map=False)
+            barrier()
+            t0b = time.perf_counter()
+            for sc in bsched[1:]:
+                sharded.run(sc, update_map=False)
+            barrier()
+            elb = (time.perf_counter() - t0b) / args.steps
+            if world > 1:
+                tb_ = torch.tensor([elb], dtype=torch.float64, device='cuda')
+                dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
+                elb = float(tb_.item())
+            result['blocked'] = {
+                'ms_per_step': 1e3 * elb,
+                'logical_gate_apps_per_s': len(gates) / elb,
+                'logical_amplitudes_per_s': len(gates) / elb * float(1 << n),
+                'blocked_passes_per_step': sum(1 for op in bsched[-1] if op[0] == 'B'),
+                'plain_gates_per_step': sum(1 for op in bsched[-1] if op[0] == 'G'),
+                'exchanges_per_step': sum(1 for op in bsched[-1] if op[0] == 'X'),
+            }
         result['exchange'] = {
             'ms_per_exchange': 1e3 * tx,
             'bytes_sent_per_gpu': shard_bytes - chunk_bytes,
