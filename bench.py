@@ -112,6 +112,44 @@ def cpu_baseline(gates, n, seconds, complex_type):
     }
 
 
+def parity_check(complex_type, depth, n=24):
+    """Full circuit (same generator, n=24, every gate) on the reference CPU core through the
+    reference driver protocol and on the GPU through hybridq_amd.simulate: norm-relative
+    max difference of ALL final amplitudes, for the plain, fused and blocked GPU paths."""
+    import oracle
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    try:
+        lib = oracle.load_ref()
+    except Exception:
+        lib = oracle.load_port()
+    gates = rqc_1q2q(n, depth=depth, seed=n)
+    t0 = time.perf_counter()
+    ref, _ = oracle.evolve_reference_protocol(lib, gates, n, complex_type=complex_type)
+    t_cpu = time.perf_counter() - t0
+    scale = float(np.abs(ref).max())
+    out = {'n_qubits': n, 'gate_applications': len(gates), 'cpu_kind': lib.kind, 'cpu_seconds': t_cpu,
+           'tolerance': 1e-6 if complex_type == 'complex64' else 1e-12, 'norm': 'max|d| / max|psi|'}
+    for name, kw in (('per_gate', dict(compress=0)), ('fused_k4', dict(compress=4)), ('blocked', dict(blocked=True))):
+        psi = simulate(gates, initial_state='0' * n, complex_type=complex_type, qubits=list(range(n)), **kw).reshape(-1)
+        out['max_rel_diff_' + name] = float(np.abs(psi - ref).max() / scale)
+        if name == 'per_gate':
+            gpu = psi
+    if complex_type == 'complex64':
+        # Two float32 evolutions of hundreds of gates differ by accumulated rounding whatever the
+        # implementation (the reference is built with -ffast-math).  Measure BOTH against a
+        # complex128 evolution of the same circuit to see who carries the error.
+        truth = simulate(gates, initial_state='0' * n, complex_type='complex128', qubits=list(range(n)),
+                         compress=0).reshape(-1)
+        out['reference_cpu_f32_vs_f64'] = float(np.abs(ref - truth).max() / scale)
+        out['gpu_f32_vs_f64'] = float(np.abs(gpu - truth).max() / scale)
+        short = gates[:len(gates) // 8]
+        r2, _ = oracle.evolve_reference_protocol(lib, short, n, complex_type=complex_type)
+        g2 = simulate(short, initial_state='0' * n, complex_type=complex_type, qubits=list(range(n)), compress=0).reshape(-1)
+        out['max_rel_diff_first_%d_gates' % len(short)] = float(np.abs(g2 - r2).max() / float(np.abs(r2).max()))
+    return out
+
+
 def main():
     args = parse_args()
     import torch
@@ -395,6 +433,13 @@ def main():
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
             result['cpu_baseline'] = {'value': None, 'unit': 'amplitudes/s', 'cores': 0, 'kind': 'port',
                                       'sample': f'failed: {e!r}'}
+    if rank == 0 and not sharded_path and not args.no_cpu_baseline:
+        # max relative difference of the final amplitudes, GPU vs the reference CPU path,
+        # on the same generator at the largest n the CPU finishes in seconds.
+        try:
+            result['parity_check'] = parity_check(args.dtype, args.depth)
+        except Exception as e:
+            result['parity_check'] = {'error': repr(e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
