@@ -130,11 +130,11 @@ def parity_check(complex_type, depth, n=24):
     scale = float(np.abs(ref).max())
     out = {'n_qubits': n, 'gate_applications': len(gates), 'cpu_kind': lib.kind, 'cpu_seconds': t_cpu,
            'tolerance': 1e-6 if complex_type == 'complex64' else 1e-12, 'norm': 'max|d| / max|psi|'}
+    results = {}
     for name, kw in (('per_gate', dict(compress=0)), ('fused_k4', dict(compress=4)), ('blocked', dict(blocked=True))):
         psi = simulate(gates, initial_state='0' * n, complex_type=complex_type, qubits=list(range(n)), **kw).reshape(-1)
         out['max_rel_diff_' + name] = float(np.abs(psi - ref).max() / scale)
-        if name == 'per_gate':
-            gpu = psi
+        results[name] = psi
     if complex_type == 'complex64':
         # Two float32 evolutions of hundreds of gates differ by accumulated rounding whatever the
         # implementation (the reference is built with -ffast-math).  Measure BOTH against a
@@ -142,7 +142,8 @@ def parity_check(complex_type, depth, n=24):
         truth = simulate(gates, initial_state='0' * n, complex_type='complex128', qubits=list(range(n)),
                          compress=0).reshape(-1)
         out['reference_cpu_f32_vs_f64'] = float(np.abs(ref - truth).max() / scale)
-        out['gpu_f32_vs_f64'] = float(np.abs(gpu - truth).max() / scale)
+        for name, psi in results.items():
+            out['gpu_f32_%s_vs_f64' % name] = float(np.abs(psi - truth).max() / scale)
         short = gates[:len(gates) // 8]
         r2, _ = oracle.evolve_reference_protocol(lib, short, n, complex_type=complex_type)
         g2 = simulate(short, initial_state='0' * n, complex_type=complex_type, qubits=list(range(n)), compress=0).reshape(-1)
