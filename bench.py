@@ -428,6 +428,29 @@ def main():
                                  logical_amplitudes_per_s=len(gates) / elb * float(1 << n),
                                  host_planning_seconds_untimed=t_plan)
         result['blocked']['inner_k_histogram'] = {str(k): v for k, v in st['inner_k_histogram'].items()}
+        # the same blocked schedule WITHOUT any algebraic fusion: each of the original gates is
+        # applied on its own inside the LDS tiles (what "no fusion" looks like when gates share passes)
+        uops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, inner_max=0, complex_type=args.dtype)
+        upacked = [('B', op[1], core.pack_blocked(op[2], args.dtype)) if op[0] == 'B' else op for op in uops]
+
+        def run_unfused():
+            for op in upacked:
+                if op[0] == 'G':
+                    core.apply_U(state.planes[0], state.planes[1], op[1], op[2], n)
+                else:
+                    core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
+
+        run_unfused()
+        barrier()
+        t0u = time.perf_counter()
+        run_unfused()
+        barrier()
+        elu = time.perf_counter() - t0u
+        stu = blocked_stats(uops)
+        result['blocked_no_fusion'] = {'blocked_passes': stu['blocked_passes'], 'plain_gates': stu['plain_gates'],
+                                       'inner_gates': stu['inner_gates'], 'ms_per_step': 1e3 * elu,
+                                       'gate_apps_per_s': len(gates) / elu,
+                                       'amplitudes_per_s': len(gates) / elu * float(1 << n)}
     if rank == 0 and not sharded_path and not args.no_cpu_baseline:
         try:
             result['cpu_baseline'] = cpu_baseline(gates, n, args.cpu_seconds, args.dtype)
