@@ -662,19 +662,32 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
     identity &= pos[i] == i;
   }
   if (identity) return 0;
-  const unsigned max_lds_bits = sizeof(E) == 4 ? 13 : 12;  // 32 KiB of elements
-  if (s <= max_lds_bits) {
+  const unsigned table_bits = sizeof(E) == 4 ? 13 : 12;  // 32 KiB of elements + index table
+  const unsigned max_lds_bits = sizeof(E) == 4 ? 15 : 14;  // 128 KiB of elements, index computed inline
+  if (s <= table_bits || (s <= max_lds_bits && reinterpret_cast<uintptr_t>(a) % 16 == 0)) {
+    const bool table = s <= table_bits;
     const unsigned tile_bits = std::min<unsigned>(n, std::max<unsigned>(s, 11));
     const uint64_t ntiles = 1ull << (n - tile_bits);
-    const size_t lds = ((((size_t)1 << s) * 2 + 15) & ~(size_t)15) + ((size_t)1 << tile_bits) * sizeof(E);
+    const size_t lds = (table ? ((((size_t)1 << s) * 2 + 15) & ~(size_t)15) : 0) + ((size_t)1 << tile_bits) * sizeof(E);
     const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
     constexpr int VEC = 16 / sizeof(E);
     const bool vec = tile_bits >= 10 && reinterpret_cast<uintptr_t>(a) % 16 == 0;
-    if (vec)
-      hipLaunchKernelGGL((swap_lds_kernel<E, VEC>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
+    static bool attr_done = false;
+    if (!attr_done) {
+      HQ_HIP_CHECK(hipFuncSetAttribute((const void*)swap_lds_kernel<uint32_t, 4, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HQ_HIP_CHECK(hipFuncSetAttribute((const void*)swap_lds_kernel<uint64_t, 2, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done = true;
+    }
+    if (!table)
+      hipLaunchKernelGGL((swap_lds_kernel<E, VEC, false>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
+                         tile_bits, ntiles);
+    else if (vec)
+      hipLaunchKernelGGL((swap_lds_kernel<E, VEC, true>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
                          tile_bits, ntiles);
     else
-      hipLaunchKernelGGL((swap_lds_kernel<E, 1>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
+      hipLaunchKernelGGL((swap_lds_kernel<E, 1, true>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
                          tile_bits, ntiles);
     HQ_HIP_CHECK(hipGetLastError());
     return 0;

@@ -720,21 +720,24 @@ struct SwapArg {
 
 // One workgroup permutes 2^tile_bits contiguous elements (>= one 2^s chunk) through LDS:
 // 16-byte loads into LDS, permuted LDS reads, 16-byte stores (VEC elements per access).
-template <typename E, int VEC>
+// TABLE = false (large s: the whole LDS budget goes to the tile) computes the permuted index
+// inline instead of reading it from a 2^s-entry table.
+template <typename E, int VEC, bool TABLE>
 __global__ void __launch_bounds__(kBlock)
 swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
                 const uint64_t ntiles) {
   struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned S = 1u << sa.s, TILE = 1u << tile_bits;
-  uint16_t* src = reinterpret_cast<uint16_t*>(smem);          // S entries
-  E* buf = reinterpret_cast<E*>(smem + (((size_t)S * 2 + 15) & ~(size_t)15));
+  uint16_t* src = reinterpret_cast<uint16_t*>(smem);          // S entries (TABLE only)
+  E* buf = reinterpret_cast<E*>(smem + (TABLE ? (((size_t)S * 2 + 15) & ~(size_t)15) : 0));
   const unsigned tid = threadIdx.x;
-  for (unsigned x = tid; x < S; x += kBlock) {
-    unsigned y = 0;
-    for (unsigned i = 0; i < sa.s; ++i) y |= ((x >> i) & 1u) << sa.pos[i];
-    src[x] = (uint16_t)y;
-  }
+  if (TABLE)
+    for (unsigned x = tid; x < S; x += kBlock) {
+      unsigned y = 0;
+      for (unsigned i = 0; i < sa.s; ++i) y |= ((x >> i) & 1u) << sa.pos[i];
+      src[x] = (uint16_t)y;
+    }
   for (uint64_t tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
     E* g = a + tb * TILE;
     __syncthreads();
@@ -747,7 +750,14 @@ swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
         const unsigned xx = x + c;
-        p.e[c] = buf[(xx & ~(S - 1)) | src[xx & (S - 1)]];
+        unsigned y;
+        if (TABLE) {
+          y = src[xx & (S - 1)];
+        } else {
+          y = 0;
+          for (unsigned i = 0; i < sa.s; ++i) y |= ((xx >> i) & 1u) << sa.pos[i];
+        }
+        p.e[c] = buf[(xx & ~(S - 1)) | y];
       }
       *reinterpret_cast<Pack*>(g + x) = p;
     }
