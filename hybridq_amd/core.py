@@ -130,6 +130,12 @@ _apply_blocked = {
     for b in (32, 64)
 }
 
+_program_begin = _define_function(_lib, 'hq_program_begin', ctypes.c_int)
+_program_end = _define_function(_lib, 'hq_program_end', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p))
+_program_size = _define_function(_lib, 'hq_program_size', ctypes.c_int, ctypes.c_void_p)
+_program_run = _define_function(_lib, 'hq_program_run', ctypes.c_int, ctypes.c_void_p)
+_program_free = _define_function(_lib, 'hq_program_free', ctypes.c_int, ctypes.c_void_p)
+
 #: symbols the C header include/hq_hip.h declares (checked by tests/test_abi.py)
 EXPORTED = [
     'get_log2_pack_size', 'apply_U_float32', 'apply_U_float64', 'to_complex64', 'to_complex128',
@@ -140,6 +146,7 @@ EXPORTED = [
     'hq_permute_bits_32', 'hq_permute_bits_64',
     'hq_probabilities_float32', 'hq_probabilities_float64', 'hq_project_float32', 'hq_project_float64',
     'hq_vdot_float32', 'hq_vdot_float64', 'hq_apply_blocked_float32', 'hq_apply_blocked_float64',
+    'hq_program_begin', 'hq_program_end', 'hq_program_size', 'hq_program_run', 'hq_program_free',
 ]
 
 
@@ -329,3 +336,48 @@ def apply_blocked(psi_re, psi_im, tile_pos, gates=None, n_qubits=None, packed=No
     rc = _apply_blocked[ft](_ptr(psi_re), _ptr(psi_im), n, tile_pos.ctypes.data_as(U32P), len(tile_pos),
                             len(k_all), U_all.ctypes.data, pos_all.ctypes.data_as(U32P), k_all.ctypes.data_as(U32P))
     _check(rc, 'apply_blocked')
+
+
+class Program:
+    """Compiled circuit: ``with Program() as prog: <apply_U / apply_blocked / ... calls>`` records
+    the launches instead of running them; ``prog.run()`` replays them (one hipGraph launch from
+    the second run on).  Bound to the plane tensors used while recording -- keep them alive."""
+
+    def __init__(self):
+        self._handle = ctypes.c_void_p(None)
+        self._recording = False
+        self._keep = []
+
+    def __enter__(self):
+        _check(_program_begin(), 'hq_program_begin')
+        self._recording = True
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        rc = _program_end(ctypes.byref(self._handle))
+        self._recording = False
+        if exc_type is None:
+            _check(rc, 'hq_program_end')
+        elif self._handle:
+            self.free()
+        return False
+
+    def keep_alive(self, *objects):
+        self._keep.extend(objects)
+
+    def __len__(self):
+        return max(0, int(_program_size(self._handle)))
+
+    def run(self):
+        _check(_program_run(self._handle), 'hq_program_run')
+
+    def free(self):
+        if self._handle:
+            _program_free(self._handle)
+            self._handle = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -22,8 +23,23 @@ namespace hq {
 // ---------------------------------------------------------------------------------
 enum class Mode { Auto, Direct, Mfma, Generic, Naive };
 
+// A recorded sequence of launches ("compiled circuit"): every matrix / operand table it needs
+// lives in its own device buffer, so replaying it is pure kernel launches -- from a plain loop
+// or, after the first run, from one hipGraph launch.
+struct Program {
+  std::vector<std::function<void(hipStream_t)>> ops;
+  std::vector<unsigned char> host;  // staged tables, uploaded once by hq_program_end
+  unsigned char* dev = nullptr;
+  size_t cap = 0;
+  bool finalized = false;
+  bool use_graph = true;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t graph_stream = nullptr;  // capture needs a non-default stream
+};
+
 struct Context {
   std::mutex mu;
+  Program* rec = nullptr;  // non-null while hq_program_begin .. hq_program_end records
   hipStream_t stream = nullptr;
   unsigned log2_pack = 1;
   Mode mode = Mode::Auto;
@@ -59,6 +75,22 @@ static int fail(const std::string& msg) {
     hipError_t _e = (expr);                                                            \
     if (_e != hipSuccess)                                                              \
       return fail(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+  } while (0)
+
+// Launch now, or append to the program being recorded (arguments are captured by value).
+#define HQ_LAUNCH(c_, kern, grid, block, lds, ...)                                              \
+  do {                                                                                          \
+    if ((c_).rec) {                                                                             \
+      (c_).rec->ops.emplace_back(                                                               \
+          [=](hipStream_t s_) { hipLaunchKernelGGL(kern, grid, block, lds, s_, __VA_ARGS__); });  \
+    } else {                                                                                    \
+      hipLaunchKernelGGL(kern, grid, block, lds, (c_).stream, __VA_ARGS__);                     \
+    }                                                                                           \
+  } while (0)
+
+#define HQ_NOT_RECORDABLE(c_, what)                                                             \
+  do {                                                                                          \
+    if ((c_).rec) return fail(std::string(what) + " cannot be recorded into a program");        \
   } while (0)
 
 static void read_env(Context& c) {
@@ -119,6 +151,14 @@ static int arena_upload(Context& c, const void* host, size_t bytes, void** dev) 
     c.arena_size = kArena;
   }
   const size_t need = (bytes + 255) & ~(size_t)255;
+  if (c.rec) {  // recording: the table goes into the program's own buffer
+    const size_t off = c.rec->host.size();
+    if (off + need > c.rec->cap) return fail("program table buffer exhausted (HQ_PROGRAM_MB)");
+    c.rec->host.resize(off + need);
+    memcpy(c.rec->host.data() + off, host, bytes);
+    *dev = c.rec->dev + off;
+    return 0;
+  }
   if (need > c.arena_size) return fail("matrix too large for the upload arena");
   if (c.arena_used + need > c.arena_size) {
     HQ_HIP_CHECK(hipStreamSynchronize(c.stream));  // wrap: wait for in-flight users
@@ -193,11 +233,9 @@ static int launch_direct_kv(Context& c, T* re, T* im, const T* U, const unsigned
     for (int j = 0; j < KR; ++j) nt = nt && (rp.p[j] + VB >= 7);
   }
   if (nt)
-    hipLaunchKernelGGL((apply_direct_kernel<T, K, VMASK, ILP, true>), dim3((unsigned)nblocks),
-                       dim3(kBlock), 0, c.stream, re, im, g, rp);
+    HQ_LAUNCH(c, (apply_direct_kernel<T, K, VMASK, ILP, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, re, im, g, rp);
   else
-    hipLaunchKernelGGL((apply_direct_kernel<T, K, VMASK, ILP, false>), dim3((unsigned)nblocks),
-                       dim3(kBlock), 0, c.stream, re, im, g, rp);
+    HQ_LAUNCH(c, (apply_direct_kernel<T, K, VMASK, ILP, false>), dim3((unsigned)nblocks), dim3(kBlock), 0, re, im, g, rp);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "direct";
   c.last_desc = std::string("apply_direct_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
@@ -412,12 +450,11 @@ template <typename T, int KBITS, int VMASK>
 static void launch_mfma_kv(Context& c, T* re, T* im, const T* dA, const MfmaPlan<T>& P, unsigned nblocks) {
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NL = 1 << (NS - KV);
   constexpr int ILP = NL >= 8 ? 1 : 8 / NL;
+  const MfmaRoles ro = P.ro;  // captured by value when the launch is recorded
   if (P.nt)
-    hipLaunchKernelGGL((apply_mfma_kernel<T, KBITS, VMASK, ILP, true>), dim3(nblocks), dim3(kBlock), 0,
-                       c.stream, re, im, dA, P.ro);
+    HQ_LAUNCH(c, (apply_mfma_kernel<T, KBITS, VMASK, ILP, true>), dim3(nblocks), dim3(kBlock), 0, re, im, dA, ro);
   else
-    hipLaunchKernelGGL((apply_mfma_kernel<T, KBITS, VMASK, ILP, false>), dim3(nblocks), dim3(kBlock), 0,
-                       c.stream, re, im, dA, P.ro);
+    HQ_LAUNCH(c, (apply_mfma_kernel<T, KBITS, VMASK, ILP, false>), dim3(nblocks), dim3(kBlock), 0, re, im, dA, ro);
 }
 
 template <typename T>
@@ -491,8 +528,7 @@ static int launch_generic(Context& c, T* re, T* im, const T* U, const unsigned* 
   }
   const uint64_t nblocks = 1ull << (n - k - a.c);
   const unsigned grid = (unsigned)std::min<uint64_t>(nblocks, 256 * 16);
-  hipLaunchKernelGGL((apply_generic_kernel<T>), dim3(grid), dim3(kBlock), lds, c.stream, re, im,
-                     (const T*)dU, a, nblocks);
+  HQ_LAUNCH(c, (apply_generic_kernel<T>), dim3(grid), dim3(kBlock), lds, re, im, (const T*)dU, a, nblocks);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "generic";
   c.last_desc = std::string("apply_generic_kernel<") + (sizeof(T) == 4 ? "float" : "double") + "> k=" + std::to_string(k);
@@ -548,11 +584,9 @@ static int launch_mfma_tile(Context& c, T* re, T* im, const T* U, const unsigned
   const uint64_t nblocks = 1ull << (n - tile_bits);
   const unsigned grid = (unsigned)std::min<uint64_t>(nblocks, 256 * 4);
   if (k == 5)
-    hipLaunchKernelGGL((apply_mfma_tile_kernel<T, 5>), dim3(grid), dim3(kBlock), lds, c.stream, re, im,
-                       (const T*)dA, a, nblocks);
+    HQ_LAUNCH(c, (apply_mfma_tile_kernel<T, 5>), dim3(grid), dim3(kBlock), lds, re, im, (const T*)dA, a, nblocks);
   else
-    hipLaunchKernelGGL((apply_mfma_tile_kernel<T, 6>), dim3(grid), dim3(kBlock), lds, c.stream, re, im,
-                       (const T*)dA, a, nblocks);
+    HQ_LAUNCH(c, (apply_mfma_tile_kernel<T, 6>), dim3(grid), dim3(kBlock), lds, re, im, (const T*)dA, a, nblocks);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "mfma_tile";
   c.last_desc = std::string("apply_mfma_tile_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
@@ -563,6 +597,7 @@ static int launch_mfma_tile(Context& c, T* re, T* im, const T* U, const unsigned
 template <typename T>
 static int launch_naive(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
                         unsigned k) {
+  HQ_NOT_RECORDABLE(c, "the tiny-state fallback kernel");
   NaiveArg a;
   memset(&a, 0, sizeof(a));
   a.k = k;
@@ -634,6 +669,7 @@ static int apply_U_entry(T* re, T* im, const T* U, const unsigned* pos, unsigned
   if (dre != dim_) return fail("apply_U: psi_re/psi_im must both be device or both host");
   if (dre) return apply_device<T>(c, re, im, U, pos, n, k);
   // host compatibility path: stage -> kernel -> copy back -> sync
+  HQ_NOT_RECORDABLE(c, "a host-pointer call");
   const size_t bytes = ((size_t)1 << n) * sizeof(T);
   void* s0 = nullptr;
   if (get_scratch(c, 0, 2 * bytes, &s0)) return 1;
@@ -681,17 +717,15 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
       attr_done = true;
     }
     if (!table)
-      hipLaunchKernelGGL((swap_lds_kernel<E, VEC, false>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
-                         tile_bits, ntiles);
+      HQ_LAUNCH(c, (swap_lds_kernel<E, VEC, false>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
     else if (vec)
-      hipLaunchKernelGGL((swap_lds_kernel<E, VEC, true>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
-                         tile_bits, ntiles);
+      HQ_LAUNCH(c, (swap_lds_kernel<E, VEC, true>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
     else
-      hipLaunchKernelGGL((swap_lds_kernel<E, 1, true>), dim3(grid), dim3(kBlock), lds, c.stream, a, sa,
-                         tile_bits, ntiles);
+      HQ_LAUNCH(c, (swap_lds_kernel<E, 1, true>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
     HQ_HIP_CHECK(hipGetLastError());
     return 0;
   }
+  HQ_NOT_RECORDABLE(c, "the out-of-place swap path");
   const uint64_t size = 1ull << n;
   void* tmp = nullptr;
   if (get_scratch(c, 2, size * sizeof(E), &tmp)) return 1;
@@ -717,6 +751,7 @@ static int swap_entry(E* a, const unsigned* pos, unsigned n, unsigned s) {
     seen |= 1ull << pos[i];
   }
   if (is_device_pointer(a)) return swap_device<E>(c, a, pos, n, s);
+  HQ_NOT_RECORDABLE(c, "a host-pointer call");
   const size_t bytes = ((size_t)1 << n) * sizeof(E);
   void* s0 = nullptr;
   if (get_scratch(c, 0, bytes, &s0)) return 1;
@@ -761,11 +796,11 @@ static int permute_bits_entry(const E* src, E* dst, const unsigned* perm, unsign
   const uint64_t units = vec16 ? size / 4 : (vec16d ? size / 2 : size);
   const unsigned grid = (unsigned)std::min<uint64_t>((units + kBlock - 1) / kBlock, 256 * 64);
   if (vec16)
-    hipLaunchKernelGGL((permute_bits_kernel<E, 4>), dim3(grid), dim3(kBlock), 0, c.stream, src, dst, pa, units);
+    HQ_LAUNCH(c, (permute_bits_kernel<E, 4>), dim3(grid), dim3(kBlock), 0, src, dst, pa, units);
   else if (vec16d)
-    hipLaunchKernelGGL((permute_bits_kernel<E, 2>), dim3(grid), dim3(kBlock), 0, c.stream, src, dst, pa, units);
+    HQ_LAUNCH(c, (permute_bits_kernel<E, 2>), dim3(grid), dim3(kBlock), 0, src, dst, pa, units);
   else
-    hipLaunchKernelGGL((permute_bits_kernel<E, 1>), dim3(grid), dim3(kBlock), 0, c.stream, src, dst, pa, units);
+    HQ_LAUNCH(c, (permute_bits_kernel<E, 1>), dim3(grid), dim3(kBlock), 0, src, dst, pa, units);
   HQ_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -782,12 +817,10 @@ static int interleave_device(Context& c, const T* re, const T* im, T* out, uint6
   if (vec) {
     const uint64_t nq = size / 4;
     const unsigned grid = (unsigned)std::min<uint64_t>((nq + kBlock - 1) / kBlock, 256 * 32);
-    hipLaunchKernelGGL((interleave4_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, out,
-                       nq);
+    HQ_LAUNCH(c, (interleave4_kernel<T>), dim3(grid), dim3(kBlock), 0, re, im, out, nq);
   } else {
     const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
-    hipLaunchKernelGGL((interleave_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, out,
-                       size);
+    HQ_LAUNCH(c, (interleave_kernel<T>), dim3(grid), dim3(kBlock), 0, re, im, out, size);
   }
   HQ_HIP_CHECK(hipGetLastError());
   return 0;
@@ -805,6 +838,7 @@ static int to_complex_entry(T* re, T* im, T* out, uint64_t size) {
   const bool d_out = is_device_pointer(out);
   const size_t bytes = size * sizeof(T);
   if (d_in && d_out) return interleave_device<T>(c, re, im, out, size);
+  HQ_NOT_RECORDABLE(c, "a host-pointer call");
   // stage whatever lives on the host
   const T *sre = re, *sim = im;
   T* sout = out;
@@ -841,8 +875,7 @@ static int init_state_entry(T* re, T* im, unsigned n, int kind, uint64_t basis) 
   if (kind != 0 && kind != 1) return fail("init_state: unknown kind");
   const T amp = (T)std::pow(2.0, -0.5 * (double)n);
   const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
-  hipLaunchKernelGGL((init_state_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, size,
-                     kind, basis, amp);
+  HQ_LAUNCH(c, (init_state_kernel<T>), dim3(grid), dim3(kBlock), 0, re, im, size, kind, basis, amp);
   HQ_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -852,6 +885,7 @@ static int norm2_entry(const T* re, const T* im, uint64_t size, double* out) {
   Context& c = ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   read_env(c);
+  HQ_NOT_RECORDABLE(c, "a reduction that returns a value to the host");
   if (!re || !im || !out) return fail("norm2: null pointer");
   if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("norm2: device pointers only");
   void* s1 = nullptr;
@@ -944,11 +978,9 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * std::min<size_t>(per_cu, 4));
   static int block_threads = getenv("HQ_BLOCKED_THREADS") ? atoi(getenv("HQ_BLOCKED_THREADS")) : 512;
   if (block_threads == 256)
-    hipLaunchKernelGGL((apply_blocked_kernel<T, 256>), dim3(grid), dim3(256), lds, c.stream, re, im,
-                       (const BlockedGate*)dG, n_gates, (const T*)dA, ba, ntiles);
+    HQ_LAUNCH(c, (apply_blocked_kernel<T, 256>), dim3(grid), dim3(256), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, ba, ntiles);
   else
-    hipLaunchKernelGGL((apply_blocked_kernel<T, 512>), dim3(grid), dim3(512), lds, c.stream, re, im,
-                       (const BlockedGate*)dG, n_gates, (const T*)dA, ba, ntiles);
+    HQ_LAUNCH(c, (apply_blocked_kernel<T, 512>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, ba, ntiles);
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "blocked";
   c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
@@ -963,6 +995,7 @@ static int probabilities_entry(const T* re, const T* im, unsigned n, const unsig
   Context& c = ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   read_env(c);
+  HQ_NOT_RECORDABLE(c, "a reduction that returns a value to the host");
   if (!re || !im || !pos || !out) return fail("probabilities: null pointer");
   if (k > kMaxK || check_positions(pos, n, k)) return fail("probabilities: invalid positions");
   if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("probabilities: device pointers only");
@@ -1000,8 +1033,7 @@ static int project_entry(T* re, T* im, unsigned n, const unsigned* pos, unsigned
   }
   const uint64_t size = 1ull << n;
   const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
-  hipLaunchKernelGGL((project_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, size, mask, want,
-                     (T)scale);
+  HQ_LAUNCH(c, (project_kernel<T>), dim3(grid), dim3(kBlock), 0, re, im, size, mask, want, (T)scale);
   HQ_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1011,6 +1043,7 @@ static int vdot_entry(const T* are, const T* aim, const T* bre, const T* bim, ui
   Context& c = ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   read_env(c);
+  HQ_NOT_RECORDABLE(c, "a reduction that returns a value to the host");
   if (!are || !aim || !bre || !bim || !out) return fail("vdot: null pointer");
   if (!is_device_pointer(are) || !is_device_pointer(aim) || !is_device_pointer(bre) || !is_device_pointer(bim))
     return fail("vdot: device pointers only");
@@ -1123,6 +1156,107 @@ int hq_apply_blocked_float64(double* re, double* im, unsigned int n, const unsig
                              unsigned int tile_bits, unsigned int n_gates, const double* U_all,
                              const unsigned int* pos_all, const unsigned int* k_all) {
   return hq::apply_blocked_entry<double>(re, im, n, tile_pos, tile_bits, n_gates, U_all, pos_all, k_all);
+}
+
+int hq_program_begin(void) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::read_env(c);
+  if (c.rec) return hq::fail("hq_program_begin: already recording");
+  if (hq::check_device(c)) return 1;
+  hq::Program* p = new hq::Program();
+  size_t mb = 64;
+  if (const char* e = getenv("HQ_PROGRAM_MB")) mb = (size_t)std::max(1, atoi(e));
+  p->cap = mb << 20;
+  if (const char* e = getenv("HQ_PROGRAM_GRAPH")) p->use_graph = atoi(e) != 0;
+  hipError_t err = hipMalloc((void**)&p->dev, p->cap);
+  if (err != hipSuccess) {
+    delete p;
+    return hq::fail(std::string("hq_program_begin: hipMalloc: ") + hipGetErrorString(err));
+  }
+  c.rec = p;
+  return 0;
+}
+
+int hq_program_end(void** handle) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (!c.rec) return hq::fail("hq_program_end: not recording");
+  hq::Program* p = c.rec;
+  c.rec = nullptr;
+  if (!p->host.empty()) {
+    hipError_t err = hipMemcpy(p->dev, p->host.data(), p->host.size(), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+      (void)hipFree(p->dev);
+      delete p;
+      return hq::fail(std::string("hq_program_end: hipMemcpy: ") + hipGetErrorString(err));
+    }
+  }
+  p->host.clear();
+  p->host.shrink_to_fit();
+  p->finalized = true;
+  if (handle) *handle = p;
+  return 0;
+}
+
+int hq_program_size(void* handle) {
+  return handle ? (int)reinterpret_cast<hq::Program*>(handle)->ops.size() : -1;
+}
+
+int hq_program_run(void* handle) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::Program* p = reinterpret_cast<hq::Program*>(handle);
+  if (!p || !p->finalized) return hq::fail("hq_program_run: invalid program");
+  if (c.rec) return hq::fail("hq_program_run: cannot run while recording");
+  if (!p->use_graph || p->ops.size() < 2) {
+    for (auto& op : p->ops) op(c.stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hq::fail(std::string("hq_program_run: ") + hipGetErrorString(e));
+    return 0;
+  }
+  // hipGraph replay.  The legacy default stream cannot be captured, so a null library stream
+  // is replaced by a private BLOCKING stream: legacy-stream semantics order it with the work
+  // around it on the default stream.
+  hipStream_t s = c.stream;
+  if (s == nullptr) {
+    if (!p->graph_stream) {
+      hipError_t e = hipStreamCreate(&p->graph_stream);
+      if (e != hipSuccess) return hq::fail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    s = p->graph_stream;
+  }
+  if (!p->exec) {
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return hq::fail(std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+    for (auto& op : p->ops) op(s);
+    e = hipStreamEndCapture(s, &graph);
+    if (e != hipSuccess) return hq::fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(&p->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return hq::fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  }
+  hipError_t e = hipGraphLaunch(p->exec, s);
+  if (e != hipSuccess) return hq::fail(std::string("hipGraphLaunch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int hq_program_free(void* handle) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::Program* p = reinterpret_cast<hq::Program*>(handle);
+  if (!p) return 0;
+  if (c.rec == p) c.rec = nullptr;
+  (void)hipStreamSynchronize(c.stream);
+  if (p->graph_stream) {
+    (void)hipStreamSynchronize(p->graph_stream);
+    (void)hipStreamDestroy(p->graph_stream);
+  }
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->dev) (void)hipFree(p->dev);
+  delete p;
+  return 0;
 }
 
 int hq_set_stream(void* hip_stream) {

@@ -176,6 +176,23 @@ class EvolutionState:
         new_psi = np.ascontiguousarray(new_psi, dtype=self.float_type).reshape(2, -1)
         self.planes.copy_(torch.from_numpy(new_psi))
 
+    def compile(self, circuit, compress=4, blocked=False):
+        """Record `circuit` (matrix gates only) against THIS state's planes into a
+        :class:`hybridq_amd.core.Program`: fusion / blocking are planned once, every operand
+        table is uploaded once, and ``program.run()`` replays the launches with no host work
+        per gate (one hipGraph launch from the second run on).  Useful when the same circuit
+        is applied repeatedly (parameter sweeps at fixed structure re-compile; shots with
+        different initial states only rewrite the planes) and at small n where one gate kernel
+        (~10 us) is shorter than the ~11 us a Python-level call costs."""
+        gates = _plan_ops(list(circuit), self.qubits, self.n, self.complex_type, compress, blocked)
+        if any(_is_functional(g) for g in gates):
+            raise ValueError('functional gates cannot be compiled')
+        prog = core.Program()
+        with prog:
+            _execute_ops(self, gates)
+        prog.keep_alive(self.planes)
+        return prog
+
     def to_complex(self):
         """Interleave the planes into a complex torch tensor on the device (:669-675)."""
         torch = _torch()
@@ -186,6 +203,63 @@ class EvolutionState:
 
     def norm2(self):
         return core.norm2(self.planes[0], self.planes[1])
+
+
+def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
+    """Turn a circuit into the op list the gate loop executes: fused ``(qubits, U)`` gates
+    (simulation.py:436-454), or the 'B'/'G' ops of the cache-blocked planner; FunctionalGates are
+    never fused (skip_compression=[FunctionalGate], :441) -- the circuit is cut at them."""
+    comp_kw = {k: v for k, v in compress.items() if k != 'max_n_qubits'} if isinstance(compress, dict) else {}
+    comp_n = compress.get('max_n_qubits', 4) if isinstance(compress, dict) else compress
+    use_blocked = bool(blocked) and n >= 14
+    pos_of = {q: n - x - 1 for x, q in enumerate(qubits)}  # simulation.py:512 (never permuted here)
+    gates, run = [], []
+
+    def flush():
+        if not run:
+            return
+        if use_blocked:
+            # many gates per HBM pass (hybridq_amd.blocking); inner fusion replaces `compress`
+            from .blocking import plan_blocked
+            opts = dict(blocked) if isinstance(blocked, dict) else {}
+            opts.setdefault('tile_bits', 13 if ctype == np.dtype('complex64') else 12)  # 64 KiB of LDS
+            opts.setdefault('low_bits', 5 if ctype == np.dtype('complex64') else 4)
+            opts.setdefault('complex_type', ctype)
+            gates.extend(plan_blocked([(U, qs) for qs, U in run], pos_of, n, **opts))
+        elif comp_n:
+            from .fusion import fuse
+            gates.extend((qs, U) for U, qs in fuse([(U, qs) for qs, U in run], comp_n, complex_type=ctype, **comp_kw))
+        else:
+            gates.extend(run)
+        run.clear()
+
+    for g in circuit:
+        if _is_functional(g):
+            flush()
+            gates.append(g)
+        else:
+            run.append(_gate_qubits_matrix(g))
+    flush()
+    return gates
+
+
+def _execute_ops(state, gates):
+    """The gate loop (simulation.py:522-646); returns the number of passes over the state."""
+    n = state.n
+    n_passes = 0
+    for g in gates:
+        if _is_functional(g):
+            state.apply_functional(g)
+        elif isinstance(g[0], str):  # ops of the blocked planner, positions already physical
+            n_passes += 1
+            if g[0] == 'B':
+                core.apply_blocked(state.planes[0], state.planes[1], g[1], g[2], n)
+            else:
+                core.apply_U(state.planes[0], state.planes[1], g[1], g[2], n)
+        else:
+            n_passes += 1
+            state.apply(g[1], g[0])
+    return n_passes
 
 
 def simulate(circuit, initial_state=None, final_state=None, optimize='evolution', backend='numpy',
@@ -222,44 +296,9 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     qubits = kwargs.get('qubits') or all_qubits(circuit)
     n = len(qubits)
     n_given = len(circuit)
-    # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519).
-    # FunctionalGates are never fused (skip_compression=[FunctionalGate], :441): the circuit
-    # is cut at them and every run of matrix gates is fused on its own.
-    comp = kwargs['compress']
-    comp_kw = {k: v for k, v in comp.items() if k != 'max_n_qubits'} if isinstance(comp, dict) else {}
-    comp_n = comp.get('max_n_qubits', 4) if isinstance(comp, dict) else comp
     ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
-    gates, run = [], []
-
-    blocked = kwargs.get('blocked', False)
-    use_blocked = bool(blocked) and n >= 14
-    pos_of = {q: n - x - 1 for x, q in enumerate(qubits)}  # simulation.py:512 (never permuted here)
-
-    def flush():
-        if not run:
-            return
-        if use_blocked:
-            # many gates per HBM pass (hybridq_amd.blocking); inner fusion replaces `compress`
-            from .blocking import plan_blocked
-            opts = dict(blocked) if isinstance(blocked, dict) else {}
-            opts.setdefault('tile_bits', 13 if ctype == np.dtype('complex64') else 12)  # 64 KiB of LDS
-            opts.setdefault('low_bits', 5 if ctype == np.dtype('complex64') else 4)
-            opts.setdefault('complex_type', ctype)
-            gates.extend(plan_blocked([(U, qs) for qs, U in run], pos_of, n, **opts))
-        elif comp_n:
-            from .fusion import fuse
-            gates.extend((qs, U) for U, qs in fuse([(U, qs) for qs, U in run], comp_n, complex_type=ctype, **comp_kw))
-        else:
-            gates.extend(run)
-        run.clear()
-
-    for g in circuit:
-        if _is_functional(g):
-            flush()
-            gates.append(g)
-        else:
-            run.append(_gate_qubits_matrix(g))
-    flush()
+    # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519)
+    gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
     if 2**n > kwargs['max_largest_intermediate']:  # simulation.py:409-412
         raise MemoryError("Memory for the given number of qubits exceeds the 'max_largest_intermediate'.")
 
@@ -269,19 +308,7 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     info = {}
     core.sync()
     t0 = time.perf_counter()  # simulation.py:519
-    n_passes = 0
-    for g in gates:
-        if _is_functional(g):
-            state.apply_functional(g)
-        elif isinstance(g[0], str):  # ops of the blocked planner, positions already physical
-            n_passes += 1
-            if g[0] == 'B':
-                core.apply_blocked(state.planes[0], state.planes[1], g[1], g[2], n)
-            else:
-                core.apply_U(state.planes[0], state.planes[1], g[1], g[2], n)
-        else:
-            n_passes += 1
-            state.apply(g[1], g[0])
+    n_passes = _execute_ops(state, gates)
     core.sync()  # the ONLY synchronisation of the loop
     t1 = time.perf_counter()  # simulation.py:666
     info['runtime (s)'] = t1 - t0

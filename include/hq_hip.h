@@ -163,6 +163,21 @@ int hq_apply_blocked_float64(double *psi_re, double *psi_im, unsigned int n_qubi
                              const unsigned int *tile_pos, unsigned int tile_bits, unsigned int n_gates,
                              const double *U_all, const unsigned int *pos_all, const unsigned int *k_all);
 
+/* Compiled circuits.  Between hq_program_begin() and hq_program_end() every DEVICE-pointer call
+ * of apply_U_*, hq_apply_blocked_*, swap_* (LDS path), hq_permute_bits_*, hq_to_complex*,
+ * hq_init_state_* and hq_project_* is RECORDED instead of executed: its launch parameters and a
+ * private copy of its matrices / operand tables go into the program.  hq_program_run() replays
+ * the recorded launches on the library's stream with no planning, no uploads and no host work
+ * per gate -- from the second run on as ONE hipGraph launch (HQ_PROGRAM_GRAPH=0: plain launch
+ * loop).  The program is bound to the plane pointers it was recorded with.  Calls that return a
+ * value to the host or need staging (host pointers, norm2, probabilities, vdot) cannot be
+ * recorded and return 1.  Table space: 64 MiB per program (env HQ_PROGRAM_MB). */
+int hq_program_begin(void);
+int hq_program_end(void **handle);
+int hq_program_size(void *handle);   /* recorded launches, -1 for NULL */
+int hq_program_run(void *handle);
+int hq_program_free(void *handle);
+
 #ifdef __cplusplus
 }
 #endif

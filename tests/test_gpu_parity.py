@@ -627,3 +627,83 @@ def test_simulate_blocked_matches_oracle(torch_cuda, oracle_port):
     psi = simulate(g[:50] + [fg] + g[50:], initial_state='0' * 16, blocked=True, qubits=list(range(16)))
     exp = oracle.evolve_tensordot(g, 16)
     assert seen and np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max() < 5e-6
+
+
+@pytest.mark.parametrize('graph', ['1', '0'])
+def test_compiled_program_matches_oracle(torch_cuda, oracle_port, graph, monkeypatch):
+    """hq_program_*: record a circuit once (per-gate, fused, blocked, swap + permute included),
+    replay it several times (loop / hipGraph capture / graph replay) -- each replay equals one
+    more application of the circuit by the oracle.  Non-recordable calls fail while recording
+    and leave the library usable."""
+    import oracle
+    from hybridq_amd import core
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    from hybridq_amd.simulation import EvolutionState
+    torch = torch_cuda
+    monkeypatch.setenv('HQ_PROGRAM_GRAPH', graph)
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    n = 16
+    gates = rqc_1q2q(n, depth=6, seed=41) + random_dense(n, 10, kmax=6, seed=42)
+    one = oracle.evolve_tensordot(gates, n)
+    for ct, tol, kw in (('complex64', 5e-6, dict(compress=0)), ('complex64', 5e-6, dict(compress=4)),
+                        ('complex64', 5e-6, dict(blocked=True)), ('complex128', 1e-12, dict(compress=4)),
+                        ('complex128', 1e-12, dict(blocked=True))):
+        st = EvolutionState(list(range(n)), complex_type=ct, initial_state='0' * n)
+        prog = st.compile(gates, **kw)
+        assert len(prog) > 0
+        core.sync()
+        # recording must not have touched the state
+        psi0 = st.to_complex().cpu().numpy()
+        assert psi0[0] == 1 and np.count_nonzero(psi0) == 1
+        prog.run()
+        core.sync()
+        psi = st.to_complex().cpu().numpy()
+        assert np.abs(psi - one).max() / np.abs(one).max() < tol, (ct, kw)
+        # replays (second run = captured graph): circuit applied 3 times in total
+        prog.run()
+        prog.run()
+        core.sync()
+        three = oracle.evolve_tensordot(gates * 3, n)
+        psi = st.to_complex().cpu().numpy()
+        assert np.abs(psi - three).max() / np.abs(three).max() < 3 * tol, (ct, kw)
+        # the library still runs eagerly after a program was recorded, and the program is
+        # unaffected by eager calls in between
+        st.apply(np.array([[0, 1], [1, 0]]), (3,))
+        st.apply(np.array([[0, 1], [1, 0]]), (3,))
+        prog.free()
+        with pytest.raises(core.HQError):
+            prog.run()
+    # swap and permute_bits record too (exact)
+    rng = np.random.default_rng(5)
+    a = torch.from_numpy(rng.standard_normal(1 << n).astype(np.float32)).cuda()
+    b = torch.empty_like(a)
+    ref = a.clone()
+    perm = [int(x) for x in rng.permutation(n)]
+    with core.Program() as prog:
+        core.swap(a, [2, 0, 1], n)
+        core.permute_bits(a, b, perm, n)
+    core.sync()
+    assert bool((a == ref).all())
+    prog.run()
+    core.sync()
+    a2, b2 = ref.clone(), torch.empty_like(ref)
+    core.swap(a2, [2, 0, 1], n)
+    core.permute_bits(a2, b2, perm, n)
+    core.sync()
+    assert bool((a == a2).all()) and bool((b == b2).all()) and not bool((a == ref).all())
+    # non-recordable calls: fail loudly, recording can be closed, nothing half-recorded runs
+    re = torch.zeros(1 << n, dtype=torch.float32, device='cuda')
+    im = torch.zeros_like(re)
+    prog = core.Program()
+    with prog:
+        with pytest.raises(core.HQError):
+            core.norm2(re, im)
+        with pytest.raises(core.HQError):
+            core.apply_U(np.zeros(1 << 10, np.float32), np.zeros(1 << 10, np.float32), np.eye(2), [3], 10)
+    assert len(prog) == 0
+    with pytest.raises(core.HQError):
+        with core.Program():
+            with core.Program():  # nested recording is an error
+                pass
+    core.init_state(re, im, 'plus')
+    assert abs(core.norm2(re, im) - 1.0) < 1e-5
