@@ -220,11 +220,30 @@ def main():
         n_permutes = sum(1 for op in schedules[-1] if op[0] == 'P')
         step_no = [0]
 
+        class OpTimer:
+            """HIP events around every op of the sharded schedule (torch's current stream IS the
+            library stream, set above); 'G' ops are labelled with the kernel they dispatched to."""
+
+            def __init__(self):
+                self.rows = []
+
+            def start(self, op):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                return (op[0], e0, e1)
+
+            def stop(self, tok):
+                tok[2].record()
+                self.rows.append((core.last_kernel_desc() if tok[0] == 'G' else {'P': 'permute_bits', 'X': 'all_to_all'}.get(tok[0], tok[0]),
+                                  tok[1], tok[2]))
+
+        op_timer = OpTimer() if not args.no_events else None
+
         def run_step(events=None):
             sched = schedules[step_no[0]]
             step_no[0] += 1
             sharded._planned_final_pos = None
-            sharded.run(sched, update_map=False)
+            sharded.run(sched, update_map=False, timer=op_timer if step_no[0] > max(1, args.warmup) else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -336,11 +355,18 @@ def main():
             'exchanges_per_step': n_exchanges,
             'permutation_passes_per_step': n_permutes,
         }
-    if rank == 0 and events is not None:
+    if rank == 0 and (events is not None or (sharded_path and op_timer is not None)):
         per_class = {}
-        for s in range(args.steps):
-            for kname, (e0, e1) in zip(kernel_of, events[s]):
-                per_class.setdefault(kname, []).append(e0.elapsed_time(e1))
+        if events is not None:
+            for s in range(args.steps):
+                for kname, (e0, e1) in zip(kernel_of, events[s]):
+                    per_class.setdefault(kname, []).append(e0.elapsed_time(e1))
+        else:  # sharded: rank 0's local gate kernels (exchange / permutation passes reported on their own)
+            other = {}
+            for kname, e0, e1 in op_timer.rows:
+                (per_class if kname not in ('permute_bits', 'all_to_all') else other).setdefault(kname, []).append(e0.elapsed_time(e1))
+            result['in_loop_ms'] = {c: {'launches': len(v), 'avg_ms': float(np.mean(v)), 'total_ms_per_step': float(np.sum(v)) / args.steps}
+                                    for c, v in sorted(other.items())}
         total = {c: float(np.sum(v)) for c, v in per_class.items()}
         dom = max(total, key=total.get)
         avg_ms = float(np.mean(per_class[dom]))

@@ -350,11 +350,14 @@ class ShardedEvolution:
             sched = out
         return sched
 
-    def run(self, schedule, update_map=True):
+    def run(self, schedule, update_map=True, timer=None):
+        """Execute a schedule.  `timer` (optional, used by bench.py): an object with
+        ``start(op) -> token`` / ``stop(token)`` called around every op on the issuing stream."""
         be = self.backend
         for op in schedule:
             if op[0] in ('P', 'X') and self.bufs[1 - self.cur] is None:
                 self.bufs[1 - self.cur] = be.empty_planes(self.m)
+            tok = timer.start(op) if timer is not None else None
             if op[0] == 'G':
                 be.apply(self.bufs[self.cur], op[1], op[2], self.m)
             elif op[0] == 'B':
@@ -365,6 +368,8 @@ class ShardedEvolution:
             else:
                 be.all_to_all(self.bufs[1 - self.cur], self.bufs[self.cur], self.group)
                 self.cur = 1 - self.cur
+            if timer is not None:
+                timer.stop(tok)
         if update_map:
             self.pos = dict(self._planned_final_pos)
 

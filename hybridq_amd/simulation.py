@@ -122,8 +122,8 @@ def prepare_state_planes(initial_state, n, float_type, device):
     psi = np.asarray(initial_state).reshape(-1)
     if psi.size != 1 << n:
         raise ValueError("'initial_state' has the wrong size.")
-    planes[0].copy_(torch.from_numpy(np.ascontiguousarray(psi.real, dtype=float_type)))
-    planes[1].copy_(torch.from_numpy(np.ascontiguousarray(psi.imag, dtype=float_type)))
+    planes[0].copy_(torch.from_numpy(np.array(psi.real, dtype=float_type, order='C')))
+    planes[1].copy_(torch.from_numpy(np.array(psi.imag, dtype=float_type, order='C')))
     return planes
 
 

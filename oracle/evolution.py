@@ -73,6 +73,19 @@ def _initial(initial_state, n, dtype):
         psi = np.zeros(1 << n, dtype=dtype)
         psi[0] = 1
         return psi
+    if isinstance(initial_state, str):
+        # '01+-' product state, first character = first (most significant) qubit; the value
+        # hybridq's prepare_state builds (circuit/simulation/utils.py:99-153: basis state,
+        # uniform superposition, or kron of ones and parity signs over sqrt(#'+' * #'-')).
+        s = initial_state * n if len(initial_state) == 1 else initial_state
+        if len(s) != n:
+            raise ValueError('initial_state has the wrong number of qubits')
+        single = {'0': (1.0, 0.0), '1': (0.0, 1.0), '+': (1.0, 1.0), '-': (1.0, -1.0)}
+        psi = np.ones(1, dtype=np.float64)
+        for ch in s:
+            psi = np.kron(psi, np.array(single[ch]))
+        psi /= np.sqrt(2.0 ** sum(ch in '+-' for ch in s))
+        return psi.astype(dtype)
     return np.array(initial_state, dtype=dtype).reshape(-1)
 
 

@@ -707,3 +707,29 @@ def test_compiled_program_matches_oracle(torch_cuda, oracle_port, graph, monkeyp
                 pass
     core.init_state(re, im, 'plus')
     assert abs(core.norm2(re, im) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize('n', [16, 20, 22])
+def test_simulation_large_like_reference(torch_cuda, oracle_port, n):
+    """Mirror of the reference's test_simulation_4__simulation_large (tests.py:2335-2369):
+    600 random NON-unitary 1-/2-qubit gates on random qubits, initial state = 3 basis characters
+    + random '01+-', complex64 with compress=4 and complex128 with compress=8 (k up to 8 through
+    the generic kernel), compared with an independent evolution.  The reference asserts 1e-3;
+    here: 2e-6-level for c64 (600 roundings) and 1e-12 for c128 against the f64 oracle run of
+    the reference's driver protocol."""
+    import oracle
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.simulation import simulate
+    rng = np.random.default_rng(100 + n)
+    init = ''.join(rng.choice(list('01'), size=3)) + ''.join(rng.choice(list('01+-'), size=n - 3))
+    gates = random_dense(n, 600, kmax=2, seed=200 + n)
+    exp, _ = oracle.evolve_reference_protocol(oracle_port, gates, n, initial_state=init, complex_type='complex128')
+    scale = np.abs(exp).max()
+    p64 = simulate(gates, initial_state=init, complex_type='complex64', compress=4, qubits=list(range(n)))
+    p128, info = simulate(gates, initial_state=init, complex_type='complex128', compress=8, qubits=list(range(n)),
+                          return_info=True)
+    assert p64.dtype == np.complex64 and p128.dtype == np.complex128 and p64.shape == (2,) * n
+    assert info['n_gates'] < 600 / 4
+    assert np.abs(p128.reshape(-1) - exp).max() / scale < 1e-12
+    assert np.abs(p64.reshape(-1) - exp).max() / scale < 1e-5
+    np.testing.assert_allclose(p64.reshape(-1), exp, rtol=1e-3, atol=1e-3 * scale)  # the reference's own bar
