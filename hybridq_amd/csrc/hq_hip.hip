@@ -21,7 +21,7 @@ namespace hq {
 // ---------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------
-enum class Mode { Auto, Direct, Mfma, Generic, Naive };
+enum class Mode { Auto, Direct, Mfma, Generic, Naive, Tile };
 
 // A recorded sequence of launches ("compiled circuit"): every matrix / operand table it needs
 // lives in its own device buffer, so replaying it is pure kernel launches -- from a plain loop
@@ -106,6 +106,7 @@ static void read_env(Context& c) {
     else if (s == "mfma") c.mode = Mode::Mfma;
     else if (s == "generic") c.mode = Mode::Generic;
     else if (s == "naive") c.mode = Mode::Naive;
+    else if (s == "tile") c.mode = Mode::Tile;
   }
   if (const char* e = getenv("HQ_NONTEMPORAL")) c.nontemporal = atoi(e) < 0 ? -1 : (atoi(e) != 0);
 }
@@ -330,14 +331,14 @@ template <typename T>
 static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigned n, unsigned k,
                       MfmaPlan<T>& P, bool for_tile = false) {
   constexpr unsigned CB = Vec<T>::VB;  // vector-component index bits: 2 (f32) / 1 (f64)
-  if (k < 1 || k > 4) return false;
+  if (k < 1 || k > (for_tile ? 4u : 6u)) return false;
   std::vector<T> Us;
   unsigned sp[kMaxK];
   sort_gate<T>(U, pos, k, Us, sp);
   const unsigned D = 1u << k;
   const T* Ur = Us.data();
   const T* Ui = Us.data() + (size_t)D * D;
-  const unsigned k_eff = k <= 3 ? 3 : 4;
+  const unsigned k_eff = k <= 3 ? 3 : k;
   P.kbits = (int)k_eff + 1;
   // effective digits: real targets (tbit = sorted target index) + identity dummies (tbit = -1)
   struct Digit { unsigned pos; int tbit; };
@@ -365,12 +366,13 @@ static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigne
   P.vmask = vmask;
   const int KV = (int)comp_digit.size(), NS = P.kbits - 2, NR = NS - KV, NL = 1 << NR;
   const unsigned na = (unsigned)addr_digit.size();
-  if (na < 1 || na > 4) return false;
+  if (na < 1 || na > 6) return false;
   P.n_addr = na;
   P.ilp = std::max(1, 8 / NL);
   if (NR < 0 || n < CB + na) return false;
   const uint64_t nslots = 1ull << (n - CB - na);
-  if (nslots < (for_tile ? 16u : (uint64_t)P.ilp * 64)) return false;  // tile mode: one wave iteration
+  // tile mode and the k >= 5 kernel (grid-stride over wave iterations): one wave iteration
+  if (nslots < ((for_tile || k_eff >= 5) ? 16u : (uint64_t)P.ilp * 64)) return false;
   // roles: -1 = plane, otherwise index into E.  q gets the low address digits first
   // (positions 2..5: a permutation of a contiguous run), then the plane, then the rest.
   constexpr int PLANE = -1;
@@ -382,7 +384,7 @@ static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigne
   std::vector<int> rd(order.begin() + 2, order.end());  // NR reg digits
   if ((int)rd.size() != NR) return false;
   MfmaRoles& ro = P.ro;
-  for (int m = 0; m < 4; ++m) ro.pos[m] = 63;
+  for (int m = 0; m < 6; ++m) ro.pos[m] = 63;
   for (unsigned m = 0; m < na; ++m) ro.pos[m] = E[addr_digit[m]].pos - CB;
   ro.q_plane = -1;
   ro.r_plane = -1;
@@ -390,7 +392,7 @@ static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigne
     ro.q_off[b] = qd[b] == PLANE ? 0u : (1u << (E[qd[b]].pos - CB));
     if (qd[b] == PLANE) ro.q_plane = b;
   }
-  for (int b = 0; b < 3; ++b) ro.r_off[b] = 0;
+  for (int b = 0; b < 5; ++b) ro.r_off[b] = 0;
   bool nt = true;
   for (int b = 0; b < NR; ++b) {
     if (rd[b] == PLANE) { ro.r_plane = b; continue; }
@@ -441,7 +443,12 @@ static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigne
           const T ur = Ur[tor * D + tir], ui = Ui[tor * D + tir];
           val = po == pi ? ur : (po == 0 ? -ui : ui);
         }
-        P.A[((size_t)rb * NSTEP + st) * 64 + lane] = val;
+        if (k_eff >= 5) {  // apply_mfma_big_kernel: G consecutive steps per 16-byte LDS read
+          constexpr int G = 16 / (int)sizeof(T);
+          P.A[((((size_t)rb * (NSTEP / G) + st / G) * 64 + lane) * G) + st % G] = val;
+        } else {
+          P.A[((size_t)rb * NSTEP + st) * 64 + lane] = val;
+        }
       }
   return true;
 }
@@ -457,11 +464,68 @@ static void launch_mfma_kv(Context& c, T* re, T* im, const T* dA, const MfmaPlan
     HQ_LAUNCH(c, (apply_mfma_kernel<T, KBITS, VMASK, ILP, false>), dim3(nblocks), dim3(kBlock), 0, re, im, dA, ro);
 }
 
+constexpr int kBigBlock = 512;
+
+template <typename T, int KBITS, int VMASK>
+static int launch_mfma_big_kv(Context& c, T* re, T* im, const T* dA, const MfmaPlan<T>& P, unsigned n) {
+  constexpr unsigned CB = Vec<T>::VB;
+  constexpr int NS = KBITS - 2, NRB = 1 << (NS - 2), NSTEP = 1 << NS;
+  constexpr size_t lds = (size_t)NRB * NSTEP * 64 * sizeof(T);
+  static bool attr_done = false;  // under the context mutex
+  if (!attr_done) {
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_mfma_big_kernel<T, KBITS, VMASK, true, kBigBlock>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_mfma_big_kernel<T, KBITS, VMASK, false, kBigBlock>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const uint64_t niter = (1ull << (n - CB - P.n_addr)) >> 4;  // 16 slots per wave iteration
+  const uint64_t wgs = (niter + kBigBlock / 64 - 1) / (kBigBlock / 64);
+  const unsigned grid = (unsigned)std::min<uint64_t>(wgs, 2048);
+  const MfmaRoles ro = P.ro;
+  if (P.nt)
+    HQ_LAUNCH(c, (apply_mfma_big_kernel<T, KBITS, VMASK, true, kBigBlock>), dim3(grid), dim3(kBigBlock), lds, re, im, dA, ro, niter);
+  else
+    HQ_LAUNCH(c, (apply_mfma_big_kernel<T, KBITS, VMASK, false, kBigBlock>), dim3(grid), dim3(kBigBlock), lds, re, im, dA, ro, niter);
+  return 0;
+}
+
+template <typename T>
+static int launch_mfma_big(Context& c, T* re, T* im, const T* A, const MfmaPlan<T>& P, unsigned n) {
+  constexpr unsigned CB = Vec<T>::VB;
+  int rc = -1;
+  switch (P.kbits * 4 + P.vmask) {
+    case 24: rc = launch_mfma_big_kv<T, 6, 0>(c, re, im, A, P, n); break;
+    case 25: rc = launch_mfma_big_kv<T, 6, 1>(c, re, im, A, P, n); break;
+    case 28: rc = launch_mfma_big_kv<T, 7, 0>(c, re, im, A, P, n); break;
+    case 29: rc = launch_mfma_big_kv<T, 7, 1>(c, re, im, A, P, n); break;
+    default:
+      if constexpr (CB == 2) {
+        switch (P.kbits * 4 + P.vmask) {
+          case 26: rc = launch_mfma_big_kv<T, 6, 2>(c, re, im, A, P, n); break;
+          case 27: rc = launch_mfma_big_kv<T, 6, 3>(c, re, im, A, P, n); break;
+          case 30: rc = launch_mfma_big_kv<T, 7, 2>(c, re, im, A, P, n); break;
+          case 31: rc = launch_mfma_big_kv<T, 7, 3>(c, re, im, A, P, n); break;
+          default: break;
+        }
+      }
+  }
+  if (rc < 0) return fail("mfma: bad plan");
+  if (rc) return rc;
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "mfma";
+  c.last_desc = std::string("apply_mfma_big_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(P.kbits) + ", " + std::to_string(P.vmask) + ", " + (P.nt ? "true" : "false") + ", " +
+                std::to_string(kBigBlock) + ">";
+  return 0;
+}
+
 template <typename T>
 static int launch_mfma(Context& c, T* re, T* im, const MfmaPlan<T>& P, unsigned n) {
   constexpr unsigned CB = Vec<T>::VB;
   void* dA = nullptr;
   if (arena_upload(c, P.A.data(), P.A.size() * sizeof(T), &dA)) return 1;
+  if (P.kbits >= 6) return launch_mfma_big<T>(c, re, im, (const T*)dA, P, n);
   const uint64_t nslots = 1ull << (n - CB - P.n_addr);
   const uint64_t nblocks64 = nslots / ((uint64_t)P.ilp * 64);
   if (nblocks64 == 0 || nblocks64 > 0x7fffffffull) return fail("mfma: grid out of range");
@@ -629,7 +693,7 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
   const bool can_generic = (n - k) >= 2 && k <= kMaxK;
   MfmaPlan<T> plan;
   bool can_mfma = false;
-  if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && k <= 4) can_mfma = plan_mfma<T>(c, U, pos, n, k, plan);
+  if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && k <= 6) can_mfma = plan_mfma<T>(c, U, pos, n, k, plan);
   auto run_mfma = [&]() -> int { return launch_mfma<T>(c, re, im, plan, n); };
   switch (c.mode) {
     case Mode::Direct:
@@ -643,6 +707,9 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
       break;
     case Mode::Naive:
       return launch_naive<T>(c, re, im, U, pos, n, k);
+    case Mode::Tile:
+      if (mfma_tile_ok<T>(n, k)) return launch_mfma_tile<T>(c, re, im, U, pos, n, k);
+      break;
     case Mode::Auto:
       break;
   }
@@ -1304,6 +1371,7 @@ int hq_set_apply_mode(const char* name) {
   else if (s == "mfma") c.mode = hq::Mode::Mfma;
   else if (s == "generic") c.mode = hq::Mode::Generic;
   else if (s == "naive") c.mode = hq::Mode::Naive;
+  else if (s == "tile") c.mode = hq::Mode::Tile;
   else if (s == "nt=1") c.nontemporal = 1;
   else if (s == "nt=0") c.nontemporal = 0;
   else if (s == "nt=auto") c.nontemporal = -1;

@@ -177,10 +177,10 @@ apply_direct_kernel(T* __restrict__ re, T* __restrict__ im, const GateArg<T, K> 
 // builds the A-operand table A[row-block][step][lane].
 // ---------------------------------------------------------------------------------
 struct MfmaRoles {
-  unsigned pos[4];    // vec positions (index bit - #component bits) of all address digits, ascending; 63 = unused
+  unsigned pos[6];    // vec positions (index bit - #component bits) of all address digits, ascending; 63 = unused
   unsigned q_off[2];  // vec offset carried by q bit b (0 if that digit is the plane)
   int q_plane;        // q bit that selects the plane, -1 if the plane is a reg digit
-  unsigned r_off[3];  // vec offset carried by reg digit b (0 if plane)
+  unsigned r_off[5];  // vec offset carried by reg digit b (0 if plane)
   int r_plane;        // reg digit that selects the plane, -1 if the plane is a q digit
 };
 
@@ -281,6 +281,116 @@ apply_mfma_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
       }
       if (NT) __builtin_nontemporal_store(y, ptr[i][ld]);
       else *ptr[i][ld] = y;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// k = 5, 6 with the same role scheme (KBITS = 6, 7).  The A-operand table no longer fits
+// in registers (k = 6: 8 row-blocks x 32 steps), so a workgroup stages it ONCE in LDS
+// (16 / 64 KiB f32, 32 / 128 KiB f64) and loops over wave iterations (grid-stride);
+// per MFMA group one conflict-free ds_read_b128 fetches 4 (f32) / 2 (f64) consecutive
+// steps.  Column blocks (free vector components) are processed one after the other and
+// each result overwrites the input component it replaces (dead by then), so the register
+// budget is the 2^NR loaded vectors + one set of accumulators.  Targets in index bits 0/1
+// are component digits exactly as for k <= 4: every access stays a 16-byte vector of a
+// contiguous run, whatever the positions.
+//   table layout: A4[(rb * NSTEP/G + s/G) * 64 + lane][s % G], G = 16 / sizeof(T).
+// ---------------------------------------------------------------------------------
+template <typename T, int KBITS, int VMASK, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ A,
+                      const MfmaRoles ro, const uint64_t niter) {
+  using V = typename Vec<T>::type;
+  using Acc = typename Mfma<T>::acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hq_big_smem[];
+  constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB, G = 16 / (int)sizeof(T);
+  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR, NA = KBITS - 1 - KV;
+  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS, NG = NSTEP / G;
+  constexpr int FMASK = ~VMASK & (NCOMP - 1);
+  V* __restrict__ As = reinterpret_cast<V*>(hq_big_smem);
+  {
+    const V* __restrict__ Ag = reinterpret_cast<const V*>(A);
+    for (int e = threadIdx.x; e < NRB * NG * 64; e += BLOCK) As[e] = Ag[e];
+  }
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned q = lane >> 4, j = lane & 15;
+  V* __restrict__ pre = reinterpret_cast<V*>(re);
+  V* __restrict__ pim = reinterpret_cast<V*>(im);
+  const uint64_t lane_off = ((q & 1) ? (uint64_t)ro.q_off[0] : 0ull) | ((q & 2) ? (uint64_t)ro.q_off[1] : 0ull);
+  const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
+  const V* __restrict__ Al = As + lane;
+  // address = per-lane plane base + (slot | uniform digit offset) + uniform plane step: only
+  // ONE per-lane 64-bit base stays live (2^NR hoisted per-load bases would spill for k = 6)
+  V* const base0 = lane_plane ? pim : pre;
+  const int64_t plane_step = pim - pre;
+  for (uint64_t it = (uint64_t)blockIdx.x * (BLOCK / 64) + wave; it < niter; it += (uint64_t)gridDim.x * (BLOCK / 64)) {
+    uint64_t v = it * 16 + j;
+#pragma unroll
+    for (int m = 0; m < NA; ++m) {
+      const uint64_t lo = (1ull << ro.pos[m]) - 1;
+      v = ((v & ~lo) << 1) | (v & lo);
+    }
+    v |= lane_off;
+    int64_t step_it = plane_step;
+    asm volatile("" : "+s"(step_it));  // not loop-invariant for the optimiser: no hoisted per-load bases
+    V x[NL];
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      uint64_t o = 0;
+      unsigned pl = 0;
+#pragma unroll
+      for (int b = 0; b < NR; ++b)
+        if ((ld >> b) & 1) { o |= ro.r_off[b]; pl |= (ro.r_plane == b) ? 1u : 0u; }
+      V* ptr = base0 + (v | o) + (pl ? step_it : (int64_t)0);
+      x[ld] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+    }
+#pragma unroll
+    for (int cf = 0; cf < NCB; ++cf) {
+      Acc acc[NRB];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) acc[rb] = Acc{0, 0, 0, 0};
+#pragma unroll
+      for (int sg = 0; sg < NG; ++sg) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+          const V a4 = Al[(rb * NG + sg) * 64];
+#pragma unroll
+          for (int t = 0; t < G; ++t) {
+            const int s = sg * G + t;
+            const int ck = s & ((1 << KV) - 1), ld = s >> KV;
+            const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+            acc[rb] = Mfma<T>::run(a4[t], x[ld][comp], acc[rb]);
+          }
+        }
+        // keep the scheduler from hoisting the LDS reads of many step groups (k = 6 would spill)
+        if (KBITS >= 7) __builtin_amdgcn_sched_barrier(0);
+      }
+      // the inputs of this column block are dead: overwrite them with its results
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld)
+#pragma unroll
+        for (int ck = 0; ck < (1 << KV); ++ck) {
+          const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+          const int so = ck | (ld << KV);
+          x[ld][comp] = acc[so >> 2][so & 3];
+        }
+    }
+    // recompute the addresses for the stores (opaque copy of v: otherwise 2^NR address pairs
+    // stay live across the whole MFMA phase and the k = 6 variants spill)
+    uint64_t vs = v;
+    asm volatile("" : "+v"(vs));
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      uint64_t o = 0;
+      unsigned pl = 0;
+#pragma unroll
+      for (int b = 0; b < NR; ++b)
+        if ((ld >> b) & 1) { o |= ro.r_off[b]; pl |= (ro.r_plane == b) ? 1u : 0u; }
+      V* ptr = base0 + (vs | o) + (pl ? step_it : (int64_t)0);
+      if (NT) __builtin_nontemporal_store(x[ld], ptr);
+      else *ptr = x[ld];
     }
   }
 }

@@ -79,10 +79,11 @@ def test_apply_U_matches_oracle(torch_cuda, oracle_port, ft, k):
         gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
         err = _relerr(gr, gi, orr, oi)
         assert err <= TOL[ft], (ft, k, pos, kern, err)
-        if k <= 4:
-            assert kern == 'mfma', kern  # matrix-core path (f32 and f64), any target position
-        else:
-            assert kern == 'mfma_tile', kern  # k = 5, 6: LDS-staged tile GEMM on the matrix cores
+        assert kern == 'mfma', kern  # matrix-core role kernels (f32 and f64), any target position, k <= 6
+        if k >= 5:  # the LDS-staged tile GEMM (second implementation for k = 5, 6)
+            gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos, mode='tile')
+            assert kern == 'mfma_tile', kern
+            assert _relerr(gr, gi, orr, oi) <= TOL[ft], (ft, k, pos, kern)
 
 
 @pytest.mark.parametrize('ft', ['float32', 'float64'])
@@ -109,9 +110,30 @@ def test_apply_U_mfma_kernels(torch_cuda, oracle_port, ft):
             gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos, mode='mfma')
             assert kern == 'mfma', (kern, k, pos)
             assert _relerr(gr, gi, orr, oi) <= TOL[ft], (k, pos)
+    # k = 5, 6 (apply_mfma_big_kernel: A operands through LDS, grid-stride): every component /
+    # lane / high-bit role combination, unsorted targets, n large enough for several workgroups
+    big = {
+        5: [[0, 1, 2, 3, 4], [4, 3, 2, 1, 0], [0, 1, 9, 13, 17], [1, 2, 3, 4, 5], [0, 5, 6, 7, 8], [2, 3, 4, 5, 6],
+            [6, 2, 5, 3, 4], [7, 8, 9, 10, 11], [13, 14, 15, 16, 17], [2, 9, 13, 16, 17], [17, 0, 8, 3, 12], [1, 6, 11, 16, 4]],
+        6: [[0, 1, 2, 3, 4, 5], [5, 4, 3, 2, 1, 0], [0, 1, 8, 11, 14, 17], [1, 2, 3, 4, 5, 6], [0, 3, 6, 9, 12, 15],
+            [2, 3, 4, 5, 6, 7], [7, 3, 6, 2, 5, 4], [8, 9, 10, 11, 12, 13], [12, 13, 14, 15, 16, 17], [2, 5, 9, 13, 16, 17],
+            [17, 0, 8, 3, 12, 1], [1, 6, 11, 16, 4, 9]],
+    }
+    for nn in (18, 21):
+        for k, plist in big.items():
+            for pos in plist:
+                pos = [p if p < 12 else p + (nn - 18) for p in pos]
+                re, im = _rand_state(rng, nn, ft)
+                U = _rand_U(rng, k)
+                orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+                gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos, mode='mfma')
+                assert kern == 'mfma', (kern, k, pos)
+                assert _relerr(gr, gi, orr, oi) <= TOL[ft], (nn, k, pos)
     # smallest states the matrix-core path accepts, and the fallback below that
-    for nn in (10, 11, 12, 13):
-        for k in (1, 2, 3, 4):
+    for nn in (8, 9, 10, 11, 12, 13):
+        for k in (1, 2, 3, 4, 5, 6):
+            if k > nn - 2:
+                continue
             pos = rng.permutation(nn)[:k]
             re, im = _rand_state(rng, nn, ft)
             U = _rand_U(rng, k)

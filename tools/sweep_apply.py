@@ -48,7 +48,8 @@ def timeit(pos, mode, reps=8):
 H = n - 1
 cases = []
 for pos in ([8, 9, 10, 11, 12], [3, 9, 14, 20, 25], [0, 1, 2, 3, 4], [2, 3, 4, 5, 6], [0, 7, 13, 21, H], [H - 4, H - 3, H - 2, H - 1, H],
-            [8, 9, 10, 11, 12, 13], [1, 5, 9, 14, 20, 25], [0, 1, 2, 3, 4, 5], [H - 5, H - 4, H - 3, H - 2, H - 1, H]):
-    cases += [(pos, 'auto'), (pos, 'generic')]
+            [2, 9, 14, 20, H],
+            [8, 9, 10, 11, 12, 13], [1, 5, 9, 14, 20, 25], [2, 3, 4, 5, 6, 7], [3, 9, 14, 18, 22, 26], [0, 1, 2, 3, 4, 5], [H - 5, H - 4, H - 3, H - 2, H - 1, H]):
+    cases += [(pos, 'auto'), (pos, 'auto+nt=0'), (pos, 'auto+nt=1'), (pos, 'tile')]
 for pos, mode in cases:
     timeit(pos, mode)
