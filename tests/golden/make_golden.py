@@ -26,6 +26,9 @@ What is recorded
   e2e_dm_circuit.npz  the same noisy circuit UNFUSED, as data: unitaries, Kraus operators,
                       weights and the reference's superoperator matrices (python
                       make_golden.py dm_circuit).
+  e2e_api.npz         host-level API around the path (python make_golden.py api): prepare_state,
+                      simulate() with mixed initial states / compress 4 and 8, Projection and
+                      Measure gates, expectation_value(), utils.dot(), utils.transpose().
 The import of the reference Python needs stand-ins for three absent third-party modules
 (opt_einsum, more_itertools, numba); none of them is on the evolution-hybridq path except
 numba.vectorize for '+-' initial states.
@@ -299,9 +302,150 @@ def dm_circuit():
     print('e2e_dm_circuit.npz:', kinds)
 
 
+def api_vectors():
+    """e2e_api.npz: outputs of the reference's host-level API around the hot path, as data:
+    prepare_state strings, simulate() with mixed initial states (complex64 compress=4 /
+    complex128 compress=8, non-unitary gates, like tests.py:2335-2369), Projection and Measure
+    functional gates inside and outside simulate(), expectation_value(), utils.dot() through
+    the compiled core (split planes, complex input, swap_back=False) and utils.transpose()."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    import hybridq.circuit.simulation.simulation as sim
+    from hybridq.circuit import Circuit
+    from hybridq.circuit.simulation import expectation_value, prepare_state, simulate
+    from hybridq.extras.random import get_rqc
+    from hybridq.gate import Gate, Measure, Projection
+    from hybridq.utils.dot import dot
+    from hybridq.utils.transpose import transpose
+    assert sim._log2_pack_size == 3, 'reference core not found: set LD_LIBRARY_PATH=oracle/_ref'
+    out = {}
+
+    # ---- prepare_state -----------------------------------------------------------------
+    strings = ['0', '1', '+', '-', '00101', '+++++', '01+-0', '-+10+-', '1-', '--+0110+']
+    out['ps_strings'] = np.array(strings)
+    for i, st in enumerate(strings):
+        out[f'ps_{i}'] = np.asarray(prepare_state(st, complex_type='complex128')).reshape(-1)
+
+    def dump_circuit(c, qubits, tag):
+        mats = [np.asarray(g.matrix(), dtype=np.complex128) for g in c]
+        out[f'{tag}_n_gates'] = len(mats)
+        for i, (U, g) in enumerate(zip(mats, c)):
+            out[f'{tag}_U{i}'] = U
+            out[f'{tag}_q{i}'] = np.asarray([qubits.index(q) for q in g.qubits], dtype=np.int32)
+
+    # ---- simulate: mixed initial state, non-unitary gates, compress 4 / 8 -------------------
+    np.random.seed(2024)
+    n = 12
+    c = get_rqc(n, 150, use_random_indexes=False, use_unitary_only=False)
+    qubits = c.all_qubits()
+    assert qubits == list(range(n))
+    init = ''.join(np.random.choice(list('01'), size=3)) + ''.join(np.random.choice(list('01+-'), size=n - 3))
+    dump_circuit(c, qubits, 'sim')
+    out['sim_init'] = np.array(init)
+    out['sim_psi64'] = simulate(c, initial_state=init, optimize='evolution-hybridq', complex_type='complex64',
+                                compress=4, simplify=False, remove_id_gates=False, verbose=False).reshape(-1)
+    out['sim_psi128'] = simulate(c, initial_state=init, optimize='evolution-hybridq', complex_type='complex128',
+                                 compress=8, simplify=False, remove_id_gates=False, verbose=False).reshape(-1)
+
+    # ---- Projection / Measure on a raw state (tests.py:948-1008, :819-945) -------------------
+    np.random.seed(77)
+    n = 10
+    r = (np.random.random((2,) * n) + 1).astype('complex64') * np.exp(1j * np.random.random((2,) * n)).astype('complex64')
+    order = tuple(int(x) for x in np.random.permutation(n) * 7 - 20)  # arbitrary integer labels
+    out['fg_state'] = r.reshape(-1)
+    out['fg_order'] = np.asarray(order, dtype=np.int64)
+    pq = [order[4], order[0], order[7]]
+    out['proj_qubits'] = np.asarray(pq, dtype=np.int64)
+    out['proj_string'] = np.array('101')
+    P = Projection(state='101', qubits=pq)
+    out['proj_raw'] = np.asarray(P(np.array(r), order, renormalize=False)[0]).reshape(-1)
+    out['proj_norm'] = np.asarray(P(np.array(r), order, renormalize=True)[0]).reshape(-1)
+    mq = [order[2], order[9], order[5], order[1]]
+    out['meas_qubits'] = np.asarray(mq, dtype=np.int64)
+    M = Measure(qubits=mq)
+    out['meas_probs'] = np.asarray(M(np.array(r / np.linalg.norm(r.reshape(-1))), order, get_probs_only=True))
+    for j, seed in enumerate((5, 6, 7)):
+        np.random.seed(seed)
+        psi_m, _ = M(np.array(r / np.linalg.norm(r.reshape(-1))), order)
+        out[f'meas_seed{j}'] = seed
+        out[f'meas_state{j}'] = np.asarray(psi_m).reshape(-1)
+
+    # ---- functional gates inside simulate(): projection in the middle of a circuit -----------
+    np.random.seed(99)
+    n = 12
+    c1 = get_rqc(n, 40, use_random_indexes=False)
+    c2 = get_rqc(n, 40, use_random_indexes=False)
+    qubits = list(range(n))
+    dump_circuit(c1, qubits, 'fs1')
+    dump_circuit(c2, qubits, 'fs2')
+    out['fs_proj_qubits'] = np.asarray([3, 8], dtype=np.int64)
+    out['fs_proj_string'] = np.array('01')
+    circ = Circuit(list(c1) + [Projection(state='01', qubits=[3, 8])] + list(c2))
+    out['fs_psi'] = simulate(circ, initial_state='0' * n, optimize='evolution-hybridq', complex_type='complex64',
+                             compress=4, simplify=False, remove_id_gates=False, verbose=False).reshape(-1)
+
+    # ---- expectation_value (tests.py:2374-2456) ------------------------------------------------
+    np.random.seed(314)
+    n = 12  # n <= 10 silently falls back to einsum (simulation.py:400)
+    c = get_rqc(n, 60, use_random_indexes=False)
+    qubits = c.all_qubits()
+    op = get_rqc(2, 3, indexes=qubits[3:5], use_random_indexes=False)
+    dump_circuit(c, qubits, 'ev')
+    dump_circuit(op, qubits, 'evop')
+    psi = simulate(c, initial_state='+' * n, optimize='evolution-hybridq', complex_type='complex64', simplify=False,
+                   remove_id_gates=False, verbose=False)
+    out['ev_state'] = psi.reshape(-1)
+    out['ev_value'] = np.asarray(expectation_value(state=psi, op=op, qubits_order=qubits, remove_id_gates=False,
+                                                   simplify=False, verbose=False), dtype=np.complex128)
+
+    # ---- utils.dot through the compiled core (tests.py:299-391) -------------------------------
+    np.random.seed(2718)
+    n = 12
+    for j, (k, t) in enumerate(((1, 'float32'), (3, 'float32'), (4, 'float64'), (6, 'float32'), (7, 'float64'))):
+        psi = np.random.random((2, 2**n)).astype(t) - 0.5
+        ct = (1j * psi[0][:1]).dtype
+        U = (np.random.random((2**k, 2**k)) + 1j * np.random.random((2**k, 2**k)) - 0.5 - 0.5j).astype(ct)
+        axes_b = np.random.choice(n, size=k, replace=False)
+        res = dot(U, np.reshape(np.array(psi), (2,) * (n + 1)), axes_b=axes_b, b_as_complex_array=True,
+                  raise_if_hcore_fails=True)
+        res_c = dot(U, np.reshape(psi[0] + 1j * psi[1], (2,) * n), axes_b=axes_b, raise_if_hcore_fails=True)
+        nsb, tr = dot(U, np.reshape(np.array(psi), (2,) * (n + 1)), axes_b=axes_b, b_as_complex_array=True,
+                      swap_back=False, raise_if_hcore_fails=True)
+        out[f'dot{j}_psi'] = psi
+        out[f'dot{j}_U'] = U
+        out[f'dot{j}_axes'] = np.asarray(axes_b, dtype=np.int64)
+        out[f'dot{j}_res'] = np.asarray(res).reshape(2, -1)
+        out[f'dot{j}_res_complex'] = np.asarray(res_c).reshape(-1)
+        out[f'dot{j}_noswap'] = np.asarray(nsb).reshape(2, -1)
+        out[f'dot{j}_tr'] = np.asarray([-1] if tr is None else tr, dtype=np.int64)
+    out['dot_n'] = n
+    out['dot_cases'] = 5
+
+    # ---- utils.transpose (tests.py:256-296) -----------------------------------------------------
+    np.random.seed(1618)
+    for j, (n, t) in enumerate(((12, 'float32'), (14, 'int64'), (13, 'uint32'), (12, 'float64'))):
+        a = (np.random.random((2,) * n) * 1000).astype(t)
+        axes = np.arange(n)
+        m = int(np.random.randint(3, 9))
+        axes[-m:] = np.random.permutation(axes[-m:])
+        b = transpose(np.array(a), axes, raise_if_hcore_fails=True)
+        assert np.array_equal(b, np.transpose(a, axes))
+        out[f'tr{j}_a'] = a.reshape(-1)
+        out[f'tr{j}_axes'] = axes.astype(np.int64)
+        out[f'tr{j}_res'] = np.asarray(b).reshape(-1)
+        out[f'tr{j}_n'] = n
+    out['tr_cases'] = 4
+    np.savez_compressed(os.path.join(HERE, 'e2e_api.npz'), **out)
+    print('e2e_api.npz:', len(out), 'arrays;', 'sim init', init, '; ev', out['ev_value'], '; dot tr',
+          [out[f'dot{j}_tr'].tolist() for j in range(5)])
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'dm_circuit':
         dm_circuit()
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'api':
+        api_vectors()
         raise SystemExit(0)
     if os.path.exists('hybridq.so'):
         raise SystemExit('run from a directory that does not contain hybridq.so')

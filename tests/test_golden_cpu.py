@@ -173,3 +173,42 @@ def test_qasm_reader_matches_reference_circuit():
     assert [len(q) for _, q in g] == [1, 2, 1, 2, 1] and np.allclose(g[4][0], np.diag([1, 1j]))
     with pytest.raises(ValueError):
         from_qasm('foo 1')
+
+
+def test_api_golden_oracle_side(oracle_port):
+    """e2e_api.npz (reference host-level API outputs): the oracle's '01+-' initial states are the
+    reference's prepare_state, and the oracle's evolution reproduces the reference's simulate()
+    with a mixed initial state and non-unitary gates (complex128 through compress=8)."""
+    from oracle.evolution import _initial
+    z = gu.load('e2e_api.npz')
+    for i, st in enumerate(str(x) for x in z['ps_strings']):
+        exp = z[f'ps_{i}']
+        n = int(np.log2(exp.size))
+        got = _initial(st, n, np.complex128)
+        assert np.abs(got - exp).max() < 1e-15, st
+    gates = gu.rqc_gates(z, 'sim')
+    init = str(z['sim_init'])
+    n = len(init)
+    psi = oracle.evolve_tensordot(gates, n, initial_state=init)
+    assert np.abs(psi - z['sim_psi128']).max() / np.abs(psi).max() < 1e-12
+    got, _ = oracle.evolve_reference_protocol(oracle_port, gates, n, initial_state=init, complex_type='complex64')
+    assert np.abs(got - z['sim_psi64']).max() / np.abs(psi).max() < 5e-6
+    # dot(): the recorded results are the plain tensor contraction; swap_back=False + tr is consistent
+    for j in range(int(z['dot_cases'])):
+        n = int(z['dot_n'])
+        psi, U, axes = z[f'dot{j}_psi'], z[f'dot{j}_U'], [int(a) for a in z[f'dot{j}_axes']]
+        k = len(axes)
+        c = (psi[0] + 1j * psi[1]).astype(np.complex128).reshape((2,) * n)
+        exp = np.moveaxis(np.tensordot(U.astype(np.complex128).reshape((2,) * (2 * k)), c,
+                                       axes=(list(range(k, 2 * k)), axes)), list(range(k)), axes).reshape(-1)
+        tol = 1e-5 if psi.dtype == np.float32 else 1e-13
+        scale = np.abs(exp).max()
+        res = z[f'dot{j}_res']
+        assert np.abs(res[0] + 1j * res[1] - exp).max() / scale < tol * 2**k
+        assert np.abs(z[f'dot{j}_res_complex'] - exp).max() / scale < tol * 2**k
+        tr = [int(a) for a in z[f'dot{j}_tr']]
+        ns = z[f'dot{j}_noswap']
+        ns = (ns[0] + 1j * ns[1]).reshape((2,) * n)
+        if tr != [-1]:
+            ns = np.transpose(ns, tr)
+        assert np.abs(ns.reshape(-1) - (res[0] + 1j * res[1])).max() == 0

@@ -107,3 +107,112 @@ def test_dm_front_end(torch_cuda):
     assert abs(np.trace(r).real - 1) < 1e-5 and np.abs(r - r.conj().T).max() < 1e-6
     rho128 = simulate(circuit, initial_state='0' * n, complex_type='complex128').reshape(-1)
     assert np.abs(rho128 - z['rho']).max() / np.abs(z['rho']).max() < 5e-6
+
+
+def test_api_simulate_mixed_initial_state(torch_cuda):
+    """Reference simulate() with a mixed '01+-' initial state and 150 non-unitary gates:
+    complex64/compress=4 and complex128/compress=8 (e2e_api.npz)."""
+    from hybridq_amd.simulation import simulate
+    z = gu.load('e2e_api.npz')
+    gates = gu.rqc_gates(z, 'sim')
+    init = str(z['sim_init'])
+    n = len(init)
+    scale = np.abs(z['sim_psi128']).max()
+    p128 = simulate(gates, initial_state=init, complex_type='complex128', compress=8, qubits=list(range(n)))
+    assert np.abs(p128.reshape(-1) - z['sim_psi128']).max() / scale < 1e-12
+    for kw in (dict(compress=4), dict(compress=0), dict(compress=6), dict(blocked=True)):
+        p64 = simulate(gates, initial_state=init, complex_type='complex64', qubits=list(range(n)), **kw)
+        assert p64.dtype == np.complex64
+        assert np.abs(p64.reshape(-1) - z['sim_psi64']).max() / scale < 5e-6, kw
+        assert np.abs(p64.reshape(-1) - z['sim_psi128']).max() / scale < 5e-6, kw
+
+
+def test_api_projection_and_measure(torch_cuda):
+    """Device-side Projection / Measure == the reference's functional gates on the same raw
+    state with arbitrary integer qubit labels (values recorded from hybridq.gate.Projection /
+    Measure; the sampled outcome follows numpy's global RNG exactly like the reference)."""
+    from hybridq_amd.functional import Measure, Projection
+    from hybridq_amd.simulation import EvolutionState, simulate
+    z = gu.load('e2e_api.npz')
+    order = [int(q) for q in z['fg_order']]
+    n = len(order)
+    r = z['fg_state'].reshape((2,) * n)
+    # axis a of `r` carries label order[a]; EvolutionState wants sorted labels on the axes
+    srt = sorted(order)
+    to_sorted = [order.index(q) for q in srt]
+    back = [srt.index(q) for q in order]
+
+    def state_of(arr):
+        return EvolutionState(srt, complex_type='complex64', initial_state=np.transpose(arr, to_sorted).reshape(-1))
+
+    def result(st):
+        return np.transpose(st.to_complex().cpu().numpy().reshape((2,) * n), back).reshape(-1)
+
+    pq = [int(q) for q in z['proj_qubits']]
+    for renorm, key in ((False, 'proj_raw'), (True, 'proj_norm')):
+        st = state_of(r)
+        Projection(str(z['proj_string']), pq, renormalize=renorm).apply_device(st)
+        exp = z[key]
+        assert np.abs(result(st) - exp).max() / np.abs(exp).max() < 2e-6, key
+    mq = [int(q) for q in z['meas_qubits']]
+    rn = r / np.linalg.norm(r.reshape(-1))
+    st = state_of(rn)
+    probs = Measure(mq).probabilities(st)
+    assert np.abs(probs - z['meas_probs']).max() < 1e-6
+    for j in range(3):
+        st = state_of(rn)
+        np.random.seed(int(z[f'meas_seed{j}']))
+        m = Measure(mq)
+        m.apply_device(st)
+        exp = z[f'meas_state{j}']
+        assert np.abs(result(st) - exp).max() / np.abs(exp).max() < 2e-6, (j, m.outcome)
+    # a Projection in the middle of a circuit run by simulate()
+    n2 = 12
+    g1, g2 = gu.rqc_gates(z, 'fs1'), gu.rqc_gates(z, 'fs2')
+    P = Projection(str(z['fs_proj_string']), [int(q) for q in z['fs_proj_qubits']])
+    for kw in (dict(compress=4), dict(blocked=True)):
+        psi = simulate(g1 + [P] + g2, initial_state='0' * n2, complex_type='complex64', qubits=list(range(n2)), **kw)
+        assert np.abs(psi.reshape(-1) - z['fs_psi']).max() / np.abs(z['fs_psi']).max() < 5e-6, kw
+
+
+def test_api_expectation_value(torch_cuda):
+    from hybridq_amd.simulation import expectation_value, simulate
+    z = gu.load('e2e_api.npz')
+    gates, op = gu.rqc_gates(z, 'ev'), gu.rqc_gates(z, 'evop')
+    n = 12
+    psi = simulate(gates, initial_state='+' * n, complex_type='complex64', qubits=list(range(n)))
+    assert np.abs(psi.reshape(-1) - z['ev_state']).max() / np.abs(z['ev_state']).max() < 5e-6
+    v = expectation_value(z['ev_state'].reshape((2,) * n), op, qubits_order=list(range(n)))
+    assert abs(v - complex(z['ev_value'])) < 2e-6
+    v = expectation_value(psi, op, qubits_order=list(range(n)), complex_type='complex128')
+    assert abs(v - complex(z['ev_value'])) < 5e-6
+
+
+def test_api_dot_and_transpose(torch_cuda):
+    """utils.dot() / utils.transpose() outputs recorded from the reference (compiled core path)."""
+    from hybridq_amd.dot import dot
+    from hybridq_amd.transpose import transpose
+    z = gu.load('e2e_api.npz')
+    n = int(z['dot_n'])
+    for j in range(int(z['dot_cases'])):
+        psi, U, axes = z[f'dot{j}_psi'], z[f'dot{j}_U'], z[f'dot{j}_axes']
+        k = len(axes)
+        tol = (2e-6 if psi.dtype == np.float32 else 1e-13) * 2**k
+        exp = z[f'dot{j}_res']
+        scale = np.abs(exp).max()
+        res = dot(U, np.reshape(np.array(psi), (2,) * (n + 1)), axes_b=axes, b_as_complex_array=True,
+                  raise_if_hcore_fails=True)
+        assert np.abs(np.asarray(res).reshape(2, -1) - exp).max() / scale < tol, j
+        res_c = dot(U, np.reshape(psi[0] + 1j * psi[1], (2,) * n), axes_b=axes, raise_if_hcore_fails=True)
+        assert np.abs(np.asarray(res_c).reshape(-1) - z[f'dot{j}_res_complex']).max() / scale < tol, j
+        nsb, tr = dot(U, np.reshape(np.array(psi), (2,) * (n + 1)), axes_b=axes, b_as_complex_array=True,
+                      swap_back=False, raise_if_hcore_fails=True)
+        nsb = np.asarray(nsb).reshape((2,) + (2,) * n)
+        if tr is not None:
+            nsb = np.stack([transpose(nsb[0], tr), transpose(nsb[1], tr)])
+        assert np.abs(nsb.reshape(2, -1) - exp).max() / scale < tol, j
+    for j in range(int(z['tr_cases'])):
+        nn = int(z[f'tr{j}_n'])
+        a = z[f'tr{j}_a'].reshape((2,) * nn)
+        b = transpose(np.array(a), [int(x) for x in z[f'tr{j}_axes']], raise_if_hcore_fails=True)
+        assert np.array_equal(np.asarray(b).reshape(-1), z[f'tr{j}_res']), j
