@@ -21,7 +21,7 @@ namespace hq {
 // ---------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------
-enum class Mode { Auto, Direct, Mfma, Generic, Naive, Tile };
+enum class Mode { Auto, Direct, Mfma, Generic, Naive, Tile, Gemm };
 
 // A recorded sequence of launches ("compiled circuit"): every matrix / operand table it needs
 // lives in its own device buffer, so replaying it is pure kernel launches -- from a plain loop
@@ -107,6 +107,7 @@ static void read_env(Context& c) {
     else if (s == "generic") c.mode = Mode::Generic;
     else if (s == "naive") c.mode = Mode::Naive;
     else if (s == "tile") c.mode = Mode::Tile;
+    else if (s == "gemm") c.mode = Mode::Gemm;
   }
   if (const char* e = getenv("HQ_NONTEMPORAL")) c.nontemporal = atoi(e) < 0 ? -1 : (atoi(e) != 0);
 }
@@ -599,6 +600,127 @@ static int launch_generic(Context& c, T* re, T* im, const T* U, const unsigned* 
   return 0;
 }
 
+// k = 7..10: tile GEMM on the matrix cores (apply_gemm_kernel)
+template <typename T>
+static bool gemm_ok(unsigned n, unsigned k) {
+  const unsigned tb = sizeof(T) == 4 ? 14 : 13;
+  return k >= 7 && k + 4 <= tb && n >= tb;
+}
+
+template <typename T, int RBW, int CBW>
+static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned* dOff, const GemmArg& a,
+                          uint64_t ntiles) {
+  const size_t lds = (size_t)2 * sizeof(T) << a.tb;
+  static bool attr_done = false;  // under the context mutex
+  if (!attr_done) {
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 1024);
+  HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+  return 0;
+}
+
+template <typename T>
+static int launch_gemm(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n, unsigned k) {
+  constexpr unsigned G = 16 / sizeof(T);
+  const unsigned tb = sizeof(T) == 4 ? 14 : 13;
+  const unsigned D = 1u << k, cbits = tb - k;
+  std::vector<T> Us;
+  unsigned sp[kMaxK];
+  sort_gate<T>(U, pos, k, Us, sp);  // matrix index bit j <-> sp[j], ascending
+  const T* Ur = Us.data();
+  const T* Ui = Us.data() + (size_t)D * D;
+  GemmArg a;
+  memset(&a, 0, sizeof(a));
+  a.tb = tb;
+  a.k = k;
+  uint64_t tmask = 0;
+  for (unsigned j = 0; j < k; ++j) tmask |= 1ull << sp[j];
+  std::vector<unsigned> cpos;
+  for (unsigned p = 0; p < n && cpos.size() < cbits; ++p)
+    if (!((tmask >> p) & 1)) cpos.push_back(p);
+  std::vector<unsigned> all(sp, sp + k);
+  all.insert(all.end(), cpos.begin(), cpos.end());
+  std::sort(all.begin(), all.end());
+  for (unsigned m = 0; m < tb; ++m) a.apos[m] = all[m];
+  auto local = [&](unsigned gpos) { return (unsigned)(std::find(all.begin(), all.end(), gpos) - all.begin()); };
+  std::vector<unsigned> tl(k), cl(cbits);
+  for (unsigned j = 0; j < k; ++j) tl[j] = local(sp[j]);
+  for (unsigned j = 0; j < cbits; ++j) cl[j] = local(cpos[j]);
+  for (int i = 0; i < 4; ++i) { a.tl[i] = tl[i]; a.cl[i] = cl[i]; }
+  // swizzle: a half-wave's B read varies the element bits {tl[0], cl[0..3]}; ds_read_b32/b64
+  // bank = element index mod 32.  Fold those of them that are >= 5 into free bits of [2,5)
+  // (bits 0,1 stay: 16-byte vectors must remain contiguous for the copy phases).
+  {
+    const unsigned lb5[5] = {tl[0], cl[0], cl[1], cl[2], cl[3]};
+    std::vector<unsigned> high, freeb;
+    for (unsigned b : lb5) if (b >= 5) high.push_back(b);
+    for (unsigned b = 2; b < 5; ++b)
+      if (std::find(lb5, lb5 + 5, b) == lb5 + 5) freeb.push_back(b);
+    std::sort(high.begin(), high.end());
+    a.n_sw = (unsigned)std::min(high.size(), freeb.size());
+    for (unsigned i = 0; i < a.n_sw; ++i) { a.sw_src[i] = high[i]; a.sw_dst[i] = freeb[i]; }
+  }
+  auto swz = [&](unsigned e) {
+    for (unsigned i = 0; i < a.n_sw; ++i) e ^= ((e >> a.sw_src[i]) & 1u) << a.sw_dst[i];
+    return e;
+  };
+  auto dep = [](unsigned v, const std::vector<unsigned>& p) {
+    unsigned e = 0;
+    for (size_t i = 0; i < p.size(); ++i) e |= ((v >> i) & 1u) << p[i];
+    return e;
+  };
+  const unsigned D4 = D / 4, NRBT = D / 16, NCB = (1u << cbits) / 16;
+  std::vector<unsigned> offs(D4 + NRBT + NCB);
+  for (unsigned st = 0; st < D4; ++st) offs[st] = swz(dep(st << 2, tl));
+  for (unsigned rb = 0; rb < NRBT; ++rb) offs[D4 + rb] = swz(dep(rb << 4, tl));
+  for (unsigned cb = 0; cb < NCB; ++cb) offs[D4 + NRBT + cb] = swz(dep(cb << 4, cl));
+  // A-operand table: [row block][step group][Ur | Ui][lane][G]: lane (i = lane & 15, q = lane >> 4)
+  // holds M[16 rb + i][4 (G sg + s) + q]
+  a.nsg = D4 / G;
+  std::vector<T> A((size_t)2 * D * D);
+  for (unsigned rb = 0; rb < NRBT; ++rb)
+    for (unsigned sg = 0; sg < a.nsg; ++sg)
+      for (unsigned lane = 0; lane < 64; ++lane) {
+        const unsigned row = rb * 16 + (lane & 15);
+        for (unsigned s2 = 0; s2 < G; ++s2) {
+          const unsigned t = 4 * (sg * G + s2) + (lane >> 4);
+          const size_t o = ((((size_t)rb * a.nsg + sg) * 2) * 64 + lane) * G + s2;
+          A[o] = Ur[(size_t)row * D + t];
+          A[o + (size_t)64 * G] = Ui[(size_t)row * D + t];
+        }
+      }
+  void* dA = nullptr;
+  void* dO = nullptr;
+  if (arena_upload(c, A.data(), A.size() * sizeof(T), &dA)) return 1;
+  if (arena_upload(c, offs.data(), offs.size() * sizeof(unsigned), &dO)) return 1;
+  const uint64_t ntiles = 1ull << (n - tb);
+  // 64 (f32) / 32 (f64) output blocks per tile over 8 waves: wave = RBW x CBW blocks
+  const unsigned per_wave = (NRBT * NCB) / 8;
+  const unsigned cbw = std::min(NCB, 4u), rbw = per_wave / cbw;
+  int rc = -1;
+  const T* Ap = (const T*)dA;
+  const unsigned* Op = (const unsigned*)dO;
+  switch (rbw * 16 + cbw) {
+    case 1 * 16 + 4: rc = launch_gemm_rc<T, 1, 4>(c, re, im, Ap, Op, a, ntiles); break;
+    case 2 * 16 + 4: rc = launch_gemm_rc<T, 2, 4>(c, re, im, Ap, Op, a, ntiles); break;
+    case 2 * 16 + 2: rc = launch_gemm_rc<T, 2, 2>(c, re, im, Ap, Op, a, ntiles); break;
+    case 4 * 16 + 2: rc = launch_gemm_rc<T, 4, 2>(c, re, im, Ap, Op, a, ntiles); break;
+    case 4 * 16 + 1: rc = launch_gemm_rc<T, 4, 1>(c, re, im, Ap, Op, a, ntiles); break;
+    case 8 * 16 + 1: rc = launch_gemm_rc<T, 8, 1>(c, re, im, Ap, Op, a, ntiles); break;
+    default: break;
+  }
+  if (rc < 0) return fail("gemm: unsupported shape");
+  if (rc) return rc;
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "gemm";
+  c.last_desc = std::string("apply_gemm_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(rbw) + ", " + std::to_string(cbw) + "> k=" + std::to_string(k);
+  return 0;
+}
+
 // k = 5, 6: LDS-staged tile GEMM on the matrix cores (apply_mfma_tile_kernel)
 template <typename T>
 static bool mfma_tile_ok(unsigned n, unsigned k) {
@@ -710,6 +832,9 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
     case Mode::Tile:
       if (mfma_tile_ok<T>(n, k)) return launch_mfma_tile<T>(c, re, im, U, pos, n, k);
       break;
+    case Mode::Gemm:
+      if (gemm_ok<T>(n, k)) return launch_gemm<T>(c, re, im, U, pos, n, k);
+      break;
     case Mode::Auto:
       break;
   }
@@ -717,6 +842,8 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
   if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
   if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && mfma_tile_ok<T>(n, k))
     return launch_mfma_tile<T>(c, re, im, U, pos, n, k);
+  if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && gemm_ok<T>(n, k))
+    return launch_gemm<T>(c, re, im, U, pos, n, k);
   if (can_generic) return launch_generic<T>(c, re, im, U, pos, n, k);
   return launch_naive<T>(c, re, im, U, pos, n, k);
 }
@@ -1372,6 +1499,7 @@ int hq_set_apply_mode(const char* name) {
   else if (s == "generic") c.mode = hq::Mode::Generic;
   else if (s == "naive") c.mode = hq::Mode::Naive;
   else if (s == "tile") c.mode = hq::Mode::Tile;
+  else if (s == "gemm") c.mode = hq::Mode::Gemm;
   else if (s == "nt=1") c.nontemporal = 1;
   else if (s == "nt=0") c.nontemporal = 0;
   else if (s == "nt=auto") c.nontemporal = -1;

@@ -575,6 +575,145 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 // ---------------------------------------------------------------------------------
 constexpr int kMaxK = 10;
 constexpr int kTileBits = 12;
+// ---------------------------------------------------------------------------------
+// k = 7..10 on the matrix cores: apply_gemm_kernel (reference: the runtime-k loop U.h:123-202).
+//
+// A workgroup (8 waves) owns a tile of 2^TB amplitudes (TB = 14 f32 / 13 f64: both planes =
+// 128 KiB of LDS) spanned by the k targets + the lowest TB-k non-target bits ("columns",
+// always including index bits 0/1 so that every HBM access is a 16-byte vector of a
+// contiguous run).  The tile is the B operand X[2^k rows][C columns] of a complex GEMM
+// out = U . X, done as 4 real MFMA streams (Ur.xr, -Ui.xi -> re; Ui.xr, Ur.xi -> im; the minus
+// sign is applied to the B register).  Wave (wr, wc) accumulates RBW x CBW 16x16 blocks of the
+// output in registers (64 accumulator VGPRs for every k); A operands (its own rows of Ur, Ui)
+// come straight from global/L2 as one 16-byte load per 4 (f32) / 2 (f64) K-steps from a table
+// the host lays out in operand order; B operands are one ds_read_b32/b64 per K-step and column
+// block.  LDS holds the tile in its natural tile-local order with an XOR swizzle chosen by
+// the host per gate so that the B reads of a half-wave hit 32 distinct banks whatever the
+// target positions.  After the K loop the results replace the tile in LDS and stream back.
+// ---------------------------------------------------------------------------------
+constexpr int kGemmBlock = 512;
+constexpr int kGemmMaxTileBits = 14;
+struct GemmArg {
+  unsigned tb, k;                    // tile bits, target bits
+  unsigned apos[kGemmMaxTileBits];   // global index positions of the tile-local bits, ascending
+  unsigned tl[4], cl[4];             // tile-local bit of the 4 lowest target / column digits
+  unsigned n_sw, sw_src[4], sw_dst[4];  // LDS swizzle: element bit src is XORed into bit dst
+  unsigned nsg;                      // A-load groups = 2^k / (4 G), G = 16 / sizeof(T)
+};
+
+template <typename T, int RBW, int CBW>
+__global__ void __launch_bounds__(kGemmBlock)
+apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ Atab,
+                  const unsigned* __restrict__ offs, const GemmArg a, const uint64_t ntiles) {
+  using V = typename Vec<T>::type;
+  using Acc = typename Mfma<T>::acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hq_gemm_smem[];
+  constexpr int CB = Vec<T>::VB, G = 16 / (int)sizeof(T);
+  T* __restrict__ xr = reinterpret_cast<T*>(hq_gemm_smem);
+  T* __restrict__ xi = xr + ((size_t)1 << a.tb);
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned q = lane >> 4, j = lane & 15;
+  const unsigned D4 = (1u << a.k) >> 2, NRBT = (1u << a.k) >> 4, NCB = (1u << (a.tb - a.k)) >> 4;
+  const unsigned WC = NCB / CBW, wr = wave / WC, wc = wave % WC;
+  const unsigned* __restrict__ toff = offs;           // [D4]   swizzled offset of K-step (t = 4 step)
+  const unsigned* __restrict__ rboff = offs + D4;     // [NRBT] ... of output row block (t = 16 rb)
+  const unsigned* __restrict__ coff = rboff + NRBT;   // [NCB]  ... of column block (col = 16 cb)
+  auto swz = [&](unsigned e) {
+    for (unsigned i = 0; i < a.n_sw; ++i) e ^= ((e >> a.sw_src[i]) & 1u) << a.sw_dst[i];
+    return e;
+  };
+  auto dep4 = [](unsigned v, const unsigned* p) {
+    return ((v & 1u) << p[0]) | (((v >> 1) & 1u) << p[1]) | (((v >> 2) & 1u) << p[2]) | (((v >> 3) & 1u) << p[3]);
+  };
+  const unsigned colpart = dep4(j, a.cl);
+  unsigned lane_cb[CBW];  // B operand: row digits 0,1 = q, column digits 0..3 = j
+  {
+    const unsigned lb = swz(((q & 1u) << a.tl[0]) | ((q >> 1) << a.tl[1]) | colpart);
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) lane_cb[c] = lb ^ coff[wc * CBW + c];
+  }
+  unsigned lane_w[4];  // D operand register r: row 4q+r (f32 MFMA) / q+4r (f64 MFMA) of the block
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned rowin = sizeof(T) == 4 ? (4 * q + r) : (q + 4 * r);
+    lane_w[r] = swz(dep4(rowin, a.tl) | colpart);
+  }
+  V* __restrict__ pre = reinterpret_cast<V*>(re);
+  V* __restrict__ pim = reinterpret_cast<V*>(im);
+  const unsigned nvec = 1u << (a.tb - CB);
+  const V* __restrict__ Av = reinterpret_cast<const V*>(Atab) + lane;
+
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint64_t base = tile;  // vec index with zeros at the tile's (non-component) positions
+    for (unsigned m = CB; m < a.tb; ++m) {
+      const uint64_t lo = (1ull << (a.apos[m] - CB)) - 1;
+      base = ((base & ~lo) << 1) | (base & lo);
+    }
+    for (unsigned v = tid; v < nvec; v += kGemmBlock) {
+      uint64_t g = base;
+      for (unsigned m = CB; m < a.tb; ++m) g |= (uint64_t)((v >> (m - CB)) & 1u) << (a.apos[m] - CB);
+      const unsigned slot = swz(v << CB) >> CB;
+      reinterpret_cast<V*>(xr)[slot] = __builtin_nontemporal_load(pre + g);
+      reinterpret_cast<V*>(xi)[slot] = __builtin_nontemporal_load(pim + g);
+    }
+    __syncthreads();
+    Acc accr[RBW][CBW], acci[RBW][CBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) { accr[rb][c] = Acc{0, 0, 0, 0}; acci[rb][c] = Acc{0, 0, 0, 0}; }
+    for (unsigned sg = 0; sg < a.nsg; ++sg) {
+      V ur[RBW], ui[RBW];
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb) {
+        const V* __restrict__ pA = Av + ((size_t)((wr * RBW + rb) * a.nsg + sg) * 2) * 64;
+        ur[rb] = pA[0];
+        ui[rb] = pA[64];
+      }
+#pragma unroll
+      for (int s = 0; s < G; ++s) {
+        const unsigned to = toff[sg * G + s];
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+          const unsigned e = lane_cb[c] ^ to;
+          const T br = xr[e], bi = xi[e], nbi = -bi;
+#pragma unroll
+          for (int rb = 0; rb < RBW; ++rb) accr[rb][c] = Mfma<T>::run(ur[rb][s], br, accr[rb][c]);
+#pragma unroll
+          for (int rb = 0; rb < RBW; ++rb) acci[rb][c] = Mfma<T>::run(ui[rb][s], br, acci[rb][c]);
+#pragma unroll
+          for (int rb = 0; rb < RBW; ++rb) accr[rb][c] = Mfma<T>::run(ui[rb][s], nbi, accr[rb][c]);
+#pragma unroll
+          for (int rb = 0; rb < RBW; ++rb) acci[rb][c] = Mfma<T>::run(ur[rb][s], bi, acci[rb][c]);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading the tile: replace it with the results
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+      const unsigned ro = rboff[wr * RBW + rb];
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) {
+        const unsigned rc = ro ^ coff[wc * CBW + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          xr[lane_w[r] ^ rc] = accr[rb][c][r];
+          xi[lane_w[r] ^ rc] = acci[rb][c][r];
+        }
+      }
+    }
+    __syncthreads();
+    for (unsigned v = tid; v < nvec; v += kGemmBlock) {
+      uint64_t g = base;
+      for (unsigned m = CB; m < a.tb; ++m) g |= (uint64_t)((v >> (m - CB)) & 1u) << (a.apos[m] - CB);
+      const unsigned slot = swz(v << CB) >> CB;
+      __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[slot], pre + g);
+      __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[slot], pim + g);
+    }
+    __syncthreads();
+  }
+}
+
 
 struct GenArg {
   unsigned k, c;                 // target bits, column bits (c >= 2)

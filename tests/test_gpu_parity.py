@@ -191,6 +191,39 @@ def test_apply_U_large_k(torch_cuda, oracle_port):
         assert _relerr(gr, gi, orr, oi) <= 4 * TOL[ft], (k, kern)
 
 
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+def test_apply_U_gemm_kernel(torch_cuda, oracle_port, ft):
+    """k = 7..10 on the matrix cores (apply_gemm_kernel: LDS tile as B operand, A operands from a
+    host-built table, per-gate LDS swizzle): low / high / scattered / unsorted targets, targets
+    on index bits 0 and 1, several tiles per workgroup, non-unitary U; generic kernel as the
+    second implementation."""
+    ft = np.dtype(ft)
+    rng = np.random.default_rng(707)
+    kmax = 10 if ft == np.dtype('float32') else 9
+    tb = 14 if ft == np.dtype('float32') else 13
+    for n in (tb, tb + 1, tb + 4):
+        for k in range(7, kmax + 1):
+            cases = [list(range(k)), list(range(n - k, n)), list(range(2, 2 + k)),
+                     [int(p) for p in rng.permutation(n)[:k]], [int(p) for p in rng.permutation(n)[:k]],
+                     [1] + list(range(5, 4 + k)), [0] + [int(p) for p in 2 + rng.permutation(n - 2)[:k - 1]]]
+            if n > tb + 1:
+                cases = cases[:1] + cases[3:5]
+            for pos in cases:
+                re, im = _rand_state(rng, n, ft)
+                U = _rand_U(rng, k)
+                orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+                gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
+                assert kern == 'gemm', (kern, n, k, pos)
+                assert _relerr(gr, gi, orr, oi) <= 4 * TOL[ft], (n, k, pos)
+    # below the tile size the LDS-tile VALU kernel takes over; 'generic' can always be forced
+    re, im = _rand_state(rng, 12, ft)
+    U = _rand_U(rng, 7)
+    pos = [int(p) for p in rng.permutation(12)[:7]]
+    orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+    gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
+    assert kern == 'generic' and _relerr(gr, gi, orr, oi) <= 4 * TOL[ft]
+
+
 def test_apply_U_error_codes(torch_cuda):
     import ctypes
     from hybridq_amd import core
