@@ -167,8 +167,20 @@ static int arena_upload(Context& c, const void* host, size_t bytes, void** dev) 
     c.arena_used = 0;
   }
   memcpy(c.arena_host + c.arena_used, host, bytes);
-  HQ_HIP_CHECK(hipMemcpyAsync(c.arena_dev + c.arena_used, c.arena_host + c.arena_used, bytes,
-                              hipMemcpyHostToDevice, c.stream));
+  if (bytes >= (64u << 10)) {
+    // Large tables (k >= 6 operand tables, up to 8 MiB): copied by a kernel that reads the pinned
+    // host arena directly, on the SAME stream.  hipMemcpyAsync would go through an SDMA queue and
+    // the cross-queue dependency costs sporadic ~75 ms host-side stalls on this platform.
+    const size_t n16 = (bytes + 15) / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((n16 + kBlock - 1) / kBlock, 512);
+    hipLaunchKernelGGL(upload_kernel, dim3(grid), dim3(kBlock), 0, c.stream,
+                       reinterpret_cast<uint4*>(c.arena_dev + c.arena_used),
+                       reinterpret_cast<const uint4*>(c.arena_host + c.arena_used), n16);
+    HQ_HIP_CHECK(hipGetLastError());
+  } else {
+    HQ_HIP_CHECK(hipMemcpyAsync(c.arena_dev + c.arena_used, c.arena_host + c.arena_used, bytes,
+                                hipMemcpyHostToDevice, c.stream));
+  }
   *dev = c.arena_dev + c.arena_used;
   c.arena_used += need;
   return 0;

@@ -575,6 +575,12 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 // ---------------------------------------------------------------------------------
 constexpr int kMaxK = 10;
 constexpr int kTileBits = 12;
+// Copy a host-pinned (device-mapped) buffer into device memory in-stream (operand tables).
+__global__ void __launch_bounds__(kBlock)
+upload_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, const size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
+}
+
 // ---------------------------------------------------------------------------------
 // k = 7..10 on the matrix cores: apply_gemm_kernel (reference: the runtime-k loop U.h:123-202).
 //
