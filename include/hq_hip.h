@@ -88,9 +88,11 @@ int hq_set_log2_pack_size(unsigned int v);
 const char *hq_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime failure). */
 int hq_device_count(void);
-/* Kernel variant selection for A/B measurements: name in {"auto","mfma","direct",
- * "generic","naive"} selects the apply_U kernel family (a forced family that cannot run
- * a call falls back to auto); {"nt=auto","nt=0","nt=1"} the non-temporal policy;
+/* Kernel variant selection for A/B measurements: name in {"auto","mfma","direct","tile",
+ * "gemm","generic","naive"} selects the apply_U kernel family -- auto = matrix-core role
+ * kernels for k <= 6, tile GEMM for k = 7..10, VALU kernels below their size limits;
+ * "tile" = LDS tile GEMM for k = 5,6; "direct" = VALU butterflies k <= 3; "generic" = VALU
+ * LDS tile any k (a forced family that cannot run a call falls back to auto); {"nt=auto","nt=0","nt=1"} the non-temporal policy;
  * {"dummy=auto","dummy=comp","dummy=low"} the placement of identity digits in the
  * matrix-core kernel.  Returns 1 for an unknown name. */
 int hq_set_apply_mode(const char *name);
