@@ -1,6 +1,8 @@
 """Developer check: per-call GPU time (events) and wall time of consecutive k=9 calls."""
 import os
 import sys
+
+os.environ.setdefault('OPENBLAS_NUM_THREADS', '8')  # numpy's QR would spin 256 threads into the CFS quota
 import time
 
 import numpy as np

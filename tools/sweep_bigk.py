@@ -3,6 +3,8 @@ Usage on the GPU box: python tools/sweep_bigk.py [n] [dtype] [kmax]"""
 import os
 import sys
 
+os.environ.setdefault('OPENBLAS_NUM_THREADS', '8')  # numpy's QR would spin 256 threads into the CFS quota
+
 import numpy as np
 import torch
 

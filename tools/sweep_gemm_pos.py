@@ -2,6 +2,8 @@
 import os
 import sys
 
+os.environ.setdefault('OPENBLAS_NUM_THREADS', '8')  # numpy's QR would spin 256 threads into the CFS quota
+
 import numpy as np
 import torch
 
