@@ -23,7 +23,32 @@ import os
 import sys
 import time
 
-import numpy as np
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU
+    boxes expose 256 hardware threads but a 16-CPU quota; 256 OpenMP threads on that run the
+    reference 15x SLOWER than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+# numpy's BLAS would otherwise spin one thread per hardware thread (256) into a 16-CPU CFS quota:
+# the kernel then freezes the WHOLE process for the rest of each 100 ms period, GPU issue included
+os.environ.setdefault('OPENBLAS_NUM_THREADS', str(max(1, usable_cpus() // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1'))))))
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -46,26 +71,6 @@ def parse_args():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-events', action='store_true', help='skip per-gate HIP events in the timed region')
     return ap.parse_args()
-
-
-def usable_cpus():
-    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU
-    boxes expose 256 hardware threads but a 16-CPU quota; 256 OpenMP threads on that run the
-    reference 15x SLOWER than 16)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
-        if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        try:
-            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
-            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-            if q > 0:
-                n = min(n, max(1, q // p))
-        except (OSError, ValueError):
-            pass
-    return n
 
 
 def cpu_baseline(gates, n, seconds, complex_type):

@@ -1,7 +1,25 @@
 import os
 import sys
 
-import pytest
+
+def _usable_cpus():
+    """Affinity mask capped by the cgroup CPU quota (GPU boxes: 256 hardware threads, 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# The CPU oracle (OpenMP) and numpy's BLAS would spin one thread per hardware thread; under a CFS
+# quota that freezes the whole process for most of every 100 ms period.  Must precede numpy's import.
+for _var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
+    os.environ.setdefault(_var, str(_usable_cpus()))
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
