@@ -788,3 +788,34 @@ def test_simulation_large_like_reference(torch_cuda, oracle_port, n):
     assert np.abs(p128.reshape(-1) - exp).max() / scale < 1e-12
     assert np.abs(p64.reshape(-1) - exp).max() / scale < 1e-5
     np.testing.assert_allclose(p64.reshape(-1), exp, rtol=1e-3, atol=1e-3 * scale)  # the reference's own bar
+
+
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+def test_apply_U_randomized_differential(torch_cuda, oracle_port, ft):
+    """Randomized differential test: random (n, k, positions, kernel family) against the oracle.
+    Every family either runs the call or falls back to the automatic choice, so each case must
+    match whatever kernel ends up running (seeded: failures are reproducible from the message)."""
+    ft = np.dtype(ft)
+    rng = np.random.default_rng(20240928 if ft == np.dtype('float32') else 20240929)
+    modes = ['auto', 'auto', 'auto', 'mfma', 'direct', 'tile', 'gemm', 'generic']
+    seen = {}
+    for case in range(260):
+        n = int(rng.integers(6, 21))
+        kcap = min(10, n - 2)
+        # bias towards small k (the common case) but cover every k
+        k = int(min(kcap, rng.choice([1, 1, 2, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 10])))
+        if n >= 19 and k >= 9:
+            k = 8  # keep the oracle's share of the run time small
+        pos = [int(p) for p in rng.permutation(n)[:k]]
+        if rng.random() < 0.3:
+            pos = sorted(pos)
+        mode = str(rng.choice(modes))
+        re, im = _rand_state(rng, n, ft)
+        U = _rand_U(rng, k)
+        orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
+        gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos, mode=mode)
+        seen[kern] = seen.get(kern, 0) + 1
+        err = _relerr(gr, gi, orr, oi)
+        assert err <= (4 if k >= 7 else 1) * TOL[ft], (case, n, k, pos, mode, kern, err)
+    # the sample exercised every kernel family
+    assert {'mfma', 'direct', 'mfma_tile', 'gemm', 'generic'} <= set(seen), seen
