@@ -613,10 +613,22 @@ static int launch_generic(Context& c, T* re, T* im, const T* U, const unsigned* 
 }
 
 // k = 7..10: tile GEMM on the matrix cores (apply_gemm_kernel)
+// Tile bits of the GEMM kernel: 128 KiB of LDS (one workgroup per CU) for the largest k, where
+// the U traffic per tile matters; 32-64 KiB for k = 7, 8 (two to four workgroups per CU, whose
+// copy and MFMA phases overlap each other).  HQ_GEMM_TB overrides (experiments).
+template <typename T>
+static unsigned gemm_tile_bits(unsigned k) {
+  static const int forced = getenv("HQ_GEMM_TB") ? atoi(getenv("HQ_GEMM_TB")) : 0;
+  const unsigned big = sizeof(T) == 4 ? 14 : 13;
+  if (forced) return std::min<unsigned>(big, std::max<unsigned>((unsigned)forced, k + 4));
+  // measured at n = 30 / 29 (gpurun_out/sweep_gemm_tb.txt): 32 columns (f32) / 16 columns (f64)
+  return std::min<unsigned>(big, k + (sizeof(T) == 4 ? 5 : 4));
+}
+
 template <typename T>
 static bool gemm_ok(unsigned n, unsigned k) {
-  const unsigned tb = sizeof(T) == 4 ? 14 : 13;
-  return k >= 7 && k + 4 <= tb && n >= tb;
+  const unsigned big = sizeof(T) == 4 ? 14 : 13;
+  return k >= 7 && k + 4 <= big && n >= gemm_tile_bits<T>(k);
 }
 
 template <typename T, int RBW, int CBW>
@@ -626,10 +638,10 @@ static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned*
   static bool attr_done = false;  // under the context mutex
   if (!attr_done) {
     HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_done = true;
   }
-  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 1024);
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 2048);
   HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
   return 0;
 }
@@ -637,7 +649,7 @@ static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned*
 template <typename T>
 static int launch_gemm(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n, unsigned k) {
   constexpr unsigned G = 16 / sizeof(T);
-  const unsigned tb = sizeof(T) == 4 ? 14 : 13;
+  const unsigned tb = gemm_tile_bits<T>(k);
   const unsigned D = 1u << k, cbits = tb - k;
   std::vector<T> Us;
   unsigned sp[kMaxK];
@@ -716,6 +728,9 @@ static int launch_gemm(Context& c, T* re, T* im, const T* U, const unsigned* pos
   const T* Ap = (const T*)dA;
   const unsigned* Op = (const unsigned*)dO;
   switch (rbw * 16 + cbw) {
+    case 1 * 16 + 1: rc = launch_gemm_rc<T, 1, 1>(c, re, im, Ap, Op, a, ntiles); break;
+    case 1 * 16 + 2: rc = launch_gemm_rc<T, 1, 2>(c, re, im, Ap, Op, a, ntiles); break;
+    case 2 * 16 + 1: rc = launch_gemm_rc<T, 2, 1>(c, re, im, Ap, Op, a, ntiles); break;
     case 1 * 16 + 4: rc = launch_gemm_rc<T, 1, 4>(c, re, im, Ap, Op, a, ntiles); break;
     case 2 * 16 + 4: rc = launch_gemm_rc<T, 2, 4>(c, re, im, Ap, Op, a, ntiles); break;
     case 2 * 16 + 2: rc = launch_gemm_rc<T, 2, 2>(c, re, im, Ap, Op, a, ntiles); break;

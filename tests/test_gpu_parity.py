@@ -200,8 +200,8 @@ def test_apply_U_gemm_kernel(torch_cuda, oracle_port, ft):
     ft = np.dtype(ft)
     rng = np.random.default_rng(707)
     kmax = 10 if ft == np.dtype('float32') else 9
-    tb = 14 if ft == np.dtype('float32') else 13
-    for n in (tb, tb + 1, tb + 4):
+    tb = 14 if ft == np.dtype('float32') else 13  # largest tile; k = 7, 8 use smaller ones (more workgroups per CU)
+    for n in (tb - 2, tb, tb + 1, tb + 4):
         for k in range(7, kmax + 1):
             cases = [list(range(k)), list(range(n - k, n)), list(range(2, 2 + k)),
                      [int(p) for p in rng.permutation(n)[:k]], [int(p) for p in rng.permutation(n)[:k]],
@@ -209,16 +209,19 @@ def test_apply_U_gemm_kernel(torch_cuda, oracle_port, ft):
             if n > tb + 1:
                 cases = cases[:1] + cases[3:5]
             for pos in cases:
+                if max(pos) >= n or len(set(pos)) != k:
+                    continue
                 re, im = _rand_state(rng, n, ft)
                 U = _rand_U(rng, k)
                 orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
                 gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
-                assert kern == 'gemm', (kern, n, k, pos)
+                min_n = min(tb, k + (5 if ft == np.dtype('float32') else 4))
+                assert kern == ('gemm' if n >= min_n else 'generic'), (kern, n, k, pos)
                 assert _relerr(gr, gi, orr, oi) <= 4 * TOL[ft], (n, k, pos)
     # below the tile size the LDS-tile VALU kernel takes over; 'generic' can always be forced
-    re, im = _rand_state(rng, 12, ft)
+    re, im = _rand_state(rng, 10, ft)
     U = _rand_U(rng, 7)
-    pos = [int(p) for p in rng.permutation(12)[:7]]
+    pos = [int(p) for p in rng.permutation(10)[:7]]
     orr, oi = _oracle_apply(oracle_port, re, im, U, pos)
     gr, gi, kern = _gpu_apply(torch_cuda, re, im, U, pos)
     assert kern == 'generic' and _relerr(gr, gi, orr, oi) <= 4 * TOL[ft]
