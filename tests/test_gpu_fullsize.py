@@ -112,7 +112,8 @@ def test_beyond_32_bit_indices(torch_cuda):
     before = torch.stack([re[idx], im[idx]]).double().cpu().numpy()
     for mode, pos in (('mfma', [32]), ('mfma', [31, 32]), ('mfma', [2, 32]), ('mfma', [0, 16, 32]),
                       ('mfma', [29, 30, 31, 32]), ('direct', [32]), ('direct', [7, 31, 32]),
-                      ('auto', [3, 9, 28, 31, 32]), ('generic', [30, 32])):
+                      ('auto', [3, 9, 28, 31, 32]), ('auto', [0, 8, 20, 30, 31, 32]),
+                      ('auto', [1, 5, 9, 27, 30, 31, 32]), ('generic', [30, 32])):
         U = haar_unitary(1 << len(pos), rng)
         core.set_apply_mode(mode)
         core.apply_U(re, im, U, pos)
