@@ -667,6 +667,13 @@ def test_simulate_blocked_matches_oracle(torch_cuda, oracle_port):
             err = np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max()
             assert err < 5e-6, (n, opts, err)
             assert info['n_passes'] < len(gates) / 2.5
+    # optimize='evolution-hip' = the same path with blocked=True / compress=5 as defaults
+    for n in (12, 18):
+        g = rqc_1q2q(n, depth=10, seed=11) + random_dense(n, 6, kmax=5, seed=12)
+        psi, info = simulate(g, initial_state='0' * n, optimize='evolution-hip', return_info=True, qubits=list(range(n)))
+        exp = oracle.evolve_tensordot(g, n)
+        assert np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max() < 5e-6
+        assert info['n_passes'] < len(g) / 2
     # every gate is scheduled exactly once and dependencies are kept (pure planner check)
     n = 22
     gates = rqc_1q2q(n, depth=16, seed=6)
