@@ -18,7 +18,8 @@ rng = np.random.default_rng(0)
 core.init_state(planes[0], planes[1], 'plus')
 print('norm2', core.norm2(planes[0], planes[1]))
 for pos in ([12], [3], [0], [12, 20], [2, 3], [0, 15], [10, 15, 20], [10, 14, 18, 22], [0, 9, 15, n - 1],
-            [8, 9, 10, 11, 12], [3, 9, 14, 20, 25, 28]):
+            [8, 9, 10, 11, 12], [0, 1, 9, 14, 20], [3, 9, 14, 20, 25, 28], [2, 5, 9, 12, 17, 21, 26],
+            [0, 4, 8, 11, 13, 19, 22, 27], [1, 3, 6, 10, 12, 16, 20, 24, 28]):
     core.apply_U(planes[0], planes[1], haar_unitary(1 << len(pos), rng), pos)
     print(pos, core.last_kernel_desc())
 core.sync()
