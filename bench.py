@@ -485,6 +485,28 @@ def main():
                                        'inner_gates': stu['inner_gates'], 'ms_per_step': 1e3 * elu,
                                        'gate_apps_per_s': len(gates) / elu,
                                        'amplitudes_per_s': len(gates) / elu * float(1 << n)}
+    if rank == 0 and not sharded_path and not args.no_fused:
+        # one gate of every width on the same resident state (k >= 5 reach the matrix cores through
+        # apply_mfma_big_kernel / apply_gemm_kernel): ms per gate, HBM rate and MFMA rate
+        from hybridq_amd.circuits import haar_unitary
+        rng_k = np.random.default_rng(5)
+        per_k = {}
+        for k in range(1, (10 if args.dtype == 'complex64' else 9) + 1):
+            pos = sorted(int(p) for p in rng_k.permutation(n)[:k])
+            U = np.ascontiguousarray(haar_unitary(1 << k, rng_k), dtype=args.dtype)
+            core.apply_U(state.planes[0], state.planes[1], U, pos, n)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 4 if k <= 8 else 2
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                core.apply_U(state.planes[0], state.planes[1], U, pos, n)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            per_k[str(k)] = {'ms_per_gate': ms, 'kernel': core.last_kernel_desc(), 'positions': pos,
+                             'hbm_GBps': bytes_per_gate / ms / 1e6, 'TFLOPs': 8.0 * (1 << k) * (1 << n) / ms / 1e9}
+        result['per_k'] = per_k
     if rank == 0 and not sharded_path and not args.no_cpu_baseline:
         try:
             result['cpu_baseline'] = cpu_baseline(gates, n, args.cpu_seconds, args.dtype)
