@@ -58,6 +58,8 @@ def evolve_tensordot(gates, n=None, initial_state=None, qubits=None, dtype=np.co
     """Independent evolution: psi <- moveaxis(tensordot(U, psi)) per gate, in `dtype`."""
     qubits = all_qubits(gates, qubits)
     n = len(qubits) if n is None else n
+    if len(qubits) != n:
+        raise ValueError(f'{n} qubits requested but the gates act on {len(qubits)}: pass qubits=[...] explicitly')
     index = {q: i for i, q in enumerate(qubits)}
     psi = _initial(initial_state, n, dtype).reshape((2,) * n)
     for U, qs in gates:
@@ -109,6 +111,8 @@ def evolve_reference_protocol(lib, gates, n=None, initial_state=None, qubits=Non
     ft = np.dtype('float32') if complex_type == np.dtype('complex64') else np.dtype('float64')
     qubits = all_qubits(gates, qubits)
     n = len(qubits) if n is None else n
+    if len(qubits) != n:
+        raise ValueError(f'{n} qubits requested but the gates act on {len(qubits)}: pass qubits=[...] explicitly')
     L = lib.log2_pack_size if log2_pack_size is None else log2_pack_size
 
     if planes is None:
