@@ -1229,9 +1229,16 @@ static int probabilities_entry(const T* re, const T* im, unsigned n, const unsig
   if (get_scratch(c, 1, std::max<size_t>(256, nb * sizeof(double)), &s1)) return 1;
   HQ_HIP_CHECK(hipMemsetAsync(s1, 0, nb * sizeof(double), c.stream));
   const uint64_t size = 1ull << n;
-  const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 8);
-  hipLaunchKernelGGL((probabilities_kernel<T>), dim3(grid), dim3(kBlock), nb * sizeof(double), c.stream, re,
-                     im, size, ba, (double*)s1);
+  constexpr unsigned kChunkBits = Vec<T>::VB + 8 + 6;  // probabilities_stream_kernel
+  if (n >= kChunkBits && kBlock == 256) {
+    const unsigned grid = (unsigned)std::min<uint64_t>(1ull << (n - kChunkBits), 256 * 8);
+    hipLaunchKernelGGL((probabilities_stream_kernel<T>), dim3(grid), dim3(kBlock), nb * sizeof(double), c.stream,
+                       re, im, n, ba, (double*)s1);
+  } else {
+    const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 8);
+    hipLaunchKernelGGL((probabilities_kernel<T>), dim3(grid), dim3(kBlock), nb * sizeof(double), c.stream, re,
+                       im, size, ba, (double*)s1);
+  }
   HQ_HIP_CHECK(hipGetLastError());
   HQ_HIP_CHECK(hipMemcpyAsync(out, s1, nb * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   HQ_HIP_CHECK(hipStreamSynchronize(c.stream));

@@ -1157,6 +1157,89 @@ probabilities_kernel(const T* __restrict__ re, const T* __restrict__ im, const u
     if (bins[i] != 0.0) atomicAdd(&out[i], bins[i]);
 }
 
+// Streaming variant for n >= 16: a workgroup walks chunks of 2^16 amplitudes as 16-byte vectors
+// (index = chunk : it[6 bits] : thread[8 bits] : component[CB bits]).  Measured bits in the
+// component / thread / chunk fields are constant per register, thread or chunk; only measured
+// bits in the 6 `it` bits change inside a chunk, and the loop is ordered so that they form the
+// OUTER loop: a thread sums a whole inner loop in registers and issues one LDS atomic per
+// (outer value, component class) instead of one per amplitude.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+probabilities_stream_kernel(const T* __restrict__ re, const T* __restrict__ im, const unsigned n,
+                            const BitsArg ba, double* __restrict__ out /* 2^k, pre-zeroed */) {
+  using V = typename Vec<T>::type;
+  constexpr unsigned CB = Vec<T>::VB, NC = 1u << CB;
+  constexpr unsigned TB = 8, IB = 6, CHUNK = CB + TB + IB;  // bits of the thread / it fields; 2^CHUNK amplitudes per chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* bins = reinterpret_cast<double*>(smem);
+  const unsigned nb = 1u << ba.k;
+  for (unsigned i = threadIdx.x; i < nb; i += kBlock) bins[i] = 0.0;
+  __syncthreads();
+  // outcome contributions of the fields
+  unsigned comp_t[NC];
+#pragma unroll
+  for (unsigned c = 0; c < NC; ++c) comp_t[c] = 0;
+  unsigned thr_t = 0, it_meas[IB], n_it_meas = 0, it_free[IB], n_it_free = 0, it_out[IB];
+  for (unsigned b = 0; b < IB; ++b) {
+    bool measured = false;
+    for (unsigned j = 0; j < ba.k; ++j)
+      if (ba.pos[j] == CB + TB + b) { it_meas[n_it_meas] = b; it_out[n_it_meas] = j; ++n_it_meas; measured = true; }
+    if (!measured) it_free[n_it_free++] = b;
+  }
+  for (unsigned j = 0; j < ba.k; ++j) {
+    const unsigned p = ba.pos[j];
+    if (p < CB) {
+#pragma unroll
+      for (unsigned c = 0; c < NC; ++c) comp_t[c] |= ((c >> p) & 1u) << j;
+    } else if (p < CB + TB) {
+      thr_t |= ((threadIdx.x >> (p - CB)) & 1u) << j;
+    }
+  }
+  const V* __restrict__ vre = reinterpret_cast<const V*>(re);
+  const V* __restrict__ vim = reinterpret_cast<const V*>(im);
+  const uint64_t nchunks = 1ull << (n - CHUNK);
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    unsigned hi_t = 0;
+    for (unsigned j = 0; j < ba.k; ++j)
+      if (ba.pos[j] >= CHUNK) hi_t |= (unsigned)((chunk >> (ba.pos[j] - CHUNK)) & 1ull) << j;
+    const uint64_t vbase = (chunk << (TB + IB)) + threadIdx.x;
+    for (unsigned om = 0; om < (1u << n_it_meas); ++om) {
+      unsigned it0 = 0, it_t = 0;
+      for (unsigned b = 0; b < n_it_meas; ++b) {
+        it0 |= ((om >> b) & 1u) << it_meas[b];
+        it_t |= ((om >> b) & 1u) << it_out[b];
+      }
+      double acc[NC];
+#pragma unroll
+      for (unsigned c = 0; c < NC; ++c) acc[c] = 0.0;
+      for (unsigned f = 0; f < (1u << n_it_free); ++f) {
+        unsigned it = it0;
+        for (unsigned b = 0; b < n_it_free; ++b) it |= ((f >> b) & 1u) << it_free[b];
+        const V r = __builtin_nontemporal_load(vre + vbase + ((uint64_t)it << TB));
+        const V m = __builtin_nontemporal_load(vim + vbase + ((uint64_t)it << TB));
+#pragma unroll
+        for (unsigned c = 0; c < NC; ++c) acc[c] += (double)r[c] * (double)r[c] + (double)m[c] * (double)m[c];
+      }
+      const unsigned t0 = hi_t | thr_t | it_t;
+      // components that fall into the same outcome are summed first
+#pragma unroll
+      for (unsigned c = 0; c < NC; ++c) {
+        bool first = true;
+        double sum = acc[c];
+#pragma unroll
+        for (unsigned d = 0; d < NC; ++d)
+          if (d != c && comp_t[d] == comp_t[c]) {
+            if (d < c) first = false; else sum += acc[d];
+          }
+        if (first) atomicAdd(&bins[t0 | comp_t[c]], sum);
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < nb; i += kBlock)
+    if (bins[i] != 0.0) atomicAdd(&out[i], bins[i]);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 project_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t size, const uint64_t mask,

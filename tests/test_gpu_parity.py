@@ -829,3 +829,29 @@ def test_apply_U_randomized_differential(torch_cuda, oracle_port, ft):
         assert err <= (4 if k >= 7 else 1) * TOL[ft], (case, n, k, pos, mode, kern, err)
     # the sample exercised every kernel family
     assert {'mfma', 'direct', 'mfma_tile', 'gemm', 'generic'} <= set(seen), seen
+
+
+@pytest.mark.parametrize('ft', ['float32', 'float64'])
+def test_probabilities_stream_kernel(torch_cuda, ft):
+    """hq_probabilities_* at n >= 16 (streaming kernel: per-thread register sums, measured bits
+    in the component / thread / iteration / chunk fields of the index) vs numpy."""
+    from hybridq_amd import core
+    torch = torch_cuda
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(9)
+    ft = np.dtype(ft)
+    for n in (16, 17, 20):
+        re, im = _rand_state(rng, n, ft)
+        p = re.astype(np.float64)**2 + im.astype(np.float64)**2
+        dre, dim_ = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+        cases = [[0], [1], [0, 1], [1, 0], [2], [9], [10], [15], [n - 1], [5, 3], [12, 11, 14], [10, 11, 12, 13, 14, 15],
+                 [0, 4, 12, n - 1], [n - 1, 1, 13, 6], [15, 0, 9, 10, 1], list(range(8)), [n - 1, n - 2, 0],
+                 [int(x) for x in rng.permutation(n)[:7]], [int(x) for x in rng.permutation(n)[:10]]]
+        for pos in cases:
+            got = core.probabilities(dre, dim_, pos, n)
+            x = np.arange(1 << n, dtype=np.int64)
+            t = np.zeros(1 << n, dtype=np.int64)
+            for j, q in enumerate(pos):
+                t |= ((x >> q) & 1) << j
+            exp = np.bincount(t, weights=p, minlength=1 << len(pos))
+            assert np.abs(got - exp).max() / exp.max() < (1e-6 if ft == np.dtype('float32') else 1e-13), (n, pos)
