@@ -708,7 +708,8 @@ def test_compiled_program_matches_oracle(torch_cuda, oracle_port, graph, monkeyp
     monkeypatch.setenv('HQ_PROGRAM_GRAPH', graph)
     core.set_stream(torch.cuda.current_stream().cuda_stream)
     n = 16
-    gates = rqc_1q2q(n, depth=6, seed=41) + random_dense(n, 10, kmax=6, seed=42)
+    gates = rqc_1q2q(n, depth=6, seed=41) + random_dense(n, 10, kmax=6, seed=42) + \
+        [g for g in random_dense(n, 60, kmax=8, seed=43) if len(g[1]) >= 7][:2]  # incl. the LDS-table and GEMM kernels
     one = oracle.evolve_tensordot(gates, n)
     for ct, tol, kw in (('complex64', 5e-6, dict(compress=0)), ('complex64', 5e-6, dict(compress=4)),
                         ('complex64', 5e-6, dict(blocked=True)), ('complex128', 1e-12, dict(compress=4)),
