@@ -486,6 +486,25 @@ def main():
                                        'gate_apps_per_s': len(gates) / elu,
                                        'amplitudes_per_s': len(gates) / elu * float(1 << n)}
     if rank == 0 and not sharded_path and not args.no_fused:
+        # the same 900-gate step through the VALU register-butterfly kernels only (no matrix cores):
+        # north_star asks for MFMA only where the tile update is a genuine GEMM (k >= 4); the role
+        # kernel is the default because it is faster for k <= 3 as well, this is the evidence
+        core.set_apply_mode('direct')
+        try:
+            run_step()
+            barrier()
+            t0d = time.perf_counter()
+            run_step()
+            barrier()
+            eld = time.perf_counter() - t0d
+            kinds = sorted({core.last_kernel()})
+        finally:
+            core.set_apply_mode('auto')
+        result['valu_direct_only'] = {'ms_per_step': 1e3 * eld, 'gate_apps_per_s': len(gates) / eld,
+                                      'amplitudes_per_s': len(gates) / eld * float(1 << n),
+                                      'hbm_frac_of_peak': len(gates) / eld * bytes_per_gate / 1e9 / HBM_PEAK_GBS,
+                                      'last_kernel': kinds[0]}
+    if rank == 0 and not sharded_path and not args.no_fused:
         # one gate of every width on the same resident state (k >= 5 reach the matrix cores through
         # apply_mfma_big_kernel / apply_gemm_kernel): ms per gate, HBM rate and MFMA rate
         from hybridq_amd.circuits import haar_unitary
