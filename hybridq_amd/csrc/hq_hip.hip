@@ -1178,30 +1178,42 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     Up += (size_t)2 << (2 * k);
     pp += k;
   }
-  void *dG = nullptr, *dA = nullptr;
-  if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
-  if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
-  const size_t lds = ((size_t)2 << tb) * sizeof(T);
+  const uint64_t ntiles = 1ull << (n - tb);
+  const size_t tile_bytes = ((size_t)2 << tb) * sizeof(T);
+  const size_t per_cu = std::min<size_t>(std::max<size_t>(1, (160 * 1024) / tile_bytes), 4);
   static bool attr_done = false;
   if (!attr_done) {
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<float, 256>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<float, 512>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<double, 256>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<double, 512>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const void* fns[] = {(const void*)apply_blocked_kernel<float, 256, false>, (const void*)apply_blocked_kernel<float, 512, false>,
+                         (const void*)apply_blocked_kernel<double, 256, false>, (const void*)apply_blocked_kernel<double, 512, false>,
+                         (const void*)apply_blocked_kernel<float, 512, true>, (const void*)apply_blocked_kernel<double, 512, true>};
+    for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  const uint64_t ntiles = 1ull << (n - tb);
-  const size_t per_cu = std::max<size_t>(1, (160 * 1024) / lds);
-  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * std::min<size_t>(per_cu, 4));
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
   static int block_threads = getenv("HQ_BLOCKED_THREADS") ? atoi(getenv("HQ_BLOCKED_THREADS")) : 512;
-  if (block_threads == 256)
-    HQ_LAUNCH(c, (apply_blocked_kernel<T, 256>), dim3(grid), dim3(256), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, ba, ntiles);
-  else
-    HQ_LAUNCH(c, (apply_blocked_kernel<T, 512>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, ba, ntiles);
+  static int a_in_lds = getenv("HQ_BLOCKED_ALDS") ? atoi(getenv("HQ_BLOCKED_ALDS")) : 1;
+  // LDS left per workgroup behind the tile when `per_cu` workgroups share a CU
+  const size_t a_budget = (160 * 1024) / per_cu - tile_bytes > 2048 ? (160 * 1024) / per_cu - tile_bytes - 1024 : 0;
+  // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
+  // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
+  const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) <= a_budget;
+  if (fits) {
+    void *dG = nullptr, *dA = nullptr;
+    if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
+    if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
+    const size_t lds = tile_bytes + Atab.size() * sizeof(T);
+    HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
+              n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+  } else {
+    void *dG = nullptr, *dA = nullptr;
+    if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
+    if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
+    const size_t lds = tile_bytes;
+    if (block_threads == 256)
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 256, false>), dim3(grid), dim3(256), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+    else
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+  }
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "blocked";
   c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +

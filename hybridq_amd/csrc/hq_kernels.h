@@ -511,17 +511,25 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
   }
 }
 
-template <typename T, int BLOCK>
+// ALDS: the A-operand tables of all gates of the pass (a_elems elements) are staged once per
+// (persistent) workgroup in LDS behind the tile; a table read from global memory puts an L2 round
+// trip (~1500 clk, as long as the gate's MFMAs) in front of every gate of every tile.
+template <typename T, int BLOCK, bool ALDS>
 __global__ void __launch_bounds__(BLOCK)
 apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* __restrict__ gates,
-                     const unsigned ngates, const T* __restrict__ Atab, const BlockedArg ba,
-                     const uint64_t ntiles) {
+                     const unsigned ngates, const T* __restrict__ Atab, const unsigned a_elems,
+                     const BlockedArg ba, const uint64_t ntiles) {
   using V = typename Vec<T>::type;
   constexpr unsigned CB = Vec<T>::VB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xr = reinterpret_cast<T*>(smem);
   T* xi = xr + (1u << ba.tb);
+  T* als = xi + (1u << ba.tb);
   const unsigned tid = threadIdx.x;
+  if (ALDS) {
+    for (unsigned i = tid; i < a_elems; i += BLOCK) als[i] = Atab[i];
+    __syncthreads();
+  }
   const unsigned tvb = ba.tb - CB, nvec = 1u << tvb;
   V* __restrict__ vre = reinterpret_cast<V*>(re);
   V* __restrict__ vim = reinterpret_cast<V*>(im);
@@ -540,7 +548,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     __syncthreads();
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedGate& G = gates[gi];
-      const T* A = Atab + G.a_off;
+      const T* A = ALDS ? als + G.a_off : Atab + G.a_off;
       switch (G.kv) {
         case 16: blocked_inner_gate<T, 4, 0, BLOCK>(xr, xi, G, A, tvb); break;
         case 17: blocked_inner_gate<T, 4, 1, BLOCK>(xr, xi, G, A, tvb); break;
