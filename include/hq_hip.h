@@ -15,6 +15,14 @@
  * detected with hipPointerGetAttributes.  `U` and `pos` are always HOST
  * pointers and are only read during the call (they are Python temporaries in
  * the reference: hybridq/circuit/simulation/simulation.py:633-644).
+ *
+ * Environment (read once): HQ_LOG2_PACK_SIZE (1..5, what get_log2_pack_size()
+ * reports), HQ_APPLY_MODE / HQ_NONTEMPORAL (initial hq_set_apply_mode values),
+ * HQ_PROGRAM_MB (table buffer of a recorded program, default 64),
+ * HQ_PROGRAM_GRAPH (0: replay programs as a launch loop instead of a hipGraph);
+ * measurement switches: HQ_GEMM_TB (tile bits of the k >= 7 kernel),
+ * HQ_BLOCKED_THREADS (256|512), HQ_BLOCKED_ALDS (0: operand tables of blocked
+ * passes stay in global memory).
  */
 #ifndef HQ_HIP_H
 #define HQ_HIP_H
