@@ -1424,6 +1424,11 @@ int hq_program_end(void** handle) {
   if (!c.rec) return hq::fail("hq_program_end: not recording");
   hq::Program* p = c.rec;
   c.rec = nullptr;
+  if (!handle) {  // nobody could run or free it
+    (void)hipFree(p->dev);
+    delete p;
+    return hq::fail("hq_program_end: null handle pointer");
+  }
   if (!p->host.empty()) {
     hipError_t err = hipMemcpy(p->dev, p->host.data(), p->host.size(), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
@@ -1435,7 +1440,7 @@ int hq_program_end(void** handle) {
   p->host.clear();
   p->host.shrink_to_fit();
   p->finalized = true;
-  if (handle) *handle = p;
+  *handle = p;
   return 0;
 }
 
