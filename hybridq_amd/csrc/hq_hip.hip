@@ -1164,6 +1164,31 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
       lp[j] = (unsigned)local_of[pp[j]];
     }
     if (check_positions(lp, tb, k)) return fail("apply_blocked: duplicate targets");
+    // largest k that takes the register butterfly on the LDS tile (blocked_inner_gate_valu) instead
+    // of the matrix-core form with identity dummies: measured, k = 1 wins (4x fewer flops), k = 2 does not
+    static int valu_kmax = getenv("HQ_BLOCKED_VALU") ? atoi(getenv("HQ_BLOCKED_VALU")) : 1;
+    if (k <= 2 && (int)k <= valu_kmax) {
+      std::vector<T> Us;
+      unsigned sp[kMaxK];
+      sort_gate<T>(Up, lp, k, Us, sp);  // planar, matrix index bits in ascending local position
+      BlockedGate& G = gates[g];
+      memset(&G, 0, sizeof(G));
+      unsigned vmask = 0, kr = 0;
+      for (int m = 0; m < 6; ++m) G.ro.pos[m] = 31;
+      for (unsigned j = 0; j < k; ++j) {
+        if (sp[j] < CB) vmask |= 1u << sp[j];
+        else G.ro.pos[kr++] = sp[j] - CB;
+      }
+      if (tb - CB < kr) return fail("apply_blocked: tile too small");
+      G.a_off = (unsigned)Atab.size();
+      G.kv = 64 + k * 4 + vmask;
+      G.n_addr = kr;
+      Atab.insert(Atab.end(), Us.begin(), Us.end());
+      while (Atab.size() % 4) Atab.push_back((T)0);  // keep the next table 16-byte aligned
+      Up += (size_t)2 << (2 * k);
+      pp += k;
+      continue;
+    }
     MfmaPlan<T> P;
     if (!plan_mfma<T>(c, Up, lp, tb, k, P, true)) return fail("apply_blocked: cannot plan an inner gate");
     BlockedGate& G = gates[g];

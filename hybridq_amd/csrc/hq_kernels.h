@@ -60,6 +60,11 @@ __host__ __device__ constexpr int pdep_c(int v, int mask) {
 
 constexpr int kBlock = 256;
 
+// fma in the TYPE of its operands: `__builtin_fma` is the double builtin, so a float call site
+// silently converts to f64 and back (found in round 1: the float butterfly kernels ran v_fma_f64)
+__device__ __forceinline__ float hq_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double hq_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // ---------------------------------------------------------------------------------
 // apply_direct
 // ---------------------------------------------------------------------------------
@@ -130,10 +135,10 @@ apply_direct_kernel(T* __restrict__ re, T* __restrict__ im, const GateArg<T, K> 
           const int ri = ti >> KV;
           const T ur = U.re[to * D + ti], ui = U.im[to * D + ti];
           const T pr = xr[i][ri][ci], pi = xi[i][ri][ci];
-          ar = __builtin_fma(ur, pr, ar);
-          ar = __builtin_fma(-ui, pi, ar);
-          ai = __builtin_fma(ur, pi, ai);
-          ai = __builtin_fma(ui, pr, ai);
+          ar = hq_fma(ur, pr, ar);
+          ar = hq_fma(-ui, pi, ar);
+          ai = hq_fma(ur, pi, ai);
+          ai = hq_fma(ui, pr, ai);
         }
         yr[co] = ar;
         yi[co] = ai;
@@ -511,11 +516,87 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
   }
 }
 
+// Pin a wave-uniform value to SGPRs (the optimiser does not always prove uniformity of loads).
+__device__ __forceinline__ float hq_uniform(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double hq_uniform(double x) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, x);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+// k = 1, 2 inner gates on the VALU: the real-embedded MFMA form needs k_eff = 3, i.e. a 1- or
+// 2-qubit gate pays for identity dummies (4x / 2x the matrix-core time); a register butterfly
+// on the LDS tile costs 2^k complex MACs per amplitude and the same LDS traffic.  A lane owns
+// the 2^KR partner vectors of both planes (KR = targets that are not vector components);
+// U (planar, ascending target order, 2 * 4^K elements at A, always in GLOBAL memory) is read
+// with uniform addresses: scalar loads, the matrix lives in SGPRs.
+template <typename T, int K, int VMASK, int BLOCK>
+__device__ __forceinline__ void blocked_inner_gate_valu(T* __restrict__ xr, T* __restrict__ xi,
+                                                        const BlockedGate& G, const T* __restrict__ A,
+                                                        const unsigned tile_vec_bits) {
+  using V = typename Vec<T>::type;
+  constexpr int VB = Vec<T>::VB, VE = 1 << VB;
+  constexpr int KV = popc_c(VMASK), KR = K - KV, R = 1 << KR, D = 1 << K;
+  T ur[D * D], ui[D * D];
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) { ur[e] = hq_uniform(A[e]); ui[e] = hq_uniform(A[D * D + e]); }
+  unsigned off[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned o = 0;
+#pragma unroll
+    for (int jj = 0; jj < KR; ++jj) o |= (unsigned)((r >> jj) & 1) << G.ro.pos[jj];
+    off[r] = o;
+  }
+  const unsigned nfree = 1u << (tile_vec_bits - KR);
+#pragma unroll 1
+  for (unsigned v0 = threadIdx.x; v0 < nfree; v0 += BLOCK) {
+    unsigned v = v0;
+#pragma unroll
+    for (int jj = 0; jj < KR; ++jj) {
+      const unsigned lo = (1u << G.ro.pos[jj]) - 1;
+      v = ((v & ~lo) << 1) | (v & lo);
+    }
+    V pr[R], pi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      pr[r] = reinterpret_cast<V*>(xr)[blocked_swz(v | off[r])];
+      pi[r] = reinterpret_cast<V*>(xi)[blocked_swz(v | off[r])];
+    }
+#pragma unroll
+    for (int ro = 0; ro < R; ++ro) {
+      V yr, yi;
+#pragma unroll
+      for (int co = 0; co < VE; ++co) {
+        const int to = pext_c(co, VMASK) | (ro << KV);
+        const int cfree = co & ~VMASK;
+        T ar = 0, ai = 0;
+#pragma unroll
+        for (int ti = 0; ti < D; ++ti) {
+          const int ci = pdep_c(ti & ((1 << KV) - 1), VMASK) | cfree;
+          const int ri = ti >> KV;
+          ar = hq_fma(ur[to * D + ti], pr[ri][ci], ar);
+          ar = hq_fma(-ui[to * D + ti], pi[ri][ci], ar);
+          ai = hq_fma(ur[to * D + ti], pi[ri][ci], ai);
+          ai = hq_fma(ui[to * D + ti], pr[ri][ci], ai);
+        }
+        yr[co] = ar;
+        yi[co] = ai;
+      }
+      reinterpret_cast<V*>(xr)[blocked_swz(v | off[ro])] = yr;
+      reinterpret_cast<V*>(xi)[blocked_swz(v | off[ro])] = yi;
+    }
+  }
+}
+
 // ALDS: the A-operand tables of all gates of the pass (a_elems elements) are staged once per
 // (persistent) workgroup in LDS behind the tile; a table read from global memory puts an L2 round
 // trip (~1500 clk, as long as the gate's MFMAs) in front of every gate of every tile.
 template <typename T, int BLOCK, bool ALDS>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* __restrict__ gates,
                      const unsigned ngates, const T* __restrict__ Atab, const unsigned a_elems,
                      const BlockedArg ba, const uint64_t ntiles) {
@@ -554,6 +635,10 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
         case 17: blocked_inner_gate<T, 4, 1, BLOCK>(xr, xi, G, A, tvb); break;
         case 20: blocked_inner_gate<T, 5, 0, BLOCK>(xr, xi, G, A, tvb); break;
         case 21: blocked_inner_gate<T, 5, 1, BLOCK>(xr, xi, G, A, tvb); break;
+        case 64 + 4 + 0: blocked_inner_gate_valu<T, 1, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+        case 64 + 4 + 1: blocked_inner_gate_valu<T, 1, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+        case 64 + 8 + 0: blocked_inner_gate_valu<T, 2, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+        case 64 + 8 + 1: blocked_inner_gate_valu<T, 2, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
         default:
           if constexpr (CB == 2) {
             switch (G.kv) {
@@ -561,6 +646,9 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
               case 19: blocked_inner_gate<T, 4, 3, BLOCK>(xr, xi, G, A, tvb); break;
               case 22: blocked_inner_gate<T, 5, 2, BLOCK>(xr, xi, G, A, tvb); break;
               case 23: blocked_inner_gate<T, 5, 3, BLOCK>(xr, xi, G, A, tvb); break;
+              case 64 + 4 + 2: blocked_inner_gate_valu<T, 1, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+              case 64 + 8 + 2: blocked_inner_gate_valu<T, 2, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+              case 64 + 8 + 3: blocked_inner_gate_valu<T, 2, 3, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
               default: break;
             }
           }
