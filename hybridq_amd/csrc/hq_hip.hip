@@ -626,9 +626,11 @@ static unsigned gemm_tile_bits(unsigned k) {
 }
 
 template <typename T>
-static bool gemm_ok(unsigned n, unsigned k) {
+static bool gemm_ok(unsigned n, unsigned k, bool forced = false) {
   const unsigned big = sizeof(T) == 4 ? 14 : 13;
-  return k >= 7 && k + 4 <= big && n >= gemm_tile_bits<T>(k);
+  const unsigned tb = gemm_tile_bits<T>(k);
+  if (k < (forced ? 6u : 7u) || k + 4 > big || n < tb) return false;  // k = 6 only on request ("gemm" mode)
+  return ((1u << k) >> 4) * ((1u << (tb - k)) >> 4) >= 8;              // one output block per wave at least
 }
 
 template <typename T, int RBW, int CBW>
@@ -723,7 +725,7 @@ static int launch_gemm(Context& c, T* re, T* im, const T* U, const unsigned* pos
   const uint64_t ntiles = 1ull << (n - tb);
   // 64 (f32) / 32 (f64) output blocks per tile over 8 waves: wave = RBW x CBW blocks
   const unsigned per_wave = (NRBT * NCB) / 8;
-  const unsigned cbw = std::min(NCB, 4u), rbw = per_wave / cbw;
+  const unsigned cbw = std::min(std::min(NCB, 4u), std::max(per_wave, 1u)), rbw = per_wave / cbw;
   int rc = -1;
   const T* Ap = (const T*)dA;
   const unsigned* Op = (const unsigned*)dO;
@@ -860,7 +862,7 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
       if (mfma_tile_ok<T>(n, k)) return launch_mfma_tile<T>(c, re, im, U, pos, n, k);
       break;
     case Mode::Gemm:
-      if (gemm_ok<T>(n, k)) return launch_gemm<T>(c, re, im, U, pos, n, k);
+      if (gemm_ok<T>(n, k, true)) return launch_gemm<T>(c, re, im, U, pos, n, k);
       break;
     case Mode::Auto:
       break;
