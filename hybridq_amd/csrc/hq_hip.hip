@@ -494,7 +494,8 @@ static int launch_mfma_big_kv(Context& c, T* re, T* im, const T* dA, const MfmaP
   }
   const uint64_t niter = (1ull << (n - CB - P.n_addr)) >> 4;  // 16 slots per wave iteration
   const uint64_t wgs = (niter + kBigBlock / 64 - 1) / (kBigBlock / 64);
-  const unsigned grid = (unsigned)std::min<uint64_t>(wgs, 2048);
+  static const int grid_cap = getenv("HQ_BIG_GRID") ? atoi(getenv("HQ_BIG_GRID")) : 2048;
+  const unsigned grid = (unsigned)std::min<uint64_t>(wgs, (uint64_t)grid_cap);
   const MfmaRoles ro = P.ro;
   if (P.nt)
     HQ_LAUNCH(c, (apply_mfma_big_kernel<T, KBITS, VMASK, true, kBigBlock>), dim3(grid), dim3(kBigBlock), lds, re, im, dA, ro, niter);
