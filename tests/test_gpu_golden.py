@@ -216,3 +216,21 @@ def test_api_dot_and_transpose(torch_cuda):
         a = z[f'tr{j}_a'].reshape((2,) * nn)
         b = transpose(np.array(a), [int(x) for x in z[f'tr{j}_axes']], raise_if_hcore_fails=True)
         assert np.array_equal(np.asarray(b).reshape(-1), z[f'tr{j}_res']), j
+
+
+def test_c_abi_demo_without_python(torch_cuda, tmp_path):
+    """examples/abi_demo.cpp: a C++ program that dlopen()s libhq_hip.so and drives the boundary
+    declared in include/hq_hip.h (reference entry point apply_U_float32 + device helpers) with
+    no Python and no torch in the process: graph state on 20 qubits, every amplitude checked."""
+    import os
+    import shutil
+    import subprocess
+    from hybridq_amd import core
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    exe = str(tmp_path / 'abi_demo')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-I', os.path.join(root, 'include'),
+                           os.path.join(root, 'examples', 'abi_demo.cpp'), '-o', exe, '-ldl'])
+    out = subprocess.run([exe, core._LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert 'wrong_amplitudes=0' in out.stdout
