@@ -44,7 +44,7 @@ struct Context {
   unsigned log2_pack = 1;
   Mode mode = Mode::Auto;
   int nontemporal = -1;  // -1 auto, 0 never, 1 always
-  int dummy_policy = -1;  // mfma identity dummies: 0 = free vector components first, 1 = lowest free bits >= 2, -1 = auto
+  int dummy_policy = -1;  // mfma identity dummies: 0 = free vector components first, 1 = lowest free bits >= 2, 2 = free bits >= 6, -1 = auto (= 2)
   std::string last_error = "";
   const char* last_kernel = "none";
   std::string last_desc = "none";  // full instantiation name of the last apply_U kernel
@@ -358,13 +358,18 @@ static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigne
   std::vector<Digit> E;
   uint64_t used = 0;
   for (unsigned j = 0; j < k; ++j) { E.push_back({sp[j], (int)j}); used |= 1ull << sp[j]; }
-  // Where the identity dummies of a k < 3 gate go (measured at n = 30, sweep3): in free
-  // low index bits (they become q digits: every wave access is one contiguous permuted
-  // run) when a target occupies a vector component or for a single target at position
-  // >= 5; in the free vector components otherwise.
+  // Where the identity dummies of a k < 3 gate go (measured at n = 30, tools/sweep_dummy.py):
+  // in free index bits >= 6.  They become register digits whose 16-byte accesses are >= 256 B
+  // apart (non-temporal policy applies) while the real low targets keep the q-digit role (a
+  // permutation of one contiguous run).  Never slower than the two earlier placements
+  // ("comp": free vector components, "low": lowest free bits >= 2) and 8 % faster for single
+  // targets on bits 2-5.  Small states fall through to "low", then to the components.
   int dummy_low = c.dummy_policy;
-  if (dummy_low < 0) dummy_low = (sp[0] < CB || (k == 1 && sp[0] >= 5)) ? 1 : 0;
-  for (unsigned p = dummy_low == 1 ? CB : 0; p < n && E.size() < k_eff; ++p)
+  if (dummy_low < 0) dummy_low = for_tile ? ((sp[0] < CB || (k == 1 && sp[0] >= 5)) ? 1 : 0) : 2;  // LDS tiles: earlier rule (sweep_blocked)
+  if (dummy_low == 2)
+    for (unsigned p = 6; p < n && E.size() < k_eff; ++p)
+      if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
+  for (unsigned p = dummy_low >= 1 ? CB : 0; p < n && E.size() < k_eff; ++p)
     if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
   for (unsigned p = 0; p < CB && E.size() < k_eff; ++p)  // tiny n: fall back to the components
     if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
@@ -1584,6 +1589,7 @@ int hq_set_apply_mode(const char* name) {
   else if (s == "nt=auto") c.nontemporal = -1;
   else if (s == "dummy=comp") c.dummy_policy = 0;
   else if (s == "dummy=low") c.dummy_policy = 1;
+  else if (s == "dummy=high") c.dummy_policy = 2;
   else if (s == "dummy=auto") c.dummy_policy = -1;
   else return hq::fail("unknown apply mode: " + s);
   return 0;

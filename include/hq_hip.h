@@ -101,7 +101,7 @@ int hq_device_count(void);
  * kernels for k <= 6, tile GEMM for k = 7..10, VALU kernels below their size limits;
  * "tile" = LDS tile GEMM for k = 5,6; "direct" = VALU butterflies k <= 3; "generic" = VALU
  * LDS tile any k (a forced family that cannot run a call falls back to auto); {"nt=auto","nt=0","nt=1"} the non-temporal policy;
- * {"dummy=auto","dummy=comp","dummy=low"} the placement of identity digits in the
+ * {"dummy=auto","dummy=comp","dummy=low","dummy=high"} the placement of identity digits in the
  * matrix-core kernel.  Returns 1 for an unknown name. */
 int hq_set_apply_mode(const char *name);
 /* Name of the kernel family the last apply_U call dispatched to. */

@@ -19,7 +19,7 @@ rng = np.random.default_rng(0)
 for pos in ([0], [1], [2], [3], [4], [5], [6], [7], [9], [12], [20], [0, 1], [0, 2], [1, 3], [2, 3], [2, 4], [3, 5], [4, 5], [2, 12], [5, 12], [6, 12], [12, 20]):
     U = haar_unitary(1 << len(pos), rng)
     row = []
-    for mode in ('dummy=comp', 'dummy=low'):
+    for mode in ('dummy=comp', 'dummy=low', 'dummy=high'):
         core.set_apply_mode('mfma')
         core.set_apply_mode(mode)
         core.apply_U(planes[0], planes[1], U, pos)
@@ -36,4 +36,4 @@ for pos in ([0], [1], [2], [3], [4], [5], [6], [7], [9], [12], [20], [0, 1], [0,
     core.apply_U(planes[0], planes[1], U, pos)
     auto_desc = core.last_kernel_desc()
     core.set_apply_mode('auto')
-    print(f'pos={str(pos):<10} comp {row[0][0]:6.3f} ms {row[0][1][18:36]}   low {row[1][0]:6.3f} ms {row[1][1][18:36]}   auto -> {auto_desc[18:36]}', flush=True)
+    print(f'pos={str(pos):<10} comp {row[0][0]:6.3f} ms {row[0][1][18:36]}   low {row[1][0]:6.3f} ms {row[1][1][18:36]}   high {row[2][0]:6.3f} ms {row[2][1][18:36]}   auto -> {auto_desc[18:36]}', flush=True)
