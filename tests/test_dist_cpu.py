@@ -106,7 +106,7 @@ def _worker(rank, world, port, n, seed, ct, out_dir):
         # fused schedule + restore to the canonical placement: the raw shards, concatenated in
         # rank order, must then BE the canonical state (no host-side un-permutation)
         sh3 = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, backend=CpuBackend(ft))
-        sh3.simulate(gates, compress=4)
+        sh3.simulate(gates, compress=5 if n >= 11 else 4)  # width 5: what the k = 5 kernel makes worthwhile
         moved = any(sh3.pos[q] != n - 1 - q for q in range(n))
         sh3.restore_order()
         assert all(sh3.pos[q] == n - 1 - q for q in range(n))
