@@ -303,63 +303,67 @@ def main():
     }
 
     if sharded_path:
-        # the exchange on its own: every rank sends (G-1)/G of both planes, one
-        # distinct chunk per peer, so the per-link figure is chunk bytes / time
-        reps = 3
-        barrier()
-        t0x = time.perf_counter()
-        for _ in range(2 * reps):  # an even count leaves the state where it was
-            sharded.run([('X',)], update_map=False)
-        barrier()
-        tx = (time.perf_counter() - t0x) / (2 * reps)
-        perm = np.arange(n_local, dtype=np.uint32)
-        if n_local >= 2:
-            perm[n_local - 1], perm[n_local - 2] = n_local - 2, n_local - 1
-        barrier()
-        t0p = time.perf_counter()
-        for _ in range(2 * reps):
-            sharded.run([('P', perm)], update_map=False)
-        barrier()
-        tp = (time.perf_counter() - t0p) / (2 * reps)
-        shard_bytes = 2 * (1 << n_local) * ft.itemsize
-        chunk_bytes = shard_bytes // max(world, 1)
-        # cache-blocked local passes between the exchanges (same circuit; reported separately)
-        if n_local >= 14 and not args.no_fused:
-            sharded.pos = dict(pos_after_main)
-            bsched = []
-            for _ in range(1 + args.steps):
-                bsched.append(sharded.plan(gates, blocked=True))
-                sharded.pos = dict(sharded._planned_final_pos)
-            sharded.run(bsched[0], update_map=False)
+        # everything in this block is a reported extra: a failure here must never cost the headline line
+        try:
+            # the exchange on its own: every rank sends (G-1)/G of both planes, one
+            # distinct chunk per peer, so the per-link figure is chunk bytes / time
+            reps = 3
             barrier()
-            t0b = time.perf_counter()
-            for sc in bsched[1:]:
-                sharded.run(sc, update_map=False)
+            t0x = time.perf_counter()
+            for _ in range(2 * reps):  # an even count leaves the state where it was
+                sharded.run([('X',)], update_map=False)
             barrier()
-            elb = (time.perf_counter() - t0b) / args.steps
-            if world > 1:
-                tb_ = torch.tensor([elb], dtype=torch.float64, device='cuda')
-                dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
-                elb = float(tb_.item())
-            result['blocked'] = {
-                'ms_per_step': 1e3 * elb,
-                'logical_gate_apps_per_s': len(gates) / elb,
-                'logical_amplitudes_per_s': len(gates) / elb * float(1 << n),
-                'blocked_passes_per_step': sum(1 for op in bsched[-1] if op[0] == 'B'),
-                'plain_gates_per_step': sum(1 for op in bsched[-1] if op[0] == 'G'),
-                'exchanges_per_step': sum(1 for op in bsched[-1] if op[0] == 'X'),
+            tx = (time.perf_counter() - t0x) / (2 * reps)
+            perm = np.arange(n_local, dtype=np.uint32)
+            if n_local >= 2:
+                perm[n_local - 1], perm[n_local - 2] = n_local - 2, n_local - 1
+            barrier()
+            t0p = time.perf_counter()
+            for _ in range(2 * reps):
+                sharded.run([('P', perm)], update_map=False)
+            barrier()
+            tp = (time.perf_counter() - t0p) / (2 * reps)
+            shard_bytes = 2 * (1 << n_local) * ft.itemsize
+            chunk_bytes = shard_bytes // max(world, 1)
+            # cache-blocked local passes between the exchanges (same circuit; reported separately)
+            if n_local >= 14 and not args.no_fused:
+                sharded.pos = dict(pos_after_main)
+                bsched = []
+                for _ in range(1 + args.steps):
+                    bsched.append(sharded.plan(gates, blocked=True))
+                    sharded.pos = dict(sharded._planned_final_pos)
+                sharded.run(bsched[0], update_map=False)
+                barrier()
+                t0b = time.perf_counter()
+                for sc in bsched[1:]:
+                    sharded.run(sc, update_map=False)
+                barrier()
+                elb = (time.perf_counter() - t0b) / args.steps
+                if world > 1:
+                    tb_ = torch.tensor([elb], dtype=torch.float64, device='cuda')
+                    dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
+                    elb = float(tb_.item())
+                result['blocked'] = {
+                    'ms_per_step': 1e3 * elb,
+                    'logical_gate_apps_per_s': len(gates) / elb,
+                    'logical_amplitudes_per_s': len(gates) / elb * float(1 << n),
+                    'blocked_passes_per_step': sum(1 for op in bsched[-1] if op[0] == 'B'),
+                    'plain_gates_per_step': sum(1 for op in bsched[-1] if op[0] == 'G'),
+                    'exchanges_per_step': sum(1 for op in bsched[-1] if op[0] == 'X'),
+                }
+            result['exchange'] = {
+                'ms_per_exchange': 1e3 * tx,
+                'bytes_sent_per_gpu': shard_bytes - chunk_bytes,
+                'bytes_per_link': chunk_bytes,
+                'GBps_per_link': chunk_bytes / tx / 1e9 if world > 1 else None,
+                'GBps_per_gpu_out': (shard_bytes - chunk_bytes) / tx / 1e9 if world > 1 else None,
+                'xgmi_link_peak_GBps': 153.0,
+                'ms_per_permutation_pass': 1e3 * tp,
+                'exchanges_per_step': n_exchanges,
+                'permutation_passes_per_step': n_permutes,
             }
-        result['exchange'] = {
-            'ms_per_exchange': 1e3 * tx,
-            'bytes_sent_per_gpu': shard_bytes - chunk_bytes,
-            'bytes_per_link': chunk_bytes,
-            'GBps_per_link': chunk_bytes / tx / 1e9 if world > 1 else None,
-            'GBps_per_gpu_out': (shard_bytes - chunk_bytes) / tx / 1e9 if world > 1 else None,
-            'xgmi_link_peak_GBps': 153.0,
-            'ms_per_permutation_pass': 1e3 * tp,
-            'exchanges_per_step': n_exchanges,
-            'permutation_passes_per_step': n_permutes,
-        }
+        except Exception as e:  # noqa: BLE001
+            result['extras_error'] = repr(e)
     if rank == 0 and (events is not None or (sharded_path and op_timer is not None)):
         per_class = {}
         if events is not None:
@@ -400,132 +404,144 @@ def main():
             'per_kernel_launches': {c: len(v) for c, v in sorted(per_class.items())},
         }
     if rank == 0 and not sharded_path and not args.no_fused:
-        # The reference's DEFAULT driver setting fuses the circuit into <= 4-qubit gates first
-        # (compress=4, simulation.py:314,436-454; untimed there, :519).  Reported separately:
-        # same circuit, same state, fewer and larger gates; "logical" rates count the ORIGINAL
-        # gate applications.
-        from hybridq_amd.fusion import fuse
-        # max_n_qubits = 4 is the reference's default; 5 is what the k = 5 matrix-core kernel
-        # makes worthwhile on this GPU (a k = 5 pass costs ~10 % more than a k <= 4 pass)
-        for width, key in ((4, 'fused'), (5, 'fused_k5')):
-            t_f = time.perf_counter()
-            fused = fuse(gates, width, complex_type=args.dtype)
-            t_fuse = time.perf_counter() - t_f
-            fplan = [(U, [state.map[q] for q in reversed(qs)]) for U, qs in fused]
-            for U, pos in fplan:
-                core.apply_U(state.planes[0], state.planes[1], U, pos, n)
-            barrier()
-            t0f = time.perf_counter()
-            for _ in range(args.steps):
+        try:  # a reported extra: a failure here must never cost the headline line
+            # The reference's DEFAULT driver setting fuses the circuit into <= 4-qubit gates first
+            # (compress=4, simulation.py:314,436-454; untimed there, :519).  Reported separately:
+            # same circuit, same state, fewer and larger gates; "logical" rates count the ORIGINAL
+            # gate applications.
+            from hybridq_amd.fusion import fuse
+            # max_n_qubits = 4 is the reference's default; 5 is what the k = 5 matrix-core kernel
+            # makes worthwhile on this GPU (a k = 5 pass costs ~10 % more than a k <= 4 pass)
+            for width, key in ((4, 'fused'), (5, 'fused_k5')):
+                t_f = time.perf_counter()
+                fused = fuse(gates, width, complex_type=args.dtype)
+                t_fuse = time.perf_counter() - t_f
+                fplan = [(U, [state.map[q] for q in reversed(qs)]) for U, qs in fused]
                 for U, pos in fplan:
                     core.apply_U(state.planes[0], state.planes[1], U, pos, n)
-            barrier()
-            el = (time.perf_counter() - t0f) / args.steps
-            result[key] = {
-                'max_n_qubits': width,
-                'apply_U_calls_per_step': len(fplan),
-                'k_histogram': {str(k): sum(1 for _, p in fplan if len(p) == k) for k in range(1, width + 1)},
-                'ms_per_step': 1e3 * el,
-                'ms_per_call': 1e3 * el / len(fplan),
-                'logical_gate_apps_per_s': len(gates) / el,
-                'logical_amplitudes_per_s': len(gates) / el * float(1 << n),
-                'host_fusion_seconds_untimed': t_fuse,
-            }
+                barrier()
+                t0f = time.perf_counter()
+                for _ in range(args.steps):
+                    for U, pos in fplan:
+                        core.apply_U(state.planes[0], state.planes[1], U, pos, n)
+                barrier()
+                el = (time.perf_counter() - t0f) / args.steps
+                result[key] = {
+                    'max_n_qubits': width,
+                    'apply_U_calls_per_step': len(fplan),
+                    'k_histogram': {str(k): sum(1 for _, p in fplan if len(p) == k) for k in range(1, width + 1)},
+                    'ms_per_step': 1e3 * el,
+                    'ms_per_call': 1e3 * el / len(fplan),
+                    'logical_gate_apps_per_s': len(gates) / el,
+                    'logical_amplitudes_per_s': len(gates) / el * float(1 << n),
+                    'host_fusion_seconds_untimed': t_fuse,
+                }
+        except Exception as e:  # noqa: BLE001
+            result['fused_error'] = repr(e)
     if rank == 0 and not sharded_path and not args.no_fused:
-        # Cache-blocked execution (hybridq_amd/blocking.py): many gates per HBM pass through
-        # LDS tiles.  Same circuit and state; scheduling is host work done before the clock,
-        # like fusion.  "logical" rates count the ORIGINAL gate applications.
-        from hybridq_amd.blocking import blocked_stats, plan_blocked
-        t_p = time.perf_counter()
-        tb = 13 if args.dtype == 'complex64' else 12  # 64 KiB of LDS per tile
-        bops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, complex_type=args.dtype)
-        t_plan = time.perf_counter() - t_p
-        packed = [('B', op[1], core.pack_blocked(op[2], args.dtype)) if op[0] == 'B' else op for op in bops]
+        try:  # a reported extra: a failure here must never cost the headline line
+            # Cache-blocked execution (hybridq_amd/blocking.py): many gates per HBM pass through
+            # LDS tiles.  Same circuit and state; scheduling is host work done before the clock,
+            # like fusion.  "logical" rates count the ORIGINAL gate applications.
+            from hybridq_amd.blocking import blocked_stats, plan_blocked
+            t_p = time.perf_counter()
+            tb = 13 if args.dtype == 'complex64' else 12  # 64 KiB of LDS per tile
+            bops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, complex_type=args.dtype)
+            t_plan = time.perf_counter() - t_p
+            packed = [('B', op[1], core.pack_blocked(op[2], args.dtype)) if op[0] == 'B' else op for op in bops]
 
-        def run_blocked():
-            for op in packed:
-                if op[0] == 'G':
-                    core.apply_U(state.planes[0], state.planes[1], op[1], op[2], n)
-                else:
-                    core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
+            def run_blocked():
+                for op in packed:
+                    if op[0] == 'G':
+                        core.apply_U(state.planes[0], state.planes[1], op[1], op[2], n)
+                    else:
+                        core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
 
-        run_blocked()
-        barrier()
-        t0b = time.perf_counter()
-        for _ in range(args.steps):
             run_blocked()
-        barrier()
-        elb = (time.perf_counter() - t0b) / args.steps
-        st = blocked_stats(bops)
-        result['blocked'] = dict(st, tile_bits=tb, ms_per_step=1e3 * elb,
-                                 logical_gate_apps_per_s=len(gates) / elb,
-                                 logical_amplitudes_per_s=len(gates) / elb * float(1 << n),
-                                 host_planning_seconds_untimed=t_plan)
-        result['blocked']['inner_k_histogram'] = {str(k): v for k, v in st['inner_k_histogram'].items()}
-        # the same blocked schedule WITHOUT any algebraic fusion: each of the original gates is
-        # applied on its own inside the LDS tiles (what "no fusion" looks like when gates share passes)
-        uops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, inner_max=0, complex_type=args.dtype)
-        upacked = [('B', op[1], core.pack_blocked(op[2], args.dtype)) if op[0] == 'B' else op for op in uops]
-
-        def run_unfused():
-            for op in upacked:
-                if op[0] == 'G':
-                    core.apply_U(state.planes[0], state.planes[1], op[1], op[2], n)
-                else:
-                    core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
-
-        run_unfused()
-        barrier()
-        t0u = time.perf_counter()
-        run_unfused()
-        barrier()
-        elu = time.perf_counter() - t0u
-        stu = blocked_stats(uops)
-        result['blocked_no_fusion'] = {'blocked_passes': stu['blocked_passes'], 'plain_gates': stu['plain_gates'],
-                                       'inner_gates': stu['inner_gates'], 'ms_per_step': 1e3 * elu,
-                                       'gate_apps_per_s': len(gates) / elu,
-                                       'amplitudes_per_s': len(gates) / elu * float(1 << n)}
-    if rank == 0 and not sharded_path and not args.no_fused:
-        # the same 900-gate step through the VALU register-butterfly kernels only (no matrix cores):
-        # north_star asks for MFMA only where the tile update is a genuine GEMM (k >= 4); the role
-        # kernel is the default because it is faster for k <= 3 as well, this is the evidence
-        core.set_apply_mode('direct')
-        try:
-            run_step()
             barrier()
-            t0d = time.perf_counter()
-            run_step()
+            t0b = time.perf_counter()
+            for _ in range(args.steps):
+                run_blocked()
             barrier()
-            eld = time.perf_counter() - t0d
-            kinds = sorted({core.last_kernel()})
-        finally:
-            core.set_apply_mode('auto')
-        result['valu_direct_only'] = {'ms_per_step': 1e3 * eld, 'gate_apps_per_s': len(gates) / eld,
-                                      'amplitudes_per_s': len(gates) / eld * float(1 << n),
-                                      'hbm_frac_of_peak': len(gates) / eld * bytes_per_gate / 1e9 / HBM_PEAK_GBS,
-                                      'last_kernel': kinds[0]}
+            elb = (time.perf_counter() - t0b) / args.steps
+            st = blocked_stats(bops)
+            result['blocked'] = dict(st, tile_bits=tb, ms_per_step=1e3 * elb,
+                                     logical_gate_apps_per_s=len(gates) / elb,
+                                     logical_amplitudes_per_s=len(gates) / elb * float(1 << n),
+                                     host_planning_seconds_untimed=t_plan)
+            result['blocked']['inner_k_histogram'] = {str(k): v for k, v in st['inner_k_histogram'].items()}
+            # the same blocked schedule WITHOUT any algebraic fusion: each of the original gates is
+            # applied on its own inside the LDS tiles (what "no fusion" looks like when gates share passes)
+            uops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, inner_max=0, complex_type=args.dtype)
+            upacked = [('B', op[1], core.pack_blocked(op[2], args.dtype)) if op[0] == 'B' else op for op in uops]
+
+            def run_unfused():
+                for op in upacked:
+                    if op[0] == 'G':
+                        core.apply_U(state.planes[0], state.planes[1], op[1], op[2], n)
+                    else:
+                        core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
+
+            run_unfused()
+            barrier()
+            t0u = time.perf_counter()
+            run_unfused()
+            barrier()
+            elu = time.perf_counter() - t0u
+            stu = blocked_stats(uops)
+            result['blocked_no_fusion'] = {'blocked_passes': stu['blocked_passes'], 'plain_gates': stu['plain_gates'],
+                                           'inner_gates': stu['inner_gates'], 'ms_per_step': 1e3 * elu,
+                                           'gate_apps_per_s': len(gates) / elu,
+                                           'amplitudes_per_s': len(gates) / elu * float(1 << n)}
+        except Exception as e:  # noqa: BLE001
+            result['blocked_error'] = repr(e)
     if rank == 0 and not sharded_path and not args.no_fused:
-        # one gate of every width on the same resident state (k >= 5 reach the matrix cores through
-        # apply_mfma_big_kernel / apply_gemm_kernel): ms per gate, HBM rate and MFMA rate
-        from hybridq_amd.circuits import haar_unitary
-        rng_k = np.random.default_rng(5)
-        per_k = {}
-        for k in range(1, (10 if args.dtype == 'complex64' else 9) + 1):
-            pos = sorted(int(p) for p in rng_k.permutation(n)[:k])
-            U = np.ascontiguousarray(haar_unitary(1 << k, rng_k), dtype=args.dtype)
-            core.apply_U(state.planes[0], state.planes[1], U, pos, n)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 4 if k <= 8 else 2
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
+        try:  # a reported extra: a failure here must never cost the headline line
+            # the same 900-gate step through the VALU register-butterfly kernels only (no matrix cores):
+            # north_star asks for MFMA only where the tile update is a genuine GEMM (k >= 4); the role
+            # kernel is the default because it is faster for k <= 3 as well, this is the evidence
+            core.set_apply_mode('direct')
+            try:
+                run_step()
+                barrier()
+                t0d = time.perf_counter()
+                run_step()
+                barrier()
+                eld = time.perf_counter() - t0d
+                kinds = sorted({core.last_kernel()})
+            finally:
+                core.set_apply_mode('auto')
+            result['valu_direct_only'] = {'ms_per_step': 1e3 * eld, 'gate_apps_per_s': len(gates) / eld,
+                                          'amplitudes_per_s': len(gates) / eld * float(1 << n),
+                                          'hbm_frac_of_peak': len(gates) / eld * bytes_per_gate / 1e9 / HBM_PEAK_GBS,
+                                          'last_kernel': kinds[0]}
+        except Exception as e:  # noqa: BLE001
+            result['valu_direct_only_error'] = repr(e)
+    if rank == 0 and not sharded_path and not args.no_fused:
+        try:  # a reported extra: a failure here must never cost the headline line
+            # one gate of every width on the same resident state (k >= 5 reach the matrix cores through
+            # apply_mfma_big_kernel / apply_gemm_kernel): ms per gate, HBM rate and MFMA rate
+            from hybridq_amd.circuits import haar_unitary
+            rng_k = np.random.default_rng(5)
+            per_k = {}
+            for k in range(1, (10 if args.dtype == 'complex64' else 9) + 1):
+                pos = sorted(int(p) for p in rng_k.permutation(n)[:k])
+                U = np.ascontiguousarray(haar_unitary(1 << k, rng_k), dtype=args.dtype)
                 core.apply_U(state.planes[0], state.planes[1], U, pos, n)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            per_k[str(k)] = {'ms_per_gate': ms, 'kernel': core.last_kernel_desc(), 'positions': pos,
-                             'hbm_GBps': bytes_per_gate / ms / 1e6, 'TFLOPs': 8.0 * (1 << k) * (1 << n) / ms / 1e9}
-        result['per_k'] = per_k
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 4 if k <= 8 else 2
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    core.apply_U(state.planes[0], state.planes[1], U, pos, n)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                per_k[str(k)] = {'ms_per_gate': ms, 'kernel': core.last_kernel_desc(), 'positions': pos,
+                                 'hbm_GBps': bytes_per_gate / ms / 1e6, 'TFLOPs': 8.0 * (1 << k) * (1 << n) / ms / 1e9}
+            result['per_k'] = per_k
+        except Exception as e:  # noqa: BLE001
+            result['per_k_error'] = repr(e)
     if rank == 0 and not sharded_path and not args.no_cpu_baseline:
         try:
             result['cpu_baseline'] = cpu_baseline(gates, n, args.cpu_seconds, args.dtype)
