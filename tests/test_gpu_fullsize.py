@@ -131,3 +131,32 @@ def test_beyond_32_bit_indices(torch_cuda):
     assert bool((re[idx] == s_before).all())
     p = core.probabilities(re, im, [32], n)
     assert abs(p.sum() - 1.0) < 1e-4 and p.min() > 0
+
+
+def test_full_size_execution_strategies_agree(torch_cuda):
+    """n = 30: the same depth-8 circuit gate by gate (compress=0), fused to width 5 (k = 5 kernel),
+    and cache-blocked (LDS tiles) -- three different kernel families and schedules -- must give the
+    same amplitudes on a random sample and the same norm."""
+    torch = torch_cuda
+    from hybridq_amd import core
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    free, _ = torch.cuda.mem_get_info()
+    n = N_FULL if free > 4 * 8 * (1 << N_FULL) else 26
+    gates = rqc_1q2q(n, depth=8, seed=77)
+    rng = np.random.default_rng(78)
+    idx = torch.from_numpy(rng.integers(0, 1 << n, 1 << 16)).cuda()
+    samples, norms = [], []
+    for kw in (dict(compress=0), dict(compress=5), dict(blocked=True), dict(optimize='evolution-hip')):
+        st = simulate(gates, initial_state='0' * n, complex_type='complex64', qubits=list(range(n)),
+                      return_numpy_array=False, **kw)
+        samples.append(_sample(st.planes, idx))
+        norms.append(st.norm2())
+        del st
+        torch.cuda.empty_cache()
+    scale = np.abs(samples[0]).max()
+    assert scale > 0
+    for s, nr in zip(samples[1:], norms[1:]):
+        assert np.abs(s - samples[0]).max() / scale < 3e-6
+        assert abs(nr - norms[0]) < 1e-5
+    assert abs(norms[0] - 1.0) < 1e-4
