@@ -212,3 +212,40 @@ def test_api_golden_oracle_side(oracle_port):
         if tr != [-1]:
             ns = np.transpose(ns, tr)
         assert np.abs(ns.reshape(-1) - (res[0] + 1j * res[1])).max() == 0
+
+
+@pytest.mark.parametrize('ct', ['complex64', 'complex128'])
+def test_blocked_planner_preserves_the_circuit(oracle_port, ct):
+    """hybridq_amd.blocking.plan_blocked (host side of the cache-blocked path) on the CPU: executing
+    its ops in order -- every inner gate of a 'B' pass, every plain 'G' gate -- with the oracle's
+    apply_U gives the state of the original circuit; tiles contain the low bits and every target of
+    their gates; options (tile size, inner fusion width, no fusion) keep that true."""
+    from hybridq_amd.blocking import blocked_stats, plan_blocked
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    ft = np.dtype('float32') if ct == 'complex64' else np.dtype('float64')
+    for n, gates in ((14, rqc_1q2q(14, depth=10, seed=1)), (16, rqc_1q2q(16, depth=6, seed=2) + random_dense(16, 30, kmax=6, seed=3))):
+        exp = oracle.evolve_tensordot(gates, n, qubits=list(range(n)))
+        pos_of = {q: n - 1 - q for q in range(n)}
+        for opts in (dict(), dict(tile_bits=12, low_bits=4, inner_max=4), dict(tile_bits=10, inner_max=0), dict(tries=1, min_gates=1)):
+            ops = plan_blocked(gates, pos_of, n, complex_type=ct, **opts)
+            pl = aligned_empty((2, 1 << n), ft)
+            pl[:] = 0
+            pl[0, 0] = 1
+            n_inner = 0
+            for op in ops:
+                if op[0] == 'B':
+                    tile = set(int(p) for p in op[1])
+                    assert {0, 1} <= tile and len(tile) == min(opts.get('tile_bits', 13), n)
+                    for U, pos in op[2]:
+                        assert set(int(p) for p in pos) <= tile and len(pos) <= max(4, opts.get('inner_max', 3))
+                        assert oracle_port.apply_U(pl[0], pl[1], np.ascontiguousarray(U, dtype=ct), pos) == 0
+                        n_inner += 1
+                else:
+                    assert oracle_port.apply_U(pl[0], pl[1], np.ascontiguousarray(op[1], dtype=ct), op[2]) == 0
+            psi = pl[0] + 1j * pl[1]
+            tol = 5e-6 if ct == 'complex64' else 1e-12
+            assert np.abs(psi - exp).max() / np.abs(exp).max() < tol, (n, opts)
+            st = blocked_stats(ops)
+            assert st['inner_gates'] == n_inner
+            if opts.get('inner_max', 3) == 0:  # no algebraic fusion: every gate of the circuit appears once
+                assert st['inner_gates'] + st['plain_gates'] == len(gates)
