@@ -249,3 +249,33 @@ def test_blocked_planner_preserves_the_circuit(oracle_port, ct):
             assert st['inner_gates'] == n_inner
             if opts.get('inner_max', 3) == 0:  # no algebraic fusion: every gate of the circuit appears once
                 assert st['inner_gates'] + st['plain_gates'] == len(gates)
+
+
+def test_driver_planning_host_logic():
+    """simulation._plan_ops (pure host code of the driver): fusion width, blocking and the cut at
+    FunctionalGates (never fused: simulation.py:441 skip_compression=[FunctionalGate])."""
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.fusion import fuse
+    from hybridq_amd.simulation import FunctionalGate, _plan_ops, all_qubits
+    n = 16
+    g = rqc_1q2q(n, depth=6, seed=5)
+    qubits = all_qubits(g)
+    assert qubits == list(range(n))
+    ct = np.dtype('complex64')
+    plain = _plan_ops(g, qubits, n, ct, 0, False)
+    assert len(plain) == len(g) and all(len(qs) <= 2 for qs, _ in plain)
+    f4 = _plan_ops(g, qubits, n, ct, 4, False)
+    assert len(f4) == len(fuse(g, 4)) < len(g) / 3 and max(len(qs) for qs, _ in f4) <= 4
+    f5 = _plan_ops(g, qubits, n, ct, {'max_n_qubits': 5}, False)
+    assert len(f5) <= len(f4) and max(len(qs) for qs, _ in f5) == 5
+    fg = FunctionalGate((3,), lambda psi, order: (psi, order))
+    cut = _plan_ops(g[:40] + [fg] + g[40:], qubits, n, ct, 4, False)
+    k = [i for i, op in enumerate(cut) if op is fg]
+    assert len(k) == 1
+    assert len(cut[:k[0]]) == len(fuse(g[:40], 4)) and len(cut[k[0] + 1:]) == len(fuse(g[40:], 4))
+    blk = _plan_ops(g[:40] + [fg] + g[40:], qubits, n, ct, 4, True)
+    kinds = [op[0] if isinstance(op, tuple) and isinstance(op[0], str) else 'F' for op in blk]
+    assert kinds.count('F') == 1 and 'B' in kinds[:kinds.index('F')] and 'B' in kinds[kinds.index('F') + 1:]
+    # blocking needs n >= 14: below that the fused stream is used
+    small = rqc_1q2q(12, depth=4, seed=6)
+    assert all(not isinstance(op[0], str) for op in _plan_ops(small, list(range(12)), 12, ct, 4, True))
