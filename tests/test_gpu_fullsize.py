@@ -160,3 +160,32 @@ def test_full_size_execution_strategies_agree(torch_cuda):
         assert np.abs(s - samples[0]).max() / scale < 3e-6
         assert abs(nr - norms[0]) < 1e-5
     assert abs(norms[0] - 1.0) < 1e-4
+
+
+def test_full_size_permute_bits_and_exchange_layout(torch_cuda):
+    """The multi-GPU local passes at shard size (m = 30: 4 GiB per plane): permute_bits on 2^30
+    elements with moves across bit 29, checked on a random sample; the all-to-all view [G, 2^(m-g)]
+    used by the exchange is the top-g-bits split of the same buffer."""
+    torch = torch_cuda
+    from hybridq_amd import core
+    free, _ = torch.cuda.mem_get_info()
+    m = 30 if free > 3 * 4 * (1 << 30) else 26
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(5)
+    src = torch.empty(1 << m, dtype=torch.float32, device='cuda')
+    src.copy_(torch.arange(1 << m, dtype=torch.int32, device='cuda').view(torch.float32))  # element = its own index
+    dst = torch.empty_like(src)
+    for trial in range(3):
+        perm = np.arange(m)
+        moved = rng.permutation(m)[:6] if trial else np.array([0, m - 1, 5, m - 2, 17, 3])
+        perm[np.sort(moved)] = moved
+        core.permute_bits(src, dst, perm, m)
+        idx = rng.integers(0, 1 << m, 1 << 16)
+        y = np.zeros_like(idx)
+        for i, p in enumerate(perm):
+            y |= ((idx >> i) & 1) << int(p)
+        got = dst[torch.from_numpy(idx).cuda()].view(torch.int32).cpu().numpy().astype(np.int64)
+        assert (got == y).all(), list(perm)
+    g = 3
+    view = src.view(1 << g, 1 << (m - g))
+    assert int(view[5, 123].view(torch.int32)) == (5 << (m - g)) + 123
