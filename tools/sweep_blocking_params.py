@@ -15,9 +15,12 @@ from hybridq_amd.simulation import EvolutionState  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 gates = rqc_1q2q(n, 40, seed=n)
 state = EvolutionState(list(range(n)), complex_type='complex64', initial_state='0' * n)
-for tb in (12, 13):
-    for lb in (3, 4, 5, 6):
-        for im in (0, 2, 3, 4):
+TBS = [int(x) for x in os.environ.get('SWEEP_TB', '12,13').split(',')]
+LBS = [int(x) for x in os.environ.get('SWEEP_LB', '3,4,5,6').split(',')]
+IMS = [int(x) for x in os.environ.get('SWEEP_IM', '0,2,3,4').split(',')]
+for tb in TBS:
+    for lb in LBS:
+        for im in IMS:
             for mg in (3,):
                 ops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=lb, inner_max=im, min_gates=mg)
                 packed = [('B', op[1], core.pack_blocked(op[2])) if op[0] == 'B' else op for op in ops]
