@@ -119,3 +119,24 @@ def fuse(gates, max_n_qubits=4, complex_type='complex64', use_matrix_commutation
         return [(U.astype(complex_type), qs) for U, qs in gates]
     layers = _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol)
     return [(L.U.astype(complex_type), tuple(L.qubits)) for L in layers]
+
+
+def matrix(gates, order=None, complex_type='complex64'):
+    """Dense matrix of a whole circuit: the counterpart of ``hybridq.circuit.utils.matrix``
+    (circuit/utils.py:688-807).  Rows/columns are indexed with ``order[0]`` as the most
+    significant bit; ``order`` defaults to the sorted qubits of the circuit and must be a
+    permutation of them."""
+    gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
+    Q = []
+    for _, qs in gates:
+        Q = _sorted_union(Q, qs)
+    if order is not None:
+        order = list(order)
+        if set(order).difference(Q) or len(order) != len(Q):  # utils.py:748-751
+            raise ValueError("'order' must be a valid permutation of indexes in 'Circuit'.")
+    else:
+        order = Q
+    M = np.eye(1 << len(order), dtype=np.complex128)
+    for U, qs in gates:
+        M = _embed(U, qs, order) @ M
+    return np.ascontiguousarray(M.astype(complex_type))

@@ -29,6 +29,7 @@ What is recorded
   e2e_api.npz         host-level API around the path (python make_golden.py api): prepare_state,
                       simulate() with mixed initial states / compress 4 and 8, Projection and
                       Measure gates, expectation_value(), utils.dot(), utils.transpose().
+  e2e_matrix.npz      utils.matrix / compress / to_matrix_gate on small circuits (python make_golden.py matrix).
 The import of the reference Python needs stand-ins for three absent third-party modules
 (opt_einsum, more_itertools, numba); none of them is on the evolution-hybridq path except
 numba.vectorize for '+-' initial states.
@@ -440,7 +441,42 @@ def api_vectors():
           [out[f'dot{j}_tr'].tolist() for j in range(5)])
 
 
+def matrix_vectors():
+    """e2e_matrix.npz: hybridq.circuit.utils.matrix (circuit -> dense unitary, the routine behind
+    to_matrix_gate, circuit/utils.py:688-807) on small random circuits, default order and a
+    permuted order, plus the layers of utils.compress(max_n_qubits=3) as (qubits, matrix)."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    from hybridq.circuit import utils
+    from hybridq.extras.random import get_rqc
+    out = {}
+    np.random.seed(808)
+    for tag, n, ng in (('a', 4, 12), ('b', 6, 25)):
+        c = get_rqc(n, ng, use_random_indexes=False)
+        qubits = c.all_qubits()
+        out[f'{tag}_n_gates'] = len(c)
+        for i, g in enumerate(c):
+            out[f'{tag}_U{i}'] = np.asarray(g.matrix(), dtype=np.complex128)
+            out[f'{tag}_q{i}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+        out[f'{tag}_qubits'] = np.asarray(qubits, dtype=np.int32)
+        out[f'{tag}_matrix'] = np.asarray(utils.matrix(c, complex_type='complex128', max_compress=0))
+        order = [int(q) for q in np.random.permutation(qubits)]
+        out[f'{tag}_order'] = np.asarray(order, dtype=np.int32)
+        out[f'{tag}_matrix_order'] = np.asarray(utils.matrix(c, order=order, complex_type='complex128'))
+        layers = utils.compress(c, max_n_qubits=3)
+        out[f'{tag}_n_layers'] = len(layers)
+        for j, layer in enumerate(layers):
+            mg = utils.to_matrix_gate(layer, complex_type='complex128')
+            out[f'{tag}_layer{j}_qubits'] = np.asarray([int(q) for q in mg.qubits], dtype=np.int32)
+            out[f'{tag}_layer{j}_matrix'] = np.asarray(mg.matrix(), dtype=np.complex128)
+    np.savez_compressed(os.path.join(HERE, 'e2e_matrix.npz'), **out)
+    print('e2e_matrix.npz:', {k: v.shape for k, v in out.items() if k.endswith('matrix')})
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'matrix':
+        matrix_vectors()
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'dm_circuit':
         dm_circuit()
         raise SystemExit(0)

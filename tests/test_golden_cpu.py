@@ -279,3 +279,23 @@ def test_driver_planning_host_logic():
     # blocking needs n >= 14: below that the fused stream is used
     small = rqc_1q2q(12, depth=4, seed=6)
     assert all(not isinstance(op[0], str) for op in _plan_ops(small, list(range(12)), 12, ct, 4, True))
+
+
+def test_matrix_and_layers_match_reference():
+    """e2e_matrix.npz: fusion.matrix == utils.matrix (default and permuted order), and
+    compress(max_n_qubits=3) + to_matrix_gate give the reference's layers one for one."""
+    from hybridq_amd.fusion import compress, matrix, to_matrix_gate
+    z = gu.load('e2e_matrix.npz')
+    for tag in ('a', 'b'):
+        gates = gu.rqc_gates(z, tag)
+        assert np.abs(matrix(gates, complex_type='complex128') - z[f'{tag}_matrix']).max() < 1e-12
+        order = [int(q) for q in z[f'{tag}_order']]
+        assert np.abs(matrix(gates, order=order, complex_type='complex128') - z[f'{tag}_matrix_order']).max() < 1e-12
+        with pytest.raises(ValueError):
+            matrix(gates, order=order[:-1] + [99])
+        layers = compress(gates, max_n_qubits=3)
+        assert len(layers) == int(z[f'{tag}_n_layers'])
+        for j, layer in enumerate(layers):
+            U, qs = to_matrix_gate(layer, complex_type='complex128')
+            assert list(qs) == [int(q) for q in z[f'{tag}_layer{j}_qubits']]
+            assert np.abs(U - z[f'{tag}_layer{j}_matrix']).max() < 1e-12
