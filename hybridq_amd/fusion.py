@@ -140,3 +140,50 @@ def matrix(gates, order=None, complex_type='complex64'):
     for U, qs in gates:
         M = _embed(U, qs, order) @ M
     return np.ascontiguousarray(M.astype(complex_type))
+
+
+def _inverse_of(U1, q1, U2, q2, atol):
+    """True if gate 2 is the inverse of gate 1 (same qubit set, any order):
+    ``gate.inv().isclose(_g)`` of hybridq/gate/property.py:447-500."""
+    if sorted(map(str, q1)) != sorted(map(str, q2)) or set(q1) != set(q2):
+        return False
+    Q = _sorted_union(q1, q2)
+    A, B = _embed(U1, q1, Q), _embed(U2, q2, Q)
+    try:
+        return bool(np.allclose(np.linalg.inv(A), B, atol=atol))
+    except np.linalg.LinAlgError:
+        return False
+
+
+def simplify(gates, atol=1e-8, use_matrix_commutation=True, max_n_qubits_matrix=10, remove_id_gates=True):
+    """Counterpart of ``hybridq.circuit.utils.simplify`` (circuit/utils.py:825-866 with
+    ``insert_from_left``, :122-208) on ``(U, qubits)`` pairs: drop identity gates, then rebuild the
+    circuit from its LAST gate backwards, sliding every gate to the right through the gates it
+    commutes with (no shared qubit, or commuting matrices) and cancelling it against the first
+    gate that is its inverse.  The circuit's action is unchanged; what changes is the gate
+    list the fusion sees (the reference's ``simulate`` runs this by default, simulation.py:304)."""
+    gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
+    if remove_id_gates:  # utils.py:841-845
+        gates = [(U, qs) for U, qs in gates
+                 if len(qs) > max_n_qubits_matrix or not np.allclose(U, np.eye(U.shape[0]), atol=atol)]
+    new = []  # in circuit order; gates are inserted from the left
+    for U, qs in reversed(gates):
+        q = set(qs)
+        placed = False
+        for p, (V, vs) in enumerate(new):
+            if _inverse_of(U, qs, V, vs, atol):  # :182-184
+                del new[p]
+                placed = True
+                break
+            ok = False
+            if len(vs) <= max_n_qubits_matrix:  # :192-195
+                ok = not (q & set(vs))
+                if not ok and use_matrix_commutation:
+                    ok = commute(U, qs, V, vs, atol)
+            if not ok:  # :199-201
+                new.insert(p, (U, qs))
+                placed = True
+                break
+        if not placed:
+            new.append((U, qs))
+    return new

@@ -205,6 +205,29 @@ class EvolutionState:
         return core.norm2(self.planes[0], self.planes[1])
 
 
+def _simplify_runs(circuit, remove_id_gates, atol, opts):
+    """``utils.simplify`` (fusion.simplify) applied to every run of matrix gates between
+    FunctionalGates; the functional gates stay where they are (the reference lets a gate slide past
+    a FunctionalGate on disjoint qubits as well: a superset of these moves, same final state)."""
+    from .fusion import simplify as _simplify
+    out, run = [], []
+
+    def flush():
+        if run:
+            gates = _simplify([(U, qs) for qs, U in run], atol=atol, remove_id_gates=remove_id_gates, **opts)
+            out.extend((U, qs) for U, qs in gates)
+            run.clear()
+
+    for g in circuit:
+        if _is_functional(g):
+            flush()
+            out.append(g)
+        else:
+            run.append(_gate_qubits_matrix(g))
+    flush()
+    return out
+
+
 def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
     """Turn a circuit into the op list the gate loop executes: fused ``(qubits, U)`` gates
     (simulation.py:436-454), or the 'B'/'G' ops of the cache-blocked planner; FunctionalGates are
@@ -278,9 +301,10 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     0 applies the gates as given; a dict may carry ``max_n_qubits`` plus the keyword
     arguments of ``fusion.fuse``), ``device``, ``blocked`` (default False; True or a dict of
     ``blocking.plan_blocked`` options: apply many gates per HBM pass through LDS tiles,
-    n >= 14 -- see hybridq_amd/blocking.py).  ``simplify`` (the reference's commuting-gate
-    reordering / inverse cancellation, circuit/utils.py:825) is a host-side IR transform
-    upstream of this path and is not reproduced: gates are fused in the order given.
+    n >= 14 -- see hybridq_amd/blocking.py).  ``simplify`` / ``remove_id_gates`` / ``atol`` as in the
+    reference (simulation.py:290-305): identity gates are dropped and `fusion.simplify` (the
+    counterpart of circuit/utils.py:825) slides commuting gates and cancels inverse pairs before
+    fusion; a dict passes ``use_matrix_commutation`` / ``max_n_qubits_matrix`` on.
     """
     if optimize not in ('evolution', 'evolution-hybridq', 'evolution-hip'):
         raise ValueError(f"hybridq_amd only implements optimize='evolution' (got {optimize!r})")
@@ -304,6 +328,12 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     qubits = kwargs.get('qubits') or all_qubits(circuit)
     n = len(qubits)
     n_given = len(circuit)
+    if remove_id_gates:  # simulation.py:289-291 (named identity gates; matrix identities go in simplify)
+        circuit = [g for g in circuit if getattr(g, 'name', None) != 'I']
+    if simplify:  # simulation.py:293-305
+        circuit = _simplify_runs(circuit, remove_id_gates, atol, simplify if isinstance(simplify, dict) else {})
+        if not kwargs.get('qubits') and all_qubits(circuit) != qubits:
+            raise ValueError("Active qubits have changed after simplification. Forcing stop.")
     ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
     # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519)
     gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))

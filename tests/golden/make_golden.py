@@ -469,6 +469,31 @@ def matrix_vectors():
             mg = utils.to_matrix_gate(layer, complex_type='complex128')
             out[f'{tag}_layer{j}_qubits'] = np.asarray([int(q) for q in mg.qubits], dtype=np.int32)
             out[f'{tag}_layer{j}_matrix'] = np.asarray(mg.matrix(), dtype=np.complex128)
+    # utils.simplify on a circuit with planted identities, inverse pairs and commuting gates
+    from hybridq.circuit import Circuit
+    from hybridq.gate import Gate
+    np.random.seed(909)
+    base = list(get_rqc(5, 30, use_random_indexes=False))
+    planted = []
+    for i, g in enumerate(base):
+        planted.append(g)
+        if i % 4 == 1:
+            planted.append(Gate('I', qubits=[int(np.random.randint(5))]))
+        if i % 5 == 2:  # an inverse pair separated by a gate on other qubits
+            h = base[(i * 7) % len(base)]
+            others = [q for q in range(5) if q not in h.qubits]
+            planted += [h, Gate('Z', qubits=[others[0]]) if others else Gate('I', qubits=[0]), h.inv()]
+    c = Circuit(planted)
+    out['s_n_gates'] = len(c)
+    for i, g in enumerate(c):
+        out[f's_U{i}'] = np.asarray(g.matrix(), dtype=np.complex128)
+        out[f's_q{i}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+    sc = utils.simplify(c, remove_id_gates=True, verbose=False)
+    out['s_simplified_n'] = len(sc)
+    for i, g in enumerate(sc):
+        out[f's_simplified_U{i}'] = np.asarray(g.matrix(), dtype=np.complex128)
+        out[f's_simplified_q{i}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+    print('simplify:', len(c), '->', len(sc))
     np.savez_compressed(os.path.join(HERE, 'e2e_matrix.npz'), **out)
     print('e2e_matrix.npz:', {k: v.shape for k, v in out.items() if k.endswith('matrix')})
 

@@ -299,3 +299,23 @@ def test_matrix_and_layers_match_reference():
             U, qs = to_matrix_gate(layer, complex_type='complex128')
             assert list(qs) == [int(q) for q in z[f'{tag}_layer{j}_qubits']]
             assert np.abs(U - z[f'{tag}_layer{j}_matrix']).max() < 1e-12
+
+
+def test_simplify_matches_reference():
+    """fusion.simplify == utils.simplify on a circuit with planted identity gates, inverse pairs
+    behind commuting gates and ordinary gates: same gate list (qubits and matrices, in order),
+    and the circuit's unitary is unchanged."""
+    from hybridq_amd.fusion import matrix, simplify
+    z = gu.load('e2e_matrix.npz')
+    gates = gu.rqc_gates(z, 's')
+    exp = [(z[f's_simplified_U{i}'], tuple(int(q) for q in z[f's_simplified_q{i}'])) for i in range(int(z['s_simplified_n']))]
+    got = simplify(gates)
+    assert len(got) == len(exp) < len(gates)
+    for (U, qs), (V, vs) in zip(got, exp):
+        assert tuple(qs) == tuple(vs)
+        assert np.abs(np.asarray(U) - V).max() < 1e-12
+    order = list(range(5))
+    assert np.abs(matrix(got, order=order, complex_type='complex128') - matrix(gates, order=order, complex_type='complex128')).max() < 1e-10
+    # without identity removal the identities stay; without matrix commutation fewer pairs cancel
+    assert len(simplify(gates, remove_id_gates=False)) > len(got)
+    assert len(simplify(gates, use_matrix_commutation=False)) >= len(got)

@@ -354,12 +354,17 @@ def test_simulate_matches_reference_protocol(torch_cuda, oracle_port, ct):
 def test_simulate_initial_states(torch_cuda):
     from hybridq_amd.simulation import simulate
     n = 12
-    psi = simulate([(np.eye(2), (q,)) for q in range(n)], initial_state='+' * n)
+    ident = [(np.eye(2), (q,)) for q in range(n)]
+    # like the reference (simulation.py:301-305): simplification removes the identities, the active
+    # qubits change and the run is stopped
+    with pytest.raises(ValueError):
+        simulate(ident, initial_state='+' * n)
+    psi = simulate(ident, initial_state='+' * n, simplify=False)
     assert np.allclose(psi, 2**(-n / 2))
     s = '0110' * 3
-    psi = simulate([(np.eye(2), (q,)) for q in range(n)], initial_state=s).reshape(-1)
+    psi = simulate(ident, initial_state=s, simplify=False).reshape(-1)
     assert psi[int(s, 2)] == 1 and np.abs(psi).sum() == 1
-    psi = simulate([(np.eye(2), (q,)) for q in range(n)], initial_state='+-01' * 3).reshape(-1)
+    psi = simulate(ident, initial_state='+-01' * 3, qubits=list(range(n))).reshape(-1)  # explicit qubits: nothing to apply
     exp = np.ones(1)
     single = {'0': [1, 0], '1': [0, 1], '+': [2**-0.5, 2**-0.5], '-': [2**-0.5, -2**-0.5]}
     for c in '+-01' * 3:
@@ -856,3 +861,32 @@ def test_probabilities_stream_kernel(torch_cuda, ft):
                 t |= ((x >> q) & 1) << j
             exp = np.bincount(t, weights=p, minlength=1 << len(pos))
             assert np.abs(got - exp).max() / exp.max() < (1e-6 if ft == np.dtype('float32') else 1e-13), (n, pos)
+
+
+def test_simulate_simplify_like_reference(torch_cuda, oracle_port):
+    """simulate(simplify=True) (the reference's default, simulation.py:293-305): planted identity
+    gates and inverse pairs disappear before fusion, the state is the one of the full circuit."""
+    import oracle
+    from hybridq_amd.circuits import haar_unitary, rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    n = 14
+    rng = np.random.default_rng(12)
+    base = rqc_1q2q(n, depth=6, seed=13)
+    planted = []
+    for i, g in enumerate(base):
+        planted.append(g)
+        if i % 5 == 0:
+            planted.append((np.eye(2), (int(rng.integers(n)),)))
+        if i % 7 == 3:
+            U = haar_unitary(4, rng)
+            a, b = (int(x) for x in rng.permutation(n)[:2])
+            other = next(q for q in range(n) if q not in (a, b))
+            planted += [(U, (a, b)), (np.diag([1, 1j]), (other,)), (U.conj().T, (a, b))]
+    exp = oracle.evolve_tensordot(planted, n, qubits=list(range(n)))
+    psi, info = simulate(planted, initial_state='0' * n, compress=0, return_info=True)
+    assert np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max() < 5e-6
+    assert info['n_gates'] < len(planted) - len(base) // 5  # identities and inverse pairs are gone
+    psi2, info2 = simulate(planted, initial_state='0' * n, compress=0, simplify=False, remove_id_gates=False,
+                           return_info=True)
+    assert info2['n_gates'] == len(planted)
+    assert np.abs(psi2.reshape(-1) - exp).max() / np.abs(exp).max() < 5e-6
