@@ -113,7 +113,11 @@ def cpu_baseline(gates, n, seconds, complex_type):
         'kind': lib.kind,
         'sample': (f'first {info["n_gates"]} gate applications (after {warm} warm-up) of the same n={n_cpu} '
                    f'depth-40 circuit through the reference driver protocol (swap policy + apply_U), '
-                   f'{info["runtime (s)"]:.1f} s, OpenMP threads={threads}'),
+                   f'{info["runtime (s)"]:.1f} s, OpenMP threads={threads} = the cgroup CPU quota of the box '
+                   f'({os.cpu_count()} hardware threads visible); '
+                   + ('reference core built -Ofast -march=haswell (AVX2, LOG2_PACK_SIZE=3: its -march=native build '
+                      'segfaults, SURVEY 8c) in the build container and shipped as oracle/_ref'
+                      if lib.kind == 'reference' else 'C port of the reference core (oracle/hq_oracle.c, -O3 -march=haswell)')),
     }
 
 
@@ -133,12 +137,22 @@ def parity_check(complex_type, depth, n=24):
     ref, _ = oracle.evolve_reference_protocol(lib, gates, n, complex_type=complex_type)
     t_cpu = time.perf_counter() - t0
     scale = float(np.abs(ref).max())
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from tolerances import BAR, circuit_tol, rounding_bound, widths  # the same bounds the -m gpu tests assert
+    bar = BAR[np.dtype(complex_type)]
     out = {'n_qubits': n, 'gate_applications': len(gates), 'cpu_kind': lib.kind, 'cpu_seconds': t_cpu,
-           'tolerance': 1e-6 if complex_type == 'complex64' else 1e-12, 'norm': 'max|d| / max|psi|'}
+           'bar': bar, 'norm': 'max|d| / max|psi|',
+           'rounding_model_bound_one_f32_evolution': rounding_bound(widths(gates), complex_type),
+           'tolerance_two_evolutions': circuit_tol(gates, gates, complex_type),
+           'statement': ('pass = (i) GPU vs reference <= tolerance_two_evolutions (the bar itself while the rounding '
+                         'model of the circuit stays below it), (ii) GPU vs complex128 truth <= 1.15 x the '
+                         "reference's own distance to it (complex64), (iii) the first 1/8 of the circuit agrees to the bar")}
     results = {}
+    ok = True
     for name, kw in (('per_gate', dict(compress=0)), ('fused_k4', dict(compress=4)), ('blocked', dict(blocked=True))):
         psi = simulate(gates, initial_state='0' * n, complex_type=complex_type, qubits=list(range(n)), **kw).reshape(-1)
         out['max_rel_diff_' + name] = float(np.abs(psi - ref).max() / scale)
+        ok = ok and out['max_rel_diff_' + name] <= out['tolerance_two_evolutions']
         results[name] = psi
     if complex_type == 'complex64':
         # Two float32 evolutions of hundreds of gates differ by accumulated rounding whatever the
@@ -149,10 +163,13 @@ def parity_check(complex_type, depth, n=24):
         out['reference_cpu_f32_vs_f64'] = float(np.abs(ref - truth).max() / scale)
         for name, psi in results.items():
             out['gpu_f32_%s_vs_f64' % name] = float(np.abs(psi - truth).max() / scale)
+            ok = ok and out['gpu_f32_%s_vs_f64' % name] <= 1.15 * out['reference_cpu_f32_vs_f64']
         short = gates[:len(gates) // 8]
-        r2, _ = oracle.evolve_reference_protocol(lib, short, n, complex_type=complex_type)
+        r2, _ = oracle.evolve_reference_protocol(lib, short, n, complex_type=complex_type, qubits=list(range(n)))
         g2 = simulate(short, initial_state='0' * n, complex_type=complex_type, qubits=list(range(n)), compress=0).reshape(-1)
         out['max_rel_diff_first_%d_gates' % len(short)] = float(np.abs(g2 - r2).max() / float(np.abs(r2).max()))
+        ok = ok and out['max_rel_diff_first_%d_gates' % len(short)] <= bar
+    out['pass'] = bool(ok)
     return out
 
 
@@ -398,6 +415,10 @@ def main():
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic,
+            'traffic_source': (None if traffic is None else
+                               'stored PMC measurement (profiles/traffic.json <- profiles/r01_pmc_hbm_traffic_v2.csv: '
+                               '2 x FETCH_SIZE + WRITE_SIZE of this kernel at this n, separate rocprofv3 --pmc passes), '
+                               'not a counter of this run'),
             'algorithmic_bytes_per_launch': bytes_per_gate,
             'avg_launch_ms': avg_ms,
             'launches': len(per_class[dom]),

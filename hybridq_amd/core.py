@@ -94,6 +94,11 @@ _init_state = {
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint,
                                             ctypes.c_int, ctypes.c_uint64) for b in (32, 64)
 }
+_init_product = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_init_product_state_float{b}', ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64,
+                                            ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint) for b in (32, 64)
+}
 _norm2 = {
     np.dtype(f'float{b}'): _define_function(_lib, f'hq_norm2_float{b}', ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_uint64,
@@ -143,6 +148,7 @@ EXPORTED = [
     'hq_set_stream', 'hq_sync', 'hq_set_log2_pack_size', 'hq_last_error', 'hq_device_count',
     'hq_set_apply_mode', 'hq_last_kernel', 'hq_last_kernel_desc', 'hq_to_complex64', 'hq_to_complex128',
     'hq_init_state_float32', 'hq_init_state_float64', 'hq_norm2_float32', 'hq_norm2_float64',
+    'hq_init_product_state_float32', 'hq_init_product_state_float64',
     'hq_permute_bits_32', 'hq_permute_bits_64',
     'hq_probabilities_float32', 'hq_probabilities_float64', 'hq_project_float32', 'hq_project_float64',
     'hq_vdot_float32', 'hq_vdot_float64', 'hq_apply_blocked_float32', 'hq_apply_blocked_float64',
@@ -182,9 +188,26 @@ def device_count():
     return int(_device_count())
 
 
+_stream_now = None
+
+
 def set_stream(stream_handle):
-    """`stream_handle`: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
-    _check(_set_stream(ctypes.c_void_p(int(stream_handle))), 'hq_set_stream')
+    """`stream_handle`: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).
+    Switching streams is ordered on the device (the new stream waits for the work already
+    enqueued on the old one), never a host synchronisation."""
+    global _stream_now
+    h = int(stream_handle)
+    if h != _stream_now:
+        _check(_set_stream(ctypes.c_void_p(h)), 'hq_set_stream')
+        _stream_now = h
+
+
+def use_torch_stream():
+    """Bind the library to torch's CURRENT stream (cheap when it has not changed).  The drivers
+    call this at every public entry point so that kernels, torch allocations and copies made by
+    the caller share one stream even under ``with torch.cuda.stream(...)``."""
+    import torch
+    set_stream(torch.cuda.current_stream().cuda_stream)
 
 
 def sync():
@@ -260,6 +283,28 @@ def init_state(psi_re, psi_im, kind='basis', basis=0):
     n = _n_qubits(psi_re)
     rc = _init_state[ft](_ptr(psi_re), _ptr(psi_im), n, {'basis': 0, 'plus': 1}[kind], int(basis))
     _check(rc, 'init_state')
+
+
+def init_product_state(psi_re, psi_im, chars_by_position, hi_bits=0):
+    """Write the product state whose factor on index bit p is ``chars_by_position[p]`` ('0', '1',
+    '+' or '-'; a dict or sequence covering every bit of the FULL index).  The planes hold the
+    2^n_local amplitudes whose higher index bits equal ``hi_bits >> n_local`` (0 on one GPU)."""
+    ft = _float_dtype(psi_re)
+    n_local = _n_qubits(psi_re)
+    items = chars_by_position.items() if hasattr(chars_by_position, 'items') else enumerate(chars_by_position)
+    m01 = v01 = mm = npm = 0
+    for p, ch in items:
+        if ch in '01':
+            m01 |= 1 << p
+            v01 |= int(ch) << p
+        elif ch in '+-':
+            npm += 1
+            if ch == '-':
+                mm |= 1 << p
+        else:
+            raise ValueError("product states are made of '0', '1', '+', '-'")
+    rc = _init_product[ft](_ptr(psi_re), _ptr(psi_im), n_local, int(hi_bits), m01, v01, mm, npm)
+    _check(rc, 'init_product_state')
 
 
 def norm2(psi_re, psi_im):

@@ -1010,12 +1010,16 @@ static int permute_bits_entry(const E* src, E* dst, const unsigned* perm, unsign
     if (perm[i] >= n || (seen >> perm[i]) & 1) return fail("permute_bits: perm is not a permutation of 0..n-1");
     seen |= 1ull << perm[i];
     if (perm[i] == i) pa.fixed_mask |= 1ull << i;
-    else {
-      if (pa.nmoved >= 16) return fail("permute_bits: more than 16 moved bits");
-      pa.from[pa.nmoved] = i;
-      pa.to[pa.nmoved] = perm[i];
-      ++pa.nmoved;
-    }
+  }
+  for (unsigned i = 0; i < n;) {  // moved bits -> fields (runs with consecutive sources)
+    if (perm[i] == i) { ++i; continue; }
+    unsigned len = 1;
+    while (i + len < n && perm[i + len] == perm[i] + len && perm[i + len] != i + len) ++len;
+    pa.from[pa.nfields] = (unsigned char)i;
+    pa.to[pa.nfields] = (unsigned char)perm[i];
+    pa.len[pa.nfields] = (unsigned char)len;
+    ++pa.nfields;
+    i += len;
   }
   const uint64_t size = 1ull << n;
   const bool vec16 = (pa.fixed_mask & 3) == 3 && n >= 2 && sizeof(E) == 4 &&
@@ -1105,6 +1109,26 @@ static int init_state_entry(T* re, T* im, unsigned n, int kind, uint64_t basis) 
   const T amp = (T)std::pow(2.0, -0.5 * (double)n);
   const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
   HQ_LAUNCH(c, (init_state_kernel<T>), dim3(grid), dim3(kBlock), 0, re, im, size, kind, basis, amp);
+  HQ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+static int init_product_entry(T* re, T* im, unsigned n_local, uint64_t hi_bits, uint64_t mask01, uint64_t val01,
+                              uint64_t mask_minus, unsigned n_pm) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!re || !im || n_local > 62) return fail("init_product_state: bad arguments");
+  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("init_product_state: device pointers only");
+  if ((val01 & ~mask01) || (mask01 & mask_minus)) return fail("init_product_state: inconsistent masks");
+  if (n_local < 2 || (reinterpret_cast<uintptr_t>(re) % 32) || (reinterpret_cast<uintptr_t>(im) % 32))
+    return fail("init_product_state: needs >= 2 local qubits and 32-byte aligned planes");
+  if (n_local < 62 && (hi_bits & ((1ull << n_local) - 1))) return fail("init_product_state: hi_bits overlaps the local index");
+  const uint64_t nquads = (1ull << n_local) / 4;
+  const T amp = (T)std::pow(2.0, -0.5 * (double)n_pm);
+  const unsigned grid = (unsigned)std::min<uint64_t>((nquads + kBlock - 1) / kBlock, 256 * 32);
+  HQ_LAUNCH(c, (init_product_kernel<T>), dim3(grid), dim3(kBlock), 0, re, im, nquads, hi_bits, mask01, val01, mask_minus, amp);
   HQ_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1540,7 +1564,21 @@ int hq_program_free(void* handle) {
 int hq_set_stream(void* hip_stream) {
   hq::Context& c = hq::ctx();
   std::lock_guard<std::mutex> lock(c.mu);
-  c.stream = reinterpret_cast<hipStream_t>(hip_stream);
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  if (s == c.stream) return 0;
+  if (c.rec) return hq::fail("hq_set_stream: cannot change the stream while recording a program");
+  // Work already enqueued on the old stream may still be reading the upload arena / scratch
+  // buffers (they are recycled in issue order): the new stream waits for it on the DEVICE, the
+  // host does not block.
+  if (c.device >= 0) {
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, c.stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, ev, 0);
+    if (ev) (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return hq::fail(std::string("hq_set_stream: ") + hipGetErrorString(e));
+  }
+  c.stream = s;
   return 0;
 }
 
@@ -1603,6 +1641,14 @@ int hq_init_state_float32(float* re, float* im, unsigned int n, int kind, uint64
 }
 int hq_init_state_float64(double* re, double* im, unsigned int n, int kind, uint64_t basis) {
   return hq::init_state_entry<double>(re, im, n, kind, basis);
+}
+int hq_init_product_state_float32(float* re, float* im, unsigned int n_local, uint64_t hi_bits, uint64_t mask01,
+                                  uint64_t val01, uint64_t mask_minus, unsigned int n_pm) {
+  return hq::init_product_entry<float>(re, im, n_local, hi_bits, mask01, val01, mask_minus, n_pm);
+}
+int hq_init_product_state_float64(double* re, double* im, unsigned int n_local, uint64_t hi_bits, uint64_t mask01,
+                                  uint64_t val01, uint64_t mask_minus, unsigned int n_pm) {
+  return hq::init_product_entry<double>(re, im, n_local, hi_bits, mask01, val01, mask_minus, n_pm);
 }
 int hq_norm2_float32(const float* re, const float* im, uint64_t size, double* out) {
   return hq::norm2_entry<float>(re, im, size, out);

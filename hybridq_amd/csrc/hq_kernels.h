@@ -1136,10 +1136,15 @@ swap_gather_kernel(const E* __restrict__ in, E* __restrict__ out, const SwapArg 
 // multi-GPU shard exchange and to restore the canonical order.  Only the moved bits cost
 // index arithmetic; if bits 0..1 are fixed the copy runs on 16-byte vectors.
 // ---------------------------------------------------------------------------------
+// Moved bits are grouped into FIELDS: runs of consecutive destination bits whose sources are
+// consecutive too (a rotation of a block of qubits is one field, whatever its width), so the
+// index arithmetic is one shift + mask per run and any permutation of up to 62 bits fits.
+constexpr int kPermMaxFields = 62;
 struct PermArg {
-  unsigned nmoved;
-  unsigned from[16];   // destination-index bit ...
-  unsigned to[16];     // ... lands at this source-index bit
+  unsigned nfields;
+  unsigned char from[kPermMaxFields];   // lowest destination-index bit of the field ...
+  unsigned char to[kPermMaxFields];     // ... lands at this source-index bit
+  unsigned char len[kPermMaxFields];    // field width in bits
   uint64_t fixed_mask; // bits that stay where they are
 };
 
@@ -1153,7 +1158,7 @@ permute_bits_kernel(const E* __restrict__ src, E* __restrict__ dst, const PermAr
     const uint64_t x = u * VEC;
     uint64_t y = x & pa.fixed_mask;
 #pragma unroll 4
-    for (unsigned i = 0; i < pa.nmoved; ++i) y |= ((x >> pa.from[i]) & 1ull) << pa.to[i];
+    for (unsigned i = 0; i < pa.nfields; ++i) y |= ((x >> pa.from[i]) & ((1ull << pa.len[i]) - 1)) << pa.to[i];
     *reinterpret_cast<Pack*>(dst + x) = *reinterpret_cast<const Pack*>(src + y);
   }
 }
@@ -1198,6 +1203,29 @@ init_state_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t size, c
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
     re[i] = kind == 1 ? amp : (i == basis ? (T)1 : (T)0);
     im[i] = 0;
+  }
+}
+
+// Product state of '0' / '1' / '+' / '-' factors (hybridq/circuit/simulation/utils.py:99-153 builds it
+// on the host with kron + parity + transpose): amplitude of index X is 0 unless the '0'/'1' bits of
+// X match, else (-1)^popcount(X & minus_mask) * 2^(-#pm/2).  X = hi_bits | local index, so a shard
+// of a multi-GPU state (hi_bits = rank << n_local) is written by the same kernel.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+init_product_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t nquads, const uint64_t hi_bits,
+                    const uint64_t mask01, const uint64_t val01, const uint64_t mask_minus, const T amp) {
+  using Q = typename Vec<T>::quad;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nquads; i += stride) {
+    Q r, z = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint64_t x = hi_bits | (4 * i + c);
+      const T v = (__popcll(x & mask_minus) & 1) ? -amp : amp;
+      r[c] = ((x & mask01) == val01) ? v : (T)0;
+    }
+    __builtin_nontemporal_store(r, reinterpret_cast<Q*>(re) + i);
+    __builtin_nontemporal_store(z, reinterpret_cast<Q*>(im) + i);
   }
 }
 

@@ -132,12 +132,21 @@ def plan_restore(pos, qubits, g):
     want = {q: n - 1 - i for i, q in enumerate(qubits)}
     ops = []
 
-    def permute_to(target):  # target: {qubit: local position} for a subset; others fill the rest in order
+    def permute_to(target):  # target: {qubit: local position} for a subset
+        # every other local qubit stays where it is unless a target claims its position; only the
+        # displaced ones move, into the positions the targets vacate (few moved bits per pass)
         taken = set(target.values())
-        free = [p for p in range(m) if p not in taken]
         rest = [at[p] for p in range(m) if at[p] not in target]
         new_local = dict(target)
-        new_local.update({q: p for q, p in zip(rest, free)})
+        displaced = []
+        for q in rest:
+            if pos[q] in taken:
+                displaced.append(q)
+            else:
+                new_local[q] = pos[q]
+                taken.add(pos[q])
+        free = [p for p in range(m) if p not in taken]
+        new_local.update({q: p for q, p in zip(displaced, free)})
         perm = [0] * m
         for q, p_new in new_local.items():
             perm[p_new] = pos[q]  # dst bit p_new <- src bit pos[q]
@@ -213,6 +222,9 @@ class HipBackend:
         planes[0].fill_(value)
         planes[1].zero_()
 
+    def fill_product(self, planes, chars_by_position, hi_bits):
+        self.core.init_product_state(planes[0], planes[1], chars_by_position, hi_bits)
+
     def apply(self, planes, U, pos, m):
         self.core.apply_U(planes[0], planes[1], U, pos, m)
 
@@ -276,12 +288,15 @@ class ShardedEvolution:
         return self.bufs[self.cur]
 
     def set_state(self, initial_state):
-        """'0'/'1' strings (basis states) and the all-'+' string; canonical qubit order."""
+        """'01+-' strings (hybridq/circuit/simulation/utils.py:99-153), one character per qubit in
+        canonical order; every rank writes its own shard on the device."""
         s = initial_state
         if len(s) == 1:
             s = s * self.n
         if len(s) != self.n:
             raise ValueError("'initial_state' has the wrong number of qubits.")
+        if any(c not in '01+-' for c in s):
+            raise ValueError("'initial_state' may contain only '0', '1', '+', '-'.")
         self.pos = {q: self.n - 1 - i for i, q in enumerate(self.qubits)}
         if all(c in '01' for c in s):
             b = int(s, 2)
@@ -292,7 +307,7 @@ class ShardedEvolution:
         elif all(c == '+' for c in s):
             self.backend.fill_const(self.planes, 2.0**(-0.5 * self.n))
         else:
-            raise ValueError("sharded initial states: '0'/'1' strings or all '+'")
+            self.backend.fill_product(self.planes, {self.n - 1 - i: c for i, c in enumerate(s)}, self.rank << self.m)
 
     # -- planning ----------------------------------------------------------------
     def plan(self, gates, compress=0, blocked=False):

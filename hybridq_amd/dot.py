@@ -59,102 +59,116 @@ def _is_cuda_tensor(x):
     return hasattr(x, 'data_ptr') and getattr(x, 'is_cuda', False)
 
 
+_DOT_DEFAULTS = dict(out=None, force_numpy=False, raise_if_hcore_fails=False, swap_back=True, alignment=32)
+
+
+class _HostOperand:
+    """Shape / dtype bookkeeping of a host `b` operand: either a complex (2,)*n array or, in split
+    form, a real (2,)+(2,)*n array [re, im].  Validation errors match the reference's wording
+    (dot.py:197-214) because its tests look for them."""
+
+    def __init__(self, b, split):
+        self.given = b
+        self.arr = np.asarray(b, order='C')
+        self.copied = self.arr is not b
+        self.split = bool(split)
+        if self.split:
+            if self.arr.shape[0] != 2:
+                raise ValueError("'b' is in the wrong format.")
+            if np.iscomplexobj(self.arr):
+                raise ValueError("'b' is expected to be real.")
+        self.shape = tuple(self.arr.shape[1:] if self.split else self.arr.shape)
+        self.n = len(self.shape)
+        self.real_type = np.dtype(self.arr.dtype if self.split else np.empty(0, self.arr.dtype).real.dtype)
+        self.complex_type = np.result_type(self.real_type, np.complex64)
+
+    def binary(self):
+        return all(d == 2 for d in self.shape)
+
+    def planes(self, inplace, alignment):
+        """(2, 2^n)-shaped view of 32-byte aligned planes holding the operand, and whether that is
+        the caller's own memory."""
+        if self.split:
+            b = self.arr
+            second = b.ctypes.data + (1 << self.n) * b.itemsize
+            usable = (inplace or self.copied) and b.flags.c_contiguous and b.flags.writeable
+            if usable and b.ctypes.data % 32 == 0 and second % 32 == 0:
+                return b, True
+            mine = aligned_empty(b.shape, self.real_type, alignment)
+            mine[...] = b
+            return mine, False
+        mine = aligned_empty((2,) + self.shape, self.real_type, alignment)
+        mine[0], mine[1] = self.arr.real, self.arr.imag
+        return mine, False
+
+
+def _numpy_dot(a, op, axes):
+    """The explicit ``force_numpy=True`` route: the target axes are brought to the front, flattened
+    into the row index of a matrix product, and put back."""
+    b = op.arr[0] + 1j * op.arr[1] if op.split else op.arr
+    order = list(axes) + [i for i in range(op.n) if i not in axes]
+    rows = np.transpose(b, order).reshape(a.shape[-1], -1)
+    out = np.dot(a, rows).reshape([op.shape[i] for i in order])
+    out = np.transpose(out, np.argsort(order))
+    return np.array([out.real, out.imag]) if op.split else out
+
+
 def dot(a, b, axes_b=None, b_as_complex_array=False, inplace=False, backend='numpy', **kwargs):
     """Apply the square matrix `a` to the axes `axes_b` of `b` (all of dimension 2).
 
     `b` is either a complex array of shape (2,)*n or, with ``b_as_complex_array=True``, a
-    real array of shape (2,)+(2,)*n holding [re, im].  ``a``'s index has ``axes_b[0]`` as
-    most significant bit (dot.py:214: ``pos = b_ndim - axes_b[::-1] - 1``)."""
+    real array of shape (2,)+(2,)*n holding [re, im] -- or a torch CUDA tensor in that split
+    form, which is updated in HBM.  ``a``'s index has ``axes_b[0]`` as most significant bit
+    (dot.py:214: ``pos = b_ndim - axes_b[::-1] - 1``)."""
     if backend != 'numpy':
         raise ValueError(f"Backend {backend} is not supported.")
-    kwargs.setdefault('out', None)
-    kwargs.setdefault('force_numpy', False)
-    kwargs.setdefault('raise_if_hcore_fails', False)
-    kwargs.setdefault('swap_back', True)
-    kwargs.setdefault('alignment', 32)
+    opt = {**_DOT_DEFAULTS, **kwargs}
     if axes_b is None:
-        return np.dot(a, b, out=kwargs['out'])
-
+        return np.dot(a, b, out=opt['out'])
     a = np.asarray(a, order='C')
-    axes_b = np.asarray(axes_b)
+    axes = [int(x) for x in np.asarray(axes_b).reshape(-1)]
+    wrap = (lambda r: r) if opt['swap_back'] is True else (lambda r: (r, None))  # no swaps are ever pending
 
-    # device-resident split planes: in-place update in HBM
-    if _is_cuda_tensor(b):
+    if _is_cuda_tensor(b):  # device-resident split planes: in-place update in HBM
         if not b_as_complex_array or b.shape[0] != 2:
             raise ValueError("CUDA tensors must be split planes: shape (2,)+(2,)*n, b_as_complex_array=True")
-        b_ndim = b.dim() - 1
-        if any(axes_b >= b_ndim):
+        n = b.dim() - 1
+        if any(x >= n for x in axes):
             raise IndexError("Index not in 'b'")
-        pos = (b_ndim - axes_b[::-1] - 1).astype('uint32')
         planes = b if inplace else b.clone()
         flat = planes.reshape(2, -1)
-        core.apply_U(flat[0], flat[1], a, pos, b_ndim)
-        return planes if kwargs['swap_back'] else (planes, None)
+        core.apply_U(flat[0], flat[1], a, [n - 1 - x for x in reversed(axes)], n)
+        return wrap(planes)
 
-    _b_orig = b
-    b = np.asarray(b, order='C')
-    _new_b = b is not _b_orig
-    a_ndim = a.ndim
-    b_ndim = b.ndim - (1 if b_as_complex_array else 0)
-    a_shape = np.asarray(a.shape)
-    b_shape = np.asarray(b.shape[:len(b.shape) - (1 if b_as_complex_array else 0)]) if not b_as_complex_array \
-        else np.asarray(b.shape[1:])
-    real_type = b.dtype if b_as_complex_array else np.real(np.array([1], dtype=b.dtype)).dtype
-    complex_type = (1j * np.array([1], dtype=real_type)).dtype
-    if b_as_complex_array:
-        if b.shape[0] != 2:
-            raise ValueError("'b' is in the wrong format.")
-        if np.iscomplexobj(b):
-            raise ValueError("'b' is expected to be real.")
-    if any(axes_b >= b_ndim):
+    op = _HostOperand(b, b_as_complex_array)
+    if any(x >= op.n for x in axes):
         raise IndexError("Index not in 'b'")
-    if a_shape[-1] != np.prod(b_shape[axes_b]):
+    if a.shape[-1] != int(np.prod([op.shape[x] for x in axes])):
         raise ValueError("'a' and 'b' are incompatible.")
-    pos = (b_ndim - axes_b[::-1] - 1).astype('uint32')
 
-    use_core = not kwargs['force_numpy']
-    use_core &= np.dtype(real_type) in _FLOAT_TYPES
-    use_core &= a_ndim == 2 and a_shape[0] == a_shape[1]
-    use_core &= bool(all(x == 2 for x in b_shape))
-    use_core &= len(axes_b) <= 10 and len(set(axes_b.tolist())) == len(axes_b)
-    if not use_core and not kwargs['force_numpy'] and kwargs['raise_if_hcore_fails']:
-        raise AssertionError("Cannot use HybridQ core.")
-
-    if use_core:
-        if a.dtype != complex_type:
-            warn(f"'a' is recast to '{complex_type}' to match 'b'.")
-            a = a.astype(complex_type)
-        n_amp = 1 << b_ndim
-        if b_as_complex_array:
-            aligned = b.ctypes.data % 32 == 0 and (b.ctypes.data + n_amp * b.itemsize) % 32 == 0
-            if (inplace or _new_b) and aligned and b.flags.c_contiguous and b.flags.writeable:
-                planes = b
-            else:
-                planes = aligned_empty(b.shape, real_type, kwargs['alignment'])
-                planes[...] = b
-        else:
-            planes = aligned_empty((2,) + b.shape, real_type, kwargs['alignment'])
-            planes[0] = np.real(b)
-            planes[1] = np.imag(b)
-        flat = planes.reshape(2, -1)
-        core.apply_U(flat[0], flat[1], a, pos, b_ndim)
-        res = planes if b_as_complex_array else to_complex(planes[0], planes[1])
-        if b_as_complex_array and inplace and planes is not b:
-            _b_orig[...] = planes  # honour inplace for unaligned / non-contiguous inputs
-            res = _b_orig
-        return res if kwargs['swap_back'] is True else (res, None)
-
-    if not kwargs['force_numpy']:
+    in_domain = (op.real_type in _FLOAT_TYPES and a.ndim == 2 and a.shape[0] == a.shape[1] and op.binary()
+                 and len(axes) <= 10 and len(set(axes)) == len(axes))
+    if opt['force_numpy']:
+        return _numpy_dot(a, op, axes)
+    if not in_domain:
+        if opt['raise_if_hcore_fails']:
+            raise AssertionError("Cannot use HybridQ core.")
         # The reference warns and falls back to numpy here (dot.py:332-335).  This package has no
         # implicit CPU path: inputs outside the HIP core's domain are an error unless the caller
         # asks for numpy explicitly.
         raise NotImplementedError(
             "dot: input outside the HIP core's domain (needs all axes of dimension 2, a square matrix, "
             "float32/float64 planes, <= 10 target axes); pass force_numpy=True for the numpy path")
-    if b_as_complex_array:
-        b = np.reshape(b[0] + 1j * b[1], b_shape)
-    perm = axes_b.tolist() + [x for x in range(b_ndim) if x not in axes_b]
-    bb = np.reshape(np.transpose(b, perm), (int(np.prod(b_shape[axes_b])), -1))
-    inv = [perm.index(x) for x in range(len(perm))]
-    bb = np.transpose(np.reshape(np.dot(a, bb), b_shape), inv)
-    return np.array([np.real(bb), np.imag(bb)]) if b_as_complex_array else bb
+
+    if a.dtype != op.complex_type:
+        warn(f"'a' is recast to '{op.complex_type}' to match 'b'.")
+        a = a.astype(op.complex_type)
+    planes, own = op.planes(inplace, opt['alignment'])
+    flat = planes.reshape(2, -1)
+    core.apply_U(flat[0], flat[1], a, [op.n - 1 - x for x in reversed(axes)], op.n)
+    if not op.split:
+        return wrap(to_complex(planes[0], planes[1]))
+    if inplace and not own:  # honour inplace for unaligned / non-contiguous inputs
+        op.given[...] = planes
+        return wrap(op.given)
+    return wrap(planes)

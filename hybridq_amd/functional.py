@@ -12,6 +12,8 @@ import numpy as np
 
 from . import core
 
+MAX_MARGINAL_QUBITS = 10  # hq_probabilities_* bins 2^k outcomes in LDS, k <= 10
+
 
 class Projection:
     """Project `qubits` onto the computational-basis `state` ('0'/'1' per qubit)."""
@@ -33,7 +35,11 @@ class Projection:
         want = int(self.state, 2)
         scale = 1.0
         if self.renormalize:
-            p = core.probabilities(st.planes[0], st.planes[1], pos, st.n)[want]
+            if len(pos) <= MAX_MARGINAL_QUBITS:
+                p = core.probabilities(st.planes[0], st.planes[1], pos, st.n)[want]
+            else:  # wider than the marginal kernel: project first, the surviving weight is the norm
+                core.project(st.planes[0], st.planes[1], pos, want, 1.0, st.n)
+                p = core.norm2(st.planes[0], st.planes[1])
             norm = np.sqrt(p)
             if norm <= self.atol:  # projection.py:58-66: nothing survives -> all zeros
                 core.project(st.planes[0], st.planes[1], pos, want, 0.0, st.n)
@@ -54,6 +60,9 @@ class Measure:
 
     def probabilities(self, st):
         pos = [st.map[q] for q in reversed(self.qubits)]
+        if len(pos) > MAX_MARGINAL_QUBITS:
+            raise ValueError(f'probabilities of more than {MAX_MARGINAL_QUBITS} qubits are not tabulated; '
+                             'apply_device() measures wider sets chunk by chunk')
         return core.probabilities(st.planes[0], st.planes[1], pos, st.n)
 
     def sample(self, probs):
@@ -64,7 +73,24 @@ class Measure:
 
     def apply_device(self, st):
         pos = [st.map[q] for q in reversed(self.qubits)]
-        probs = core.probabilities(st.planes[0], st.planes[1], pos, st.n)
-        self.outcome = self.sample(probs)
-        scale = 1.0 / np.sqrt(probs[self.outcome]) if self.renormalize else 1.0
-        core.project(st.planes[0], st.planes[1], pos, self.outcome, scale, st.n)
+        if len(pos) <= MAX_MARGINAL_QUBITS:
+            probs = core.probabilities(st.planes[0], st.planes[1], pos, st.n)
+            self.outcome = self.sample(probs)
+            scale = 1.0 / np.sqrt(probs[self.outcome]) if self.renormalize else 1.0
+            core.project(st.planes[0], st.planes[1], pos, self.outcome, scale, st.n)
+            return
+        # More qubits than the marginal kernel bins (2^10): measure them chunk by chunk.  The
+        # marginal of the next chunk on the state already projected (NOT renormalised) onto the
+        # earlier outcomes is the joint probability, so sampling from it normalised is sampling the
+        # conditional distribution: the same joint law as one draw over 2^k outcomes.
+        outcome, joint = 0, 1.0
+        for lo in range(0, len(pos), MAX_MARGINAL_QUBITS):
+            chunk = pos[lo:lo + MAX_MARGINAL_QUBITS]
+            probs = core.probabilities(st.planes[0], st.planes[1], chunk, st.n)
+            o = self.sample(probs)
+            joint = probs[o]
+            core.project(st.planes[0], st.planes[1], chunk, o, 1.0, st.n)
+            outcome |= o << lo
+        self.outcome = outcome
+        if self.renormalize:
+            core.project(st.planes[0], st.planes[1], pos, outcome, 1.0 / np.sqrt(joint), st.n)

@@ -50,12 +50,13 @@ def commute(U1, q1, U2, q2, atol=1e-7):
 
 
 class _Layer:
-    __slots__ = ('gates', 'qubits', 'U')
+    __slots__ = ('gates', 'qubits', 'U', 'compress')
 
-    def __init__(self, U, qs):
+    def __init__(self, U, qs, compress=True):
         self.gates = [(U, qs)]
         self.qubits = _sorted_union(qs, ())
         self.U = _embed(U, qs, self.qubits)
+        self.compress = compress  # False: nothing may be merged into this layer (utils.py:615-617)
 
     def merge(self, U, qs):
         self.gates.append((U, qs))
@@ -65,15 +66,17 @@ class _Layer:
         self.qubits = Q
 
 
-def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol):
+def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits=()):
     layers = []
+    exclude = set(exclude_qubits or ())
     for U, qs in gates:
         q = set(qs)
+        can = not (q & exclude)  # gates on `exclude_qubits` are never compressed (utils.py:615-617)
         merge_to = len(layers)
         for i in range(len(layers) - 1, -1, -1):
             L = layers[i]
             cq = set(L.qubits)
-            if len(q | cq) <= max(max_n_qubits, len(cq), len(q)):  # utils.py:626-630
+            if can and L.compress and len(q | cq) <= max(max_n_qubits, len(cq), len(q)):  # utils.py:626-630
                 merge_to = i
             if use_matrix_commutation:  # utils.py:633-646
                 if not (q & cq):
@@ -84,17 +87,19 @@ def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matr
         if merge_to < len(layers):
             layers[merge_to].merge(U, qs)
         else:
-            layers.append(_Layer(U, qs))
+            layers.append(_Layer(U, qs, can))
     return layers
 
 
-def compress(gates, max_n_qubits=4, use_matrix_commutation=True, max_n_qubits_matrix=10, atol=1e-7):
+def compress(gates, max_n_qubits=4, use_matrix_commutation=True, max_n_qubits_matrix=10, atol=1e-7,
+             exclude_qubits=None):
     """Group `gates` ([(U, qubits), ...]) into layers like hybridq's ``utils.compress``.
     Returns a list of layers, each a list of the original gates in application order."""
     gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
     if max_n_qubits is None or max_n_qubits <= 0:  # utils.py:565-566
         return [[g] for g in gates]
-    return [L.gates for L in _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol)]
+    return [L.gates for L in _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol,
+                                           exclude_qubits)]
 
 
 def to_matrix_gate(layer, complex_type='complex64'):
@@ -110,14 +115,14 @@ def to_matrix_gate(layer, complex_type='complex64'):
 
 
 def fuse(gates, max_n_qubits=4, complex_type='complex64', use_matrix_commutation=True,
-         max_n_qubits_matrix=10, atol=1e-7):
+         max_n_qubits_matrix=10, atol=1e-7, exclude_qubits=None):
     """compress + to_matrix_gate in one go: the fused gate stream ``_simulate_evolution``
     hands to the core (simulation.py:436-454).  Layer matrices are accumulated in
     complex128 and cast once."""
     gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
     if max_n_qubits is None or max_n_qubits <= 0:
         return [(U.astype(complex_type), qs) for U, qs in gates]
-    layers = _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol)
+    layers = _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits)
     return [(L.U.astype(complex_type), tuple(L.qubits)) for L in layers]
 
 

@@ -26,6 +26,7 @@ import numpy as np
 from . import core
 
 _FLOAT_OF = {np.dtype('complex64'): np.dtype('float32'), np.dtype('complex128'): np.dtype('float64')}
+MAX_GATE_QUBITS = 10  # kMaxK of the HIP core (apply_U rejects n_pos > 10; reference dot.py:236)
 
 
 class FunctionalGate:
@@ -89,14 +90,17 @@ def alloc_planes(n, torch_dtype, device):
     torch = _torch()
     itemsize = torch.empty((), dtype=torch_dtype).element_size()
     pad = PLANE_PAD_BYTES // itemsize if n >= 12 else 0
-    raw = torch.empty((2, (1 << n) + pad), dtype=torch_dtype, device=device)
+    # the row stride stays a multiple of 32 bytes for the tiniest states too (n <= 2 in complex64,
+    # n <= 1 in complex128: 2^n elements alone are shorter than the alignment apply_U checks)
+    stride = -(-((1 << n) + pad) * itemsize // 32) * 32 // itemsize
+    raw = torch.empty((2, stride), dtype=torch_dtype, device=device)
     return raw[:, :1 << n]
 
 
 def prepare_state_planes(initial_state, n, float_type, device):
     """Planes for an initial state given as a '01+-' string (hybridq/circuit/simulation/
-    utils.py:41-156) or as an array of 2^n amplitudes.  Basis and all-'+' states are
-    written by a device kernel; anything else is built on the host and uploaded."""
+    utils.py:41-156) or as an array of 2^n amplitudes.  Strings are written by device kernels
+    (basis, uniform, and the mixed '01+-' product state); arrays are uploaded."""
     torch = _torch()
     tdt = {np.dtype('float32'): torch.float32, np.dtype('float64'): torch.float64}[float_type]
     planes = alloc_planes(n, tdt, device)
@@ -113,6 +117,9 @@ def prepare_state_planes(initial_state, n, float_type, device):
             return planes
         if all(c == '+' for c in s):
             core.init_state(planes[0], planes[1], 'plus')
+            return planes
+        if n >= 2:  # mixed '01+-': one device pass, no 2^n host array (label x <-> bit n-1-x)
+            core.init_product_state(planes[0], planes[1], {n - 1 - x: c for x, c in enumerate(s)})
             return planes
         vec = np.ones(1, dtype=np.float64)
         single = {'0': [1, 0], '1': [0, 1], '+': [2**-0.5, 2**-0.5], '-': [2**-0.5, -2**-0.5]}
@@ -143,7 +150,7 @@ class EvolutionState:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.map = {q: self.n - x - 1 for x, q in enumerate(self.qubits)}  # simulation.py:512
         with torch.cuda.device(self.device):
-            core.set_stream(torch.cuda.current_stream().cuda_stream)
+            core.use_torch_stream()
             self.planes = prepare_state_planes(initial_state, self.n, self.float_type, self.device)
 
     @property
@@ -155,6 +162,7 @@ class EvolutionState:
         return self.planes[1]
 
     def apply(self, U, qubits):
+        core.use_torch_stream()
         pos = [self.map[q] for q in reversed(qubits)]  # simulation.py:633
         core.apply_U(self.planes[0], self.planes[1], U, pos, self.n)
 
@@ -163,6 +171,7 @@ class EvolutionState:
         (2,)+(2,)*n real array and the current qubit order.  Reference functional gates are
         host numpy code, so the state makes a D2H/H2D round trip here (rare; device-side
         projection/measurement are the "next" row of SURVEY 8f)."""
+        core.use_torch_stream()
         if callable(getattr(gate, 'apply_device', None)):
             gate.apply_device(self)
             return
@@ -187,6 +196,7 @@ class EvolutionState:
         gates = _plan_ops(list(circuit), self.qubits, self.n, self.complex_type, compress, blocked)
         if any(_is_functional(g) for g in gates):
             raise ValueError('functional gates cannot be compiled')
+        core.use_torch_stream()
         prog = core.Program()
         with prog:
             _execute_ops(self, gates)
@@ -197,11 +207,13 @@ class EvolutionState:
         """Interleave the planes into a complex torch tensor on the device (:669-675)."""
         torch = _torch()
         cdt = {np.dtype('complex64'): torch.complex64, np.dtype('complex128'): torch.complex128}[self.complex_type]
+        core.use_torch_stream()
         out = torch.empty(1 << self.n, dtype=cdt, device=self.device)
         core.to_complex(self.planes[0], self.planes[1], out)
         return out
 
     def norm2(self):
+        core.use_torch_stream()
         return core.norm2(self.planes[0], self.planes[1])
 
 
@@ -234,6 +246,14 @@ def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
     never fused (skip_compression=[FunctionalGate], :441) -- the circuit is cut at them."""
     comp_kw = {k: v for k, v in compress.items() if k != 'max_n_qubits'} if isinstance(compress, dict) else {}
     comp_n = compress.get('max_n_qubits', 4) if isinstance(compress, dict) else compress
+    # checked BEFORE any planning work: the core applies gates of up to MAX_GATE_QUBITS qubits, and only
+    # these keys of the reference's utils.compress have a counterpart in fusion.fuse
+    if comp_n and comp_n > MAX_GATE_QUBITS:
+        raise ValueError(f"compress={comp_n}: fused gates are limited to {MAX_GATE_QUBITS} qubits by the HIP core")
+    unknown = set(comp_kw) - {'use_matrix_commutation', 'max_n_qubits_matrix', 'atol', 'exclude_qubits'}
+    if unknown:
+        raise ValueError(f"unsupported 'compress' option(s) {sorted(unknown)}: FunctionalGates are never compressed "
+                         "here (the reference's skip_compression default), other skip lists have no counterpart")
     use_blocked = bool(blocked) and n >= 14
     pos_of = {q: n - x - 1 for x, q in enumerate(qubits)}  # simulation.py:512 (never permuted here)
     gates, run = [], []
@@ -270,6 +290,7 @@ def _execute_ops(state, gates):
     """The gate loop (simulation.py:522-646); returns the number of passes over the state."""
     n = state.n
     n_passes = 0
+    core.use_torch_stream()
     for g in gates:
         if _is_functional(g):
             state.apply_functional(g)

@@ -123,9 +123,21 @@ int hq_init_state_float32(float *psi_re, float *psi_im, unsigned int n_qubits, i
 int hq_init_state_float64(double *psi_re, double *psi_im, unsigned int n_qubits, int kind,
                           uint64_t basis);
 
+/* Product states of '0' / '1' / '+' / '-' factors written on the device (the mixed-string branch of
+ * prepare_state, hybridq/circuit/simulation/utils.py:115-153, which builds a 2^n kron on the
+ * host): with X = hi_bits | x for the local index x in [0, 2^n_local),
+ *   re[x] = ((X & mask01) == val01) ? (-1)^popcount(X & mask_minus) * 2^(-n_pm/2) : 0,  im[x] = 0.
+ * mask01 / val01: index bits holding a '0'/'1' character and their values; mask_minus: bits holding
+ * '-'; n_pm: number of '+' and '-' characters.  hi_bits = 0 on one GPU; rank << n_local for the
+ * shard of a multi-GPU state.  Device pointers only, n_local >= 2. */
+int hq_init_product_state_float32(float *psi_re, float *psi_im, unsigned int n_local, uint64_t hi_bits,
+                                  uint64_t mask01, uint64_t val01, uint64_t mask_minus, unsigned int n_pm);
+int hq_init_product_state_float64(double *psi_re, double *psi_im, unsigned int n_local, uint64_t hi_bits,
+                                  uint64_t mask01, uint64_t val01, uint64_t mask_minus, unsigned int n_pm);
+
 /* Out-of-place permutation of ARBITRARY index bits of an array of 2^n 4-byte
  * (_32) or 8-byte (_64) elements: dst[x] = src[pi(x)], where bit i of x moves to
- * bit perm[i] of pi(x) (perm = a permutation of 0..n-1, at most 16 moved bits).
+ * bit perm[i] of pi(x) (perm = a permutation of 0..n-1, any number of moved bits).
  * Generalises swap_* (low bits only, in place) to the whole index; the multi-GPU
  * driver uses it to bring qubits into the exchange slots.  Device pointers only. */
 int hq_permute_bits_32(const void *src, void *dst, const unsigned int *perm, unsigned int n);

@@ -93,7 +93,8 @@ def _initial(initial_state, n, dtype):
 
 def evolve_reference_protocol(lib, gates, n=None, initial_state=None, qubits=None,
                               complex_type='complex64', trace=None, log2_pack_size=None,
-                              planes=None, max_seconds=None, warmup_gates=0, to_complex=True):
+                              planes=None, max_seconds=None, warmup_gates=0, to_complex=True,
+                              checkpoints=None):
     """Replay the reference driver loop (simulation.py:491-675) on `lib`.
 
     Returns (psi_complex, info) with info['runtime (s)'] measured like the
@@ -106,7 +107,11 @@ def evolve_reference_protocol(lib, gates, n=None, initial_state=None, qubits=Non
     clock starts (page faults, thread pool); `max_seconds` = stop after the first gate
     that crosses this budget (info['n_gates'] says how many were timed; the final
     restore is then skipped and the state is NOT the circuit's final state);
-    `to_complex=False` skips the interleave and returns the planes."""
+    `to_complex=False` skips the interleave and returns the planes.
+
+    `checkpoints`: iterable of gate counts; info['checkpoints'][c] is the state (canonical qubit
+    order, complex) after the first c gates -- taken on a COPY of the planes brought back to
+    canonical order with the same final un-permute the loop ends with (:655-663)."""
     complex_type = np.dtype(complex_type)
     ft = np.dtype('float32') if complex_type == np.dtype('complex64') else np.dtype('float64')
     qubits = all_qubits(gates, qubits)
@@ -128,7 +133,22 @@ def evolve_reference_protocol(lib, gates, n=None, initial_state=None, qubits=Non
     t0 = time.perf_counter()
     n_timed = 0
     truncated = False
+    want_cp = set(int(c) for c in checkpoints) if checkpoints is not None else set()
+    snapshots = {}
+
+    def snapshot(count):
+        order = [_inv.index(q) for q in reversed(qubits)][:max_swap]
+        cre, cim = aligned_empty(re.shape, ft), aligned_empty(im.shape, ft)
+        cre[...] = re
+        cim[...] = im
+        if order:
+            lib.swap(cre, order, n)
+            lib.swap(cim, order, n)
+        snapshots[count] = lib.to_complex(cre, cim)
+
     for gi, (U, qs) in enumerate(gates):
+        if gi in want_cp:
+            snapshot(gi)
         if gi == warmup_gates and warmup_gates:
             t0 = time.perf_counter()
             n_timed = 0
@@ -166,6 +186,8 @@ def evolve_reference_protocol(lib, gates, n=None, initial_state=None, qubits=Non
             trace.append(('S', list(order)))
     t1 = time.perf_counter()
     info = {'runtime (s)': t1 - t0, 'n_gates': n_timed, 'truncated': truncated}
+    if checkpoints is not None:
+        info['checkpoints'] = snapshots
     if not to_complex:
         return planes, info
     psi = lib.to_complex(re, im)  # :669-675

@@ -7,7 +7,7 @@
  * (hybridq_amd/) never links, imports or falls back to it.
  *
  * Parity pin: checked against (a) the reference C++ core compiled from
- * /root/reference/include/python_{U,swap}.cpp into oracle/_ref/ (tests/test_oracle_vs_ref.py,
+ * /root/reference/include/python_{U,swap}.cpp into oracle/_ref/ (tests/test_oracle.py,
  * only where /root/reference exists) and (b) the committed golden vectors under
  * tests/golden/ which were produced by that compiled reference and by the
  * reference's Python driver (tests/golden/make_golden.py).

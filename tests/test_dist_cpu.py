@@ -42,6 +42,16 @@ class CpuBackend:
         planes[0].fill_(value)
         planes[1].zero_()
 
+    def fill_product(self, planes, chars_by_position, hi_bits):
+        m = int(planes.shape[1]).bit_length() - 1
+        x = np.arange(1 << m, dtype=np.int64) | int(hi_bits)
+        v = np.ones(1 << m)
+        for p, ch in chars_by_position.items():
+            bit = (x >> p) & 1
+            v *= {'0': 1 - bit, '1': bit, '+': np.full(1 << m, 2**-0.5), '-': (1 - 2 * bit) * 2**-0.5}[ch]
+        planes[0].copy_(self.torch.from_numpy(v.astype(self.float_type)))
+        planes[1].zero_()
+
     def apply(self, planes, U, pos, m):
         assert self.lib.apply_U(planes[0].numpy(), planes[1].numpy(), U, pos, m) == 0
 
@@ -97,8 +107,8 @@ def _worker(rank, world, port, n, seed, ct, out_dir):
         psi = sh.state_numpy()
         n_x = sum(1 for op in sched if op[0] == 'X')
         n_p = sum(1 for op in sched if op[0] == 'P')
-        # second circuit from the permuted placement + '+' initial state
-        sh2 = ShardedEvolution(n, complex_type=ct, initial_state='+' * n, backend=CpuBackend(ft))
+        # second circuit from the permuted placement + a mixed '01+-' initial state
+        sh2 = ShardedEvolution(n, complex_type=ct, initial_state=('-+10+' * n)[:n], backend=CpuBackend(ft))
         g2 = random_dense(n, 25, kmax=3, seed=seed + 2)
         sh2.simulate(g2[:12])
         sh2.simulate(g2[12:])  # re-planned from a non-identity map
@@ -150,7 +160,7 @@ def test_sharded_matches_single_process(tmp_path, world, n, ct):
     assert np.abs(out['psi4'] - exp).max() / np.abs(exp).max() < tol  # blocked local passes
     assert (int(out['nb']) >= 1) == (n - int(np.log2(world)) >= 14)
     g2 = random_dense(n, 25, kmax=3, seed=seed + 2)
-    exp2 = oracle.evolve_tensordot(g2, n, initial_state=np.full(1 << n, 2.0**(-n / 2)))
+    exp2 = oracle.evolve_tensordot(g2, n, initial_state=('-+10+' * n)[:n], qubits=list(range(n)))
     assert np.abs(out['psi2'] - exp2).max() / np.abs(exp2).max() < tol
 
 

@@ -1,0 +1,221 @@
+"""GPU tests of the round-2 additions: tiny states through simulate() (plane alignment), device
+prepare_state for mixed '01+-' strings vs the reference's vectors, bit permutations with many
+moved bits, restore_order on the HIP backend, Measure / Projection on more than 10 qubits,
+QASM text -> simulate, stream switching, per-call parity directly against oracle/_ref."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from tolerances import BAR, circuit_tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('ct', ['complex64', 'complex128'])
+def test_simulate_tiny_states(torch_cuda, ct):
+    """n = 1..4 (a Bell pair is n = 2): the im plane of the single allocation must stay 32-byte
+    aligned (alloc_planes put it at base + 2^n * itemsize)."""
+    import oracle
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.dm import simulate as dm_simulate
+    from hybridq_amd.simulation import EvolutionState, simulate
+    h = np.array([[1, 1], [1, -1]]) / np.sqrt(2)
+    cx = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=complex)
+    bell = simulate([(h, (0,)), (cx, (0, 1))], initial_state='00', complex_type=ct, compress=0).reshape(-1)
+    assert np.abs(bell - np.array([1, 0, 0, 1]) / np.sqrt(2)).max() < BAR[np.dtype(ct)]
+    for n in (1, 2, 3, 4):
+        st = EvolutionState(list(range(n)), complex_type=ct, initial_state='0' * n)
+        assert st.planes[0].data_ptr() % 32 == 0 and st.planes[1].data_ptr() % 32 == 0
+        gates = random_dense(n, 12, kmax=min(n, 3), seed=n, unitary=True)
+        exp = oracle.evolve_tensordot(gates, n, qubits=list(range(n)))
+        for kw in (dict(compress=0), dict(compress=4)):
+            psi = simulate(gates, initial_state='0' * n, complex_type=ct, qubits=list(range(n)), **kw).reshape(-1)
+            assert np.abs(psi - exp).max() / np.abs(exp).max() < circuit_tol(gates, complex_type=ct), (n, kw)
+    # a 1-qubit density matrix = 2-qubit state vector
+    rho = dm_simulate([(h, (0,))], initial_state='0', complex_type=ct).reshape(2, 2)
+    assert np.abs(rho - 0.5).max() < BAR[np.dtype(ct)]
+
+
+def test_prepare_state_matches_reference_vectors(torch_cuda):
+    """prepare_state strings recorded from the reference (e2e_api.npz: '0', '1', '+', '-' mixes):
+    every amplitude, written by the device kernel."""
+    from hybridq_amd.simulation import EvolutionState
+    z = gu.load('e2e_api.npz')
+    strings = [str(s) for s in z['ps_strings']]
+    assert any(set(s) - set('01') and set(s) != {'+'} for s in strings)  # the mixed branch is covered
+    for i, s in enumerate(strings):
+        exp = z[f'ps_{i}']
+        for ct in ('complex64', 'complex128'):
+            st = EvolutionState(list(range(len(s))), complex_type=ct, initial_state=s)
+            got = st.to_complex().cpu().numpy()
+            assert np.abs(got - exp).max() <= (1e-7 if ct == 'complex64' else 1e-15) * max(1.0, np.abs(exp).max()), (s, ct)
+
+
+def test_prepare_state_mixed_large(torch_cuda):
+    """n = 28 mixed string: norm 1, zero outside the '0'/'1' pattern, signs from the '-' characters
+    (sampled), and the same state reached by applying H / X gates to |0...0> with the core."""
+    from hybridq_amd import core
+    from hybridq_amd.simulation import EvolutionState
+    n = 28
+    rng = np.random.default_rng(7)
+    s = ''.join(rng.choice(list('01+-'), size=n))
+    st = EvolutionState(list(range(n)), complex_type='complex64', initial_state=s)
+    assert abs(st.norm2() - 1.0) < 1e-6
+    ref = EvolutionState(list(range(n)), complex_type='complex64', initial_state='0' * n)
+    h = np.array([[1, 1], [1, -1]]) / np.sqrt(2)
+    x = np.array([[0, 1], [1, 0]])
+    for q, ch in enumerate(s):
+        if ch in '1-':
+            ref.apply(x, (q,))
+        if ch in '+-':
+            ref.apply(h, (q,))
+    ov = core.vdot(ref.planes[0], ref.planes[1], st.planes[0], st.planes[1])
+    assert abs(ov - 1.0) < 1e-5  # float32 H gates on 2^28 amplitudes
+
+
+def test_permute_bits_many_moved_bits(torch_cuda):
+    """hq_permute_bits with more than 16 moved bits (the cap made restore_order fail
+    at the target scale): full random permutations of 20..24 index bits, 4- and 8-byte elements."""
+    from hybridq_amd import core
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    for n, dt in ((20, torch.float32), (22, torch.float64), (24, torch.int32)):
+        for trial in range(3):
+            perm = rng.permutation(n) if trial else np.roll(np.arange(n), 7)  # trial 0: one long rotated field
+            src = torch.arange(1 << n, device='cuda').to(dt)
+            dst = torch.empty_like(src)
+            core.permute_bits(src, dst, perm, n)
+            core.sync()
+            x = np.arange(1 << n, dtype=np.int64)
+            y = np.zeros_like(x)
+            for i in range(n):
+                y |= ((x >> i) & 1) << int(perm[i])
+            assert (dst.cpu().numpy().astype(np.int64) == y).all(), (n, list(perm))
+
+
+def test_restore_order_hip_backend(torch_cuda):
+    """ShardedEvolution.restore_order() on the HIP backend with m = 21 local qubits (world = 1: the
+    permutation passes are the whole story) after a circuit that leaves a scrambled placement."""
+    import oracle
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.dist import ShardedEvolution
+    n = 21
+    gates = rqc_1q2q(n, depth=4, seed=2)
+    sh = ShardedEvolution(n, complex_type='complex64', initial_state='0' * n)
+    sh.simulate(gates)
+    rng = np.random.default_rng(0)  # scramble the placement the way evictions would
+    perm = rng.permutation(n)
+    sh.run([('P', np.asarray(perm, dtype=np.uint32))], update_map=False)
+    at = {p: q for q, p in sh.pos.items()}
+    sh.pos = {at[int(perm[i])]: i for i in range(n)}  # dst bit i <- src bit perm[i]
+    assert sum(sh.pos[q] != n - 1 - q for q in range(n)) > 16
+    sh.restore_order()
+    assert all(sh.pos[q] == n - 1 - q for q in range(n))
+    raw = sh.backend.to_numpy(sh.planes)
+    exp = oracle.evolve_tensordot(gates, n)
+    assert np.abs(raw[0] + 1j * raw[1] - exp).max() / np.abs(exp).max() < circuit_tol(gates)
+
+
+def test_measure_and_projection_wide(torch_cuda):
+    """More than 10 measured / projected qubits (hq_probabilities bins at most 2^10
+    outcomes): chunked measurement collapses onto ONE basis pattern with norm 1; a wide
+    Projection equals the numpy slice."""
+    import oracle
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.functional import Measure, Projection
+    from hybridq_amd.simulation import simulate
+    n = 16
+    gates = rqc_1q2q(n, depth=4, seed=9)
+    exp = oracle.evolve_tensordot(gates, n).reshape((2,) * n)
+    qs = tuple(int(q) for q in np.random.default_rng(1).permutation(n)[:13])
+    m = Measure(qs, rng=np.random.default_rng(5))
+    psi = simulate(gates + [m], initial_state='0' * n, complex_type='complex64', qubits=list(range(n)))
+    bits = [(m.outcome >> (len(qs) - 1 - i)) & 1 for i in range(len(qs))]  # qubits[0] = most significant bit
+    idx = [slice(None)] * n
+    for q, b in zip(qs, bits):
+        idx[q] = b
+    kept = exp[tuple(idx)]
+    assert np.linalg.norm(kept.ravel()) > 0
+    got = psi[tuple(idx)]
+    assert abs(np.linalg.norm(psi.ravel()) - 1) < 1e-5
+    assert abs(np.linalg.norm(got.ravel()) - 1) < 1e-5  # nothing survives outside the pattern
+    ref = kept / np.linalg.norm(kept.ravel())
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 10 * circuit_tol(gates)
+    state = ''.join(str(b) for b in bits)
+    for renorm in (True, False):
+        psi = simulate(gates + [Projection(state, qs, renormalize=renorm)], initial_state='0' * n,
+                       complex_type='complex64', qubits=list(range(n)))
+        want = np.zeros_like(exp)
+        want[tuple(idx)] = ref if renorm else kept
+        assert np.abs(psi - want).max() / np.abs(want).max() < 10 * circuit_tol(gates), renorm
+
+
+def test_qasm_text_to_gpu(torch_cuda):
+    """BASELINE cfg1 from TEXT: the gate-per-line QASM of examples/circuit_simple.qasm rebuilt from
+    the golden fixture's gate list -> hybridq_amd.qasm.from_qasm -> simulate, against the
+    reference's recorded amplitudes."""
+    from hybridq_amd.qasm import from_qasm
+    from hybridq_amd.simulation import simulate
+    z = gu.load('e2e_simple_qasm.npz')
+    n = int(z['n_qubits'])
+    lines = [str(n)]
+    for nm, qs in zip(z['gate_names'], z['gate_qubits']):
+        lines.append(' '.join([str(nm).lower()] + [str(int(q)) for q in qs if q >= 0]))
+    gates = from_qasm('\n'.join(['# rebuilt from e2e_simple_qasm.npz'] + lines))
+    assert len(gates) == len(z['gate_names'])
+    psi = simulate(gates, initial_state='0' * n, complex_type='complex64').reshape(-1)
+    stride = int(z['sample_stride'])
+    scale = np.abs(z['psi_sample']).max()
+    calls = [len(pos) for kind, pos, _ in gu.trace(z, 'trace_') if kind == 'U']
+    assert np.abs(psi[::stride] - z['psi_sample']).max() / scale < circuit_tol(calls, calls)
+    assert np.abs(psi[:8] - z['psi_head']).max() / scale < circuit_tol(calls, calls)
+
+
+def test_stream_switch_is_ordered(torch_cuda):
+    """Work issued under `with torch.cuda.stream(s)` after work on the default stream sees its
+    results (hq_set_stream makes the new stream wait on the device) and vice versa."""
+    import oracle
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import EvolutionState
+    torch = torch_cuda
+    n = 22
+    gates = rqc_1q2q(n, depth=6, seed=4)
+    st = EvolutionState(list(range(n)), complex_type='complex64', initial_state='0' * n)
+    side = torch.cuda.Stream()
+    for i, (U, qs) in enumerate(gates):
+        if (i // 7) % 2:
+            with torch.cuda.stream(side):
+                st.apply(U, qs)
+        else:
+            st.apply(U, qs)
+    psi = st.to_complex()
+    torch.cuda.synchronize()
+    exp = oracle.evolve_tensordot(gates, n)
+    assert np.abs(psi.cpu().numpy() - exp).max() / np.abs(exp).max() < circuit_tol(gates)
+
+
+def test_apply_U_directly_against_reference_core(torch_cuda, oracle_ref):
+    """Per-call parity of the HIP library against the reference's OWN compiled core (oracle/_ref;
+    the other per-call tests use the C port, itself pinned to _ref on CPU): k = 1..6, positions
+    >= 3 as the reference build requires (LOG2_PACK_SIZE = 3), both precisions."""
+    from hybridq_amd import core
+    from oracle.binding import aligned_empty
+    torch = torch_cuda
+    rng = np.random.default_rng(17)
+    for ft, n in (('float32', 18), ('float64', 16)):
+        ft = np.dtype(ft)
+        for k in range(1, 7):
+            for trial in range(3):
+                pos = 3 + rng.permutation(n - 3)[:k]
+                re = rng.standard_normal(1 << n).astype(ft)
+                im = rng.standard_normal(1 << n).astype(ft)
+                U = (rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k))) / np.sqrt(2.0 * (1 << k))
+                pl = aligned_empty((2, 1 << n), ft)
+                pl[0], pl[1] = re, im
+                assert oracle_ref.apply_U(pl[0], pl[1], U, pos, n) == 0
+                dre, dim_ = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+                core.apply_U(dre, dim_, U, pos, n)
+                core.sync()
+                scale = max(np.abs(pl[0]).max(), np.abs(pl[1]).max())
+                err = max(np.abs(dre.cpu().numpy() - pl[0]).max(), np.abs(dim_.cpu().numpy() - pl[1]).max()) / scale
+                assert err <= BAR[np.dtype('complex64' if ft == np.dtype('float32') else 'complex128')], (ft, k, list(pos), err)
