@@ -238,8 +238,8 @@ def main():
             sharded.pos = dict(sharded._planned_final_pos)
         pos_after_main = dict(sharded.pos)
         sharded.pos = pos0
-        n_exchanges = sum(1 for op in schedules[-1] if op[0] == 'X')
-        n_permutes = sum(1 for op in schedules[-1] if op[0] == 'P')
+        n_exchanges = sum(1 for op in schedules[-1] if op[0] in ('X', 'XP'))
+        n_permutes = sum(1 for op in schedules[-1] if op[0] in ('P', 'XP'))
         step_no = [0]
 
         class OpTimer:
@@ -367,7 +367,7 @@ def main():
                     'logical_amplitudes_per_s': len(gates) / elb * float(1 << n),
                     'blocked_passes_per_step': sum(1 for op in bsched[-1] if op[0] == 'B'),
                     'plain_gates_per_step': sum(1 for op in bsched[-1] if op[0] == 'G'),
-                    'exchanges_per_step': sum(1 for op in bsched[-1] if op[0] == 'X'),
+                    'exchanges_per_step': sum(1 for op in bsched[-1] if op[0] in ('X', 'XP')),
                 }
             result['exchange'] = {
                 'ms_per_exchange': 1e3 * tx,

@@ -135,6 +135,27 @@ _apply_blocked = {
     for b in (32, 64)
 }
 
+_shard_unique_id = _define_function(_lib, 'hq_shard_unique_id', ctypes.c_int, ctypes.c_void_p)
+_shard_init_rccl = _define_function(_lib, 'hq_shard_init_rccl', ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p)
+_shard_attach_rccl = _define_function(_lib, 'hq_shard_attach_rccl', ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint)
+_shard_init_p2p = _define_function(_lib, 'hq_shard_init_p2p', ctypes.c_int, ctypes.c_uint, ctypes.c_uint)
+_shard_p2p_register = _define_function(_lib, 'hq_shard_p2p_register', ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.POINTER(ctypes.c_void_p))
+_shard_info = _define_function(_lib, 'hq_shard_info', ctypes.c_int, ctypes.POINTER(ctypes.c_uint),
+                               ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_int))
+_shard_free = _define_function(_lib, 'hq_shard_free', ctypes.c_int)
+_ipc_export = _define_function(_lib, 'hq_ipc_export', ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                               ctypes.POINTER(ctypes.c_uint64))
+_ipc_open = _define_function(_lib, 'hq_ipc_open', ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
+                             ctypes.POINTER(ctypes.c_void_p))
+_ipc_close = _define_function(_lib, 'hq_ipc_close', ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64)
+_exchange = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_exchange_float{b}', ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint,
+                                            ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int))
+    for b in (32, 64)
+}
+
 _program_begin = _define_function(_lib, 'hq_program_begin', ctypes.c_int)
 _program_end = _define_function(_lib, 'hq_program_end', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p))
 _program_size = _define_function(_lib, 'hq_program_size', ctypes.c_int, ctypes.c_void_p)
@@ -153,6 +174,9 @@ EXPORTED = [
     'hq_probabilities_float32', 'hq_probabilities_float64', 'hq_project_float32', 'hq_project_float64',
     'hq_vdot_float32', 'hq_vdot_float64', 'hq_apply_blocked_float32', 'hq_apply_blocked_float64',
     'hq_program_begin', 'hq_program_end', 'hq_program_size', 'hq_program_run', 'hq_program_free',
+    'hq_shard_unique_id', 'hq_shard_init_rccl', 'hq_shard_attach_rccl', 'hq_shard_init_p2p', 'hq_shard_p2p_register',
+    'hq_shard_info', 'hq_shard_free', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
+    'hq_exchange_float32', 'hq_exchange_float64',
 ]
 
 
@@ -357,6 +381,71 @@ def vdot(a_re, a_im, b_re, b_im):
     rc = _vdot[ft](_ptr(a_re), _ptr(a_im), _ptr(b_re), _ptr(b_im), size, out)
     _check(rc, 'vdot')
     return complex(out[0], out[1])
+
+
+# --- multi-GPU shard exchange (include/hq_hip.h) -----------------------------------------------
+def shard_unique_id():
+    """128 opaque bytes from ncclGetUniqueId (rank 0 calls this and ships them to the others)."""
+    buf = ctypes.create_string_buffer(128)
+    _check(_shard_unique_id(buf), 'hq_shard_unique_id')
+    return bytes(buf.raw)
+
+
+def shard_init_rccl(world, rank, unique_id):
+    """Collective: creates this rank's RCCL communicator on the current device."""
+    buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+    _check(_shard_init_rccl(int(world), int(rank), buf), 'hq_shard_init_rccl')
+
+
+def shard_init_p2p(world, rank):
+    _check(_shard_init_p2p(int(world), int(rank)), 'hq_shard_init_p2p')
+
+
+def shard_p2p_register(local_plane, peer_addresses):
+    arr = (ctypes.c_void_p * len(peer_addresses))(*[int(a) for a in peer_addresses])
+    _check(_shard_p2p_register(_ptr(local_plane), arr), 'hq_shard_p2p_register')
+
+
+def shard_info():
+    w, r, t = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_int(0)
+    _shard_info(ctypes.byref(w), ctypes.byref(r), ctypes.byref(t))
+    return {'world': w.value, 'rank': r.value, 'transport': {0: None, 1: 'rccl', 2: 'p2p'}[t.value]}
+
+
+def shard_free():
+    _check(_shard_free(), 'hq_shard_free')
+
+
+def ipc_export(tensor):
+    """(64-byte handle, offset) of the allocation holding `tensor` (HIP IPC / dmabuf)."""
+    buf = ctypes.create_string_buffer(64)
+    off = ctypes.c_uint64(0)
+    _check(_ipc_export(_ptr(tensor), buf, ctypes.byref(off)), 'hq_ipc_export')
+    return bytes(buf.raw), int(off.value)
+
+
+def ipc_open(handle, offset):
+    """Device address, in THIS process, of the memory another process exported."""
+    buf = ctypes.create_string_buffer(bytes(handle), 64)
+    out = ctypes.c_void_p(None)
+    _check(_ipc_open(buf, int(offset), ctypes.byref(out)), 'hq_ipc_open')
+    return int(out.value)
+
+
+def exchange(src_re, src_im, dst_re, dst_im, perm=None, n_local=None):
+    """One qubit exchange (hq_exchange_*).  Returns True if the exchanged shard is in the SRC planes."""
+    ft = _float_dtype(src_re)
+    m = _n_qubits(src_re) if n_local is None else int(n_local)
+    pp = None
+    if perm is not None:
+        perm = np.ascontiguousarray(perm, dtype=np.uint32)
+        if len(perm) != m:
+            raise ValueError("'perm' must have one entry per local index bit")
+        pp = perm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    where = ctypes.c_int(0)
+    rc = _exchange[ft](_ptr(src_re), _ptr(src_im), _ptr(dst_re), _ptr(dst_im), m, pp, ctypes.byref(where))
+    _check(rc, 'exchange')
+    return bool(where.value)
 
 
 def pack_blocked(gates, complex_type='complex64'):

@@ -302,10 +302,29 @@ apply_mfma_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
 // contiguous run, whatever the positions.
 //   table layout: A4[(rb * NSTEP/G + s/G) * 64 + lane][s % G], G = 16 / sizeof(T).
 // ---------------------------------------------------------------------------------
-template <typename T, int KBITS, int VMASK, bool NT, int BLOCK>
+// Byte offset of register-digit load `ld` from the lane's base address: the OR of the digit
+// offsets it selects plus (im - re) when the plane is one of those digits.  Wave-uniform, built by
+// the host (it knows both plane pointers) and read through the scalar cache: the kernel keeps no
+// per-load address state in registers.
+struct BigOffsets { int64_t off[32]; };
+
+// PHASED = false: every wave loads / multiplies / stores in turn and the other resident waves cover
+//   its memory phases (k = 5: HBM-bound, 4 waves per SIMD fit).
+// PHASED = true (k = 6, matrix-core bound; BLOCK = 512 = two waves per SIMD): the two halves of the
+//   workgroup run in ANTI-PHASE, separated by workgroup barriers: while waves 0-3 (one per SIMD) are
+//   in their MFMA phase, waves 4-7 store their results and issue the loads of their next
+//   wave-iteration, then the roles swap.  A SIMD's matrix pipe always has exactly one wave feeding it
+//   and that wave's operands arrived a whole phase earlier.  Why it is needed (n = 30 knock-outs):
+//   MFMA phase alone 3.69 ms, memory phases alone 3.6 ms, two free-running waves 4.7 ms -- left
+//   alone the two waves of a SIMD share the pipe, finish together and then BOTH wait for HBM with
+//   the pipe idle (s_setprio did not break the symmetry: 4.72 vs 4.73 ms; two register sets in one
+//   wave did not either, 4.67 ms: vmcnt counts loads and stores in order, so a prefetch issued
+//   before the stores cannot be waited for without waiting for the stores' acknowledgement, and
+//   the register allocator copies the second set around the loop).
+template <typename T, int KBITS, int VMASK, bool NT, int BLOCK, bool PHASED>
 __global__ void __launch_bounds__(BLOCK)
 apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ A,
-                      const MfmaRoles ro, const uint64_t niter) {
+                      const MfmaRoles ro, const BigOffsets tab, const uint64_t niter) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char hq_big_smem[];
@@ -313,90 +332,146 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR, NA = KBITS - 1 - KV;
   constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS, NG = NSTEP / G;
   constexpr int FMASK = ~VMASK & (NCOMP - 1);
+  constexpr int NP = NRB / 2, NGRP = NG * NP;
+  static_assert(NL <= 32 && NRB >= 2, "shape");
   V* __restrict__ As = reinterpret_cast<V*>(hq_big_smem);
   {
     const V* __restrict__ Ag = reinterpret_cast<const V*>(A);
     for (int e = threadIdx.x; e < NRB * NG * 64; e += BLOCK) As[e] = Ag[e];
   }
   __syncthreads();
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar for the optimiser
   const unsigned q = lane >> 4, j = lane & 15;
-  V* __restrict__ pre = reinterpret_cast<V*>(re);
-  V* __restrict__ pim = reinterpret_cast<V*>(im);
-  const uint64_t lane_off = ((q & 1) ? (uint64_t)ro.q_off[0] : 0ull) | ((q & 2) ? (uint64_t)ro.q_off[1] : 0ull);
-  const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
   const V* __restrict__ Al = As + lane;
-  // address = per-lane plane base + (slot | uniform digit offset) + uniform plane step: only
-  // ONE per-lane 64-bit base stays live (2^NR hoisted per-load bases would spill for k = 6)
-  V* const base0 = lane_plane ? pim : pre;
-  const int64_t plane_step = pim - pre;
-  for (uint64_t it = (uint64_t)blockIdx.x * (BLOCK / 64) + wave; it < niter; it += (uint64_t)gridDim.x * (BLOCK / 64)) {
-    uint64_t v = it * 16 + j;
+  // address of load ld in iteration it = lane base (loop-invariant, per lane: plane of the q digit,
+  // q-digit offsets, the slot bits j spread over the non-digit index bits) + 16 * spread(it * 16)
+  // (wave-uniform, a handful of scalar ops per iteration) + tab.off[ld] (wave-uniform, scalar load)
+  auto spread = [&](uint64_t v) {
 #pragma unroll
     for (int m = 0; m < NA; ++m) {
       const uint64_t lo = (1ull << ro.pos[m]) - 1;
       v = ((v & ~lo) << 1) | (v & lo);
     }
-    v |= lane_off;
-    int64_t step_it = plane_step;
-    asm volatile("" : "+s"(step_it));  // not loop-invariant for the optimiser: no hoisted per-load bases
-    V x[NL];
+    return v;
+  };
+  const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
+  const uint64_t lane_vec = spread((uint64_t)j) | ((q & 1) ? (uint64_t)ro.q_off[0] : 0ull) | ((q & 2) ? (uint64_t)ro.q_off[1] : 0ull);
+  unsigned char* const lane_base = reinterpret_cast<unsigned char*>(lane_plane ? im : re) + 16 * lane_vec;
+
+  auto load_x = [&](V (&x)[NL], const uint64_t it) {
+    const int64_t it_off = (int64_t)(16 * spread(it * 16));
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
-      uint64_t o = 0;
-      unsigned pl = 0;
-#pragma unroll
-      for (int b = 0; b < NR; ++b)
-        if ((ld >> b) & 1) { o |= ro.r_off[b]; pl |= (ro.r_plane == b) ? 1u : 0u; }
-      V* ptr = base0 + (v | o) + (pl ? step_it : (int64_t)0);
+      V* ptr = reinterpret_cast<V*>(lane_base + (it_off + tab.off[ld]));
+#ifdef HQ_EXP_BIG_NOMEM  // experiment: MFMA phase alone
+      x[ld] = V{};
+      asm volatile("" : "+v"(x[ld]));
+#else
       x[ld] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+#endif
     }
+  };
+  // the store addresses are computed from an opaque copy of the iteration offset: shared with the
+  // loads they would be 2^NR live 64-bit values across the whole MFMA phase (spills at k = 6)
+  auto store_x = [&](V (&x)[NL], const uint64_t it) {
+    int64_t st_off = (int64_t)(16 * spread(it * 16));
+    asm volatile("" : "+s"(st_off));
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      V* ptr = reinterpret_cast<V*>(lane_base + (st_off + tab.off[ld]));
+#ifdef HQ_EXP_BIG_NOMEM
+      asm volatile("" ::"v"(x[ld]), "v"(ptr));
+#else
+      if (NT) __builtin_nontemporal_store(x[ld], ptr);
+      else *ptr = x[ld];
+#endif
+    }
+  };
+#ifdef HQ_EXP_BIG_NOMFMA  // experiment: memory phases alone
+#define HQ_BIG_MFMA(a_, b_, c_) (c_ + Acc{(a_) * (b_), 0, 0, 0})
+#else
+#define HQ_BIG_MFMA(a_, b_, c_) Mfma<T>::run(a_, b_, c_)
+#endif
+  // MFMA phase, software-pipelined: the operand reads of pair-group g+1 (two ds_read_b128: row blocks
+  // 2p and 2p+1 of one step group) are issued BEFORE the 2*G MFMAs of pair-group g, which alternate
+  // between the two accumulators (a 16x16x4 MFMA issues every 32 cycles but its result is only
+  // available after 40: back-to-back MFMAs on ONE accumulator lose a fifth of the pipe).  The
+  // pipeline runs across column blocks (the operand sequence repeats): only the first read of an
+  // iteration is exposed.  Alone this phase runs at 149 of 157 TFLOP/s (k = 6 knock-out).
+  auto compute = [&](V (&x)[NL]) {
+    V a0 = Al[0], a1 = Al[NG * 64];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf) {
       Acc acc[NRB];
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) acc[rb] = Acc{0, 0, 0, 0};
 #pragma unroll
-      for (int sg = 0; sg < NG; ++sg) {
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-          const V a4 = Al[(rb * NG + sg) * 64];
-#pragma unroll
-          for (int t = 0; t < G; ++t) {
-            const int s = sg * G + t;
-            const int ck = s & ((1 << KV) - 1), ld = s >> KV;
-            const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
-            acc[rb] = Mfma<T>::run(a4[t], x[ld][comp], acc[rb]);
-          }
+      for (int g = 0; g < NGRP; ++g) {
+        const int sg = g / NP, rb = 2 * (g % NP);
+        const int gn = (g + 1) % NGRP, sgn = gn / NP, rbn = 2 * (gn % NP);
+        V n0 = a0, n1 = a1;
+        if (g + 1 < NGRP || cf + 1 < NCB) {
+          n0 = Al[(rbn * NG + sgn) * 64];
+          n1 = Al[((rbn + 1) * NG + sgn) * 64];
         }
-        // keep the scheduler from hoisting the LDS reads of many step groups (k = 6 would spill)
-        if (KBITS >= 7) __builtin_amdgcn_sched_barrier(0);
-      }
-      // the inputs of this column block are dead: overwrite them with its results
+        __builtin_amdgcn_sched_barrier(0);  // the reads of the NEXT pair-group stay in front of ...
 #pragma unroll
-      for (int ld = 0; ld < NL; ++ld)
+        for (int t = 0; t < G; ++t) {
+          const int s = sg * G + t;
+          const int ck = s & ((1 << KV) - 1), ld = s >> KV;
+          const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+          acc[rb] = HQ_BIG_MFMA(a0[t], x[ld][comp], acc[rb]);
+          acc[rb + 1] = HQ_BIG_MFMA(a1[t], x[ld][comp], acc[rb + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // ... this pair-group's MFMAs, which wait for nothing
+        a0 = n0;
+        a1 = n1;
+      }
+      // the inputs of this column block are dead: overwrite them with its results.  The empty asm
+      // pins the merged vector in registers HERE: left alone, the optimiser keeps the results of every
+      // column block in their accumulator registers until the stores (4 x the accumulators live).
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld) {
 #pragma unroll
         for (int ck = 0; ck < (1 << KV); ++ck) {
           const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
           const int so = ck | (ld << KV);
           x[ld][comp] = acc[so >> 2][so & 3];
         }
+        if (NCB > 1) asm volatile("" : "+v"(x[ld]));
+      }
     }
-    // recompute the addresses for the stores (opaque copy of v: otherwise 2^NR address pairs
-    // stay live across the whole MFMA phase and the k = 6 variants spill)
-    uint64_t vs = v;
-    asm volatile("" : "+v"(vs));
-#pragma unroll
-    for (int ld = 0; ld < NL; ++ld) {
-      uint64_t o = 0;
-      unsigned pl = 0;
-#pragma unroll
-      for (int b = 0; b < NR; ++b)
-        if ((ld >> b) & 1) { o |= ro.r_off[b]; pl |= (ro.r_plane == b) ? 1u : 0u; }
-      V* ptr = base0 + (vs | o) + (pl ? step_it : (int64_t)0);
-      if (NT) __builtin_nontemporal_store(x[ld], ptr);
-      else *ptr = x[ld];
+  };
+#undef HQ_BIG_MFMA
+  const uint64_t stride = (uint64_t)gridDim.x * (BLOCK / 64);
+  uint64_t it = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
+  if constexpr (!PHASED) {
+    for (; it < niter; it += stride) {
+      V x[NL];
+      load_x(x, it);
+      compute(x);
+      store_x(x, it);
     }
+  } else {
+    static_assert(BLOCK == 512, "two waves per SIMD");
+    // every wave of the workgroup passes the same number of barriers: the trip count comes from
+    // the workgroup's FIRST wave; a wave whose iteration index runs past the end idles through
+    const uint64_t first = (uint64_t)blockIdx.x * (BLOCK / 64);
+    const uint64_t trips = first < niter ? (niter - first + stride - 1) / stride : 0;
+    const bool second = wave >= BLOCK / 128;  // waves w and w + 4 share a SIMD
+    V x[NL];
+    if (trips && it < niter) load_x(x, it);
+    if (trips && second) __builtin_amdgcn_s_barrier();  // the second half starts one phase late
+    for (uint64_t k = 0; k < trips; ++k) {
+      if (it < niter) compute(x);
+      __builtin_amdgcn_s_barrier();  // ---- phase switch: the partner half takes over the matrix pipe
+      if (it < niter) store_x(x, it);
+      it += stride;
+      if (k + 1 < trips && it < niter) load_x(x, it);  // in flight for a whole phase before its first use
+      __builtin_amdgcn_s_barrier();
+    }
+    if (trips && !second) __builtin_amdgcn_s_barrier();
   }
 }
 
@@ -1160,6 +1235,47 @@ permute_bits_kernel(const E* __restrict__ src, E* __restrict__ dst, const PermAr
 #pragma unroll 4
     for (unsigned i = 0; i < pa.nfields; ++i) y |= ((x >> pa.from[i]) & ((1ull << pa.len[i]) - 1)) << pa.to[i];
     *reinterpret_cast<Pack*>(dst + x) = *reinterpret_cast<const Pack*>(src + y);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// exchange_pack: the local half of the multi-GPU qubit exchange.  The shard (2^m elements per
+// plane) is cut into G = 2^g chunks by its top g LOCAL index bits; chunk j belongs to rank j after
+// the exchange.  One pass reads the plane(s) through an optional local bit permutation (the
+// eviction that brings the outgoing qubits to the top g bits -- folded in here instead of a pass
+// of its own) and writes every chunk to its own destination base:
+//   * RCCL transport: dst[j] = slot j of the local send buffer (then ncclSend / ncclRecv);
+//   * peer-to-peer transport: dst[j] = slot `rank` of rank j's receive buffer, mapped through HIP
+//     IPC -- the stores travel over xGMI and no second pass exists at all.
+// Both planes in one launch (planes = 2) or one plane per launch (so that the transfer of the first
+// plane overlaps the packing of the second).
+// ---------------------------------------------------------------------------------
+constexpr int kMaxShardRanks = 16;
+struct ExchArg {
+  unsigned g, m, planes;
+  PermArg perm;                       // identity: nfields = 0
+  void* dst[kMaxShardRanks][2];       // [chunk][plane]
+};
+
+template <typename E, int VEC>
+__global__ void __launch_bounds__(kBlock)
+exchange_pack_kernel(const E* __restrict__ src0, const E* __restrict__ src1, const ExchArg a,
+                     const uint64_t nunits /* 2^m / VEC */) {
+  struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const unsigned cbits = a.m - a.g;
+  const uint64_t wmask = (1ull << cbits) - 1;
+  for (uint64_t u = (uint64_t)blockIdx.x * kBlock + threadIdx.x; u < nunits; u += stride) {
+    const uint64_t x = u * VEC;
+    uint64_t y = x & a.perm.fixed_mask;
+#pragma unroll 4
+    for (unsigned i = 0; i < a.perm.nfields; ++i)
+      y |= ((x >> a.perm.from[i]) & ((1ull << a.perm.len[i]) - 1)) << a.perm.to[i];
+    const unsigned j = (unsigned)(x >> cbits);
+    const uint64_t w = x & wmask;
+    *reinterpret_cast<Pack*>(reinterpret_cast<E*>(a.dst[j][0]) + w) = *reinterpret_cast<const Pack*>(src0 + y);
+    if (a.planes == 2)
+      *reinterpret_cast<Pack*>(reinterpret_cast<E*>(a.dst[j][1]) + w) = *reinterpret_cast<const Pack*>(src1 + y);
   }
 }
 

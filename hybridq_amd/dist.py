@@ -190,13 +190,36 @@ def plan_restore(pos, qubits, g):
     return ops, dict(pos)
 
 
+def fuse_evictions(schedule):
+    """('P', perm) directly followed by ('X',) -> ('XP', perm): the eviction permutation is applied
+    by the exchange's own pack pass (hq_exchange_* `perm`) instead of a pass of its own."""
+    out = []
+    for op in schedule:
+        if op[0] == 'X' and out and out[-1][0] == 'P':
+            out[-1] = ('XP', out[-1][1])
+        else:
+            out.append(op)
+    return out
+
+
 # ------------------------------------------------------------------------------------
 # backends
 # ------------------------------------------------------------------------------------
 class HipBackend:
-    """Shard planes in HBM (torch tensors), kernels from libhq_hip.so, RCCL collectives."""
+    """Shard planes in HBM (torch tensors), kernels and the qubit exchange from libhq_hip.so.
 
-    def __init__(self, float_type, device=None):
+    Exchange transports (``transport=`` or env HQ_SHARD_TRANSPORT; default 'auto'):
+      'rccl'   hq_exchange_* over the library's own RCCL communicator (ncclSend/ncclRecv to the G-1
+               peers in one group, both planes, self chunk by an own kernel, eviction permutation
+               folded into the pack pass) -- the default whenever the process group runs on nccl;
+      'p2p'    hq_exchange_* with peer-to-peer stores into the other ranks' planes mapped through
+               HIP IPC: ONE pass, bracketed by host barriers -- the default for ranks that share one
+               GPU (gloo process group: RCCL refuses two ranks per device), also usable over xGMI;
+      'torch'  permute_bits + torch.distributed.all_to_all_single per plane (the round-1 path; kept
+               as a cross-check and as the fallback when the library's transports cannot start)."""
+
+    def __init__(self, float_type, device=None, transport=None):
+        import os
         import torch
         import torch.distributed as dist
         from . import core
@@ -206,11 +229,92 @@ class HipBackend:
         self.float_type = np.dtype(float_type)
         self.tdt = {np.dtype('float32'): torch.float32, np.dtype('float64'): torch.float64}[self.float_type]
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        core.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.transport = transport or os.environ.get('HQ_SHARD_TRANSPORT', 'auto')
+        self.transport_note = ''
+        self._peer_maps = []  # keeps the IPC mappings alive
+        core.use_torch_stream()
 
     def empty_planes(self, m):
         from .simulation import alloc_planes
         return alloc_planes(m, self.tdt, self.device)  # re/im rows offset by PLANE_PAD_BYTES
+
+    # -- exchange transport ---------------------------------------------------------------
+    def setup_exchange(self, group, buffers):
+        """Collective.  `buffers`: the rank's two shard buffers (each a (2, 2^m) plane pair)."""
+        dist = self.dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.group, self.world, self.rank = group, world, rank
+        if world == 1:
+            self.transport = 'none'
+            return
+        want = self.transport
+        if want == 'auto':
+            want = 'rccl' if dist.get_backend(group) == 'nccl' else 'p2p'
+        try:
+            if want == 'rccl':
+                uid = [self.core.shard_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                self.core.shard_init_rccl(world, rank, uid[0])
+            elif want == 'p2p':
+                self._setup_p2p(group, buffers)
+            elif want != 'torch':
+                raise ValueError(f'unknown exchange transport {want!r}')
+        except Exception as e:  # noqa: BLE001 -- every rank takes the same branch: the failure modes are collective
+            ok = [None] * world
+            dist.all_gather_object(ok, repr(e), group=group)
+            self.transport_note = f'{want} transport unavailable ({e!r}); using torch.distributed collectives'
+            want = 'torch'
+        else:
+            ok = [None] * world
+            dist.all_gather_object(ok, '', group=group)
+            if any(ok):  # some other rank failed: everybody falls back together
+                self.transport_note = f'{want} transport unavailable on a peer ({[o for o in ok if o][0]}); using torch.distributed collectives'
+                want = 'torch'
+        self.transport = want
+
+    def _setup_p2p(self, group, buffers):
+        core, dist = self.core, self.dist
+        planes = [b[p] for b in buffers for p in (0, 1)]
+        mine = [core.ipc_export(t) + (t.data_ptr(),) for t in planes]  # (handle, offset, local address)
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, [(h, o) for h, o, _ in mine], group=group)
+        core.shard_init_p2p(self.world, self.rank)
+        opened = {}
+        for i, t in enumerate(planes):
+            addrs = []
+            for r in range(self.world):
+                if r == self.rank:
+                    addrs.append(t.data_ptr())
+                    continue
+                h, o = everyone[r][i]
+                if (r, h) not in opened:  # one mapping per exported allocation
+                    opened[(r, h)] = core.ipc_open(h, 0)
+                addrs.append(opened[(r, h)] + o)
+            core.shard_p2p_register(t, addrs)
+        self._peer_maps.append(opened)
+
+    def exchange(self, src, dst, perm, m, group):
+        """Exchange the top-g local bits with the rank bits, applying the local permutation `perm`
+        (or None) on the way.  Returns True if the result is in `src` (else in `dst`)."""
+        core = self.core
+        if self.transport in ('rccl', 'none'):
+            return core.exchange(src[0], src[1], dst[0], dst[1], perm, m)
+        if self.transport == 'p2p':
+            # nobody may write into a peer's dst planes before that peer is done with them, and nobody
+            # may read its own dst planes before every peer's stores have landed
+            core.sync()
+            self.dist.barrier(group=group)
+            where = core.exchange(src[0], src[1], dst[0], dst[1], perm, m)
+            core.sync()
+            self.dist.barrier(group=group)
+            return where
+        # 'torch': two passes (three with a permutation)
+        if perm is not None:
+            self.permute(src, dst, perm, m)
+            src, dst = dst, src
+        self.all_to_all(dst, src, group)
+        return perm is not None
 
     def fill_zero(self, planes):
         planes.zero_()
@@ -239,6 +343,9 @@ class HipBackend:
     def all_to_all(self, dst, src, group):
         self.dist.all_to_all_single(dst[0], src[0], group=group)
         self.dist.all_to_all_single(dst[1], src[1], group=group)
+
+    def interleave(self, planes, out):
+        self.core.to_complex(planes[0], planes[1], out)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -277,6 +384,8 @@ class ShardedEvolution:
         # second buffer (receive side of the exchange / destination of the permutation pass)
         # is allocated on first use when there is a single rank
         self.bufs = [self.backend.empty_planes(self.m), self.backend.empty_planes(self.m) if self.g else None]
+        if hasattr(self.backend, 'setup_exchange'):
+            self.backend.setup_exchange(group, [b for b in self.bufs if b is not None])
         self.cur = 0
         self.pos = {q: n - 1 - i for i, q in enumerate(self.qubits)}
         self._gates = None
@@ -333,6 +442,7 @@ class ShardedEvolution:
             else:
                 sched.append(op)
         self._planned_final_pos = final_pos
+        sched = fuse_evictions(sched)
         if blocked and self.m >= 14:
             from .blocking import plan_blocked
             opts = dict(blocked) if isinstance(blocked, dict) else {}
@@ -370,7 +480,7 @@ class ShardedEvolution:
         ``start(op) -> token`` / ``stop(token)`` called around every op on the issuing stream."""
         be = self.backend
         for op in schedule:
-            if op[0] in ('P', 'X') and self.bufs[1 - self.cur] is None:
+            if op[0] in ('P', 'X', 'XP') and self.bufs[1 - self.cur] is None:
                 self.bufs[1 - self.cur] = be.empty_planes(self.m)
             tok = timer.start(op) if timer is not None else None
             if op[0] == 'G':
@@ -380,9 +490,18 @@ class ShardedEvolution:
             elif op[0] == 'P':
                 be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m)
                 self.cur = 1 - self.cur
-            else:
-                be.all_to_all(self.bufs[1 - self.cur], self.bufs[self.cur], self.group)
-                self.cur = 1 - self.cur
+            else:  # 'X' / 'XP': the exchange, with the eviction permutation folded in for 'XP'
+                perm = op[1] if op[0] == 'XP' else None
+                if hasattr(be, 'exchange'):
+                    in_src = be.exchange(self.bufs[self.cur], self.bufs[1 - self.cur], perm, self.m, self.group)
+                else:  # minimal backends (tests): the two primitive passes
+                    if perm is not None:
+                        be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], perm, self.m)
+                        self.cur = 1 - self.cur
+                    be.all_to_all(self.bufs[1 - self.cur], self.bufs[self.cur], self.group)
+                    in_src = False
+                if not in_src:
+                    self.cur = 1 - self.cur
             if timer is not None:
                 timer.stop(tok)
         if update_map:
@@ -397,7 +516,7 @@ class ShardedEvolution:
         counterpart of the reference's final un-permute (simulation.py:655-663)."""
         order = list(self.qubits)
         ops, final = plan_restore(self.pos, order, self.g)
-        sched = [('P', np.asarray(op[1], dtype=np.uint32)) if op[0] == 'P' else op for op in ops]
+        sched = fuse_evictions([('P', np.asarray(op[1], dtype=np.uint32)) if op[0] == 'P' else op for op in ops])
         self._planned_final_pos = final
         self.run(sched)
         return self

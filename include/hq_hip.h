@@ -143,6 +143,47 @@ int hq_init_product_state_float64(double *psi_re, double *psi_im, unsigned int n
 int hq_permute_bits_32(const void *src, void *dst, const unsigned int *perm, unsigned int n);
 int hq_permute_bits_64(const void *src, void *dst, const unsigned int *perm, unsigned int n);
 
+/* ---- Multi-GPU: high-qubit shards and the qubit exchange (the reference has no counterpart,
+ * hybridq/circuit/simulation/simulation.py:379-380).  One process per GPU; rank r of G = 2^g holds the
+ * 2^n_local amplitudes whose top g index bits equal r.  A gate on a global qubit is preceded by ONE
+ * hq_exchange_* call that swaps the g global index bits with the top g local ones.
+ *
+ * Transports (pick one per process after hipSetDevice):
+ *   hq_shard_init_rccl   RCCL: rank 0 obtains 128 bytes from hq_shard_unique_id, every rank receives them
+ *                        out of band (the Python driver uses torch.distributed) and calls init (collective,
+ *                        ncclCommInitRank).  hq_shard_attach_rccl adopts an ncclComm_t the caller owns.
+ *                        librccl is dlopen()ed (env HQ_RCCL_LIBRARY overrides the search), so the library
+ *                        has no link-time dependency on it.
+ *   hq_shard_init_p2p    peer-to-peer stores over xGMI: every rank maps the other ranks' planes with
+ *                        hq_ipc_export / hq_ipc_open (HIP IPC, dmabuf) and registers, per local plane, the
+ *                        address of the same plane on every rank (hq_shard_p2p_register; entry `rank` is
+ *                        the local address).  The caller MUST bracket hq_exchange_* with barriers: no rank
+ *                        may start before all ranks finished using their dst planes, none may touch dst
+ *                        before all ranks' exchange has completed (hq_sync + barrier).
+ * hq_exchange_*: src/dst = the rank's two shard buffers (split planes, device pointers).  `perm` (NULL =
+ * none) is a local bit permutation applied on the way (dst bit i <- src bit perm[i], as hq_permute_bits):
+ * the eviction that moves the outgoing qubits to the top g local bits costs no pass of its own.  Effect:
+ * with P = permuted src cut into G chunks by its top g local bits, chunk j of rank r becomes chunk r of
+ * rank j.  *result_in_src tells where the exchanged shard is: 0 = dst planes, 1 = src planes (RCCL with a
+ * permutation packs src -> dst and transfers dst -> src).  Asynchronous on the library stream; both
+ * planes travel in one ncclGroup (all 2(G-1) transfers of a GPU at once: xGMI is point to point), the
+ * self chunk is copied by an own kernel, and with a permutation the transfer of the re plane overlaps
+ * the packing of the im plane on a second stream. */
+int hq_shard_unique_id(void *id128);
+int hq_shard_init_rccl(unsigned int world, unsigned int rank, const void *id128);
+int hq_shard_attach_rccl(void *nccl_comm, unsigned int world, unsigned int rank);
+int hq_shard_init_p2p(unsigned int world, unsigned int rank);
+int hq_shard_p2p_register(const void *local_plane, void *const *peer_planes);
+int hq_shard_info(unsigned int *world, unsigned int *rank, int *transport /* 0 none, 1 rccl, 2 p2p */);
+int hq_shard_free(void);
+int hq_ipc_export(const void *dev_ptr, void *handle64, uint64_t *offset);
+int hq_ipc_open(const void *handle64, uint64_t offset, void **dev_ptr);
+int hq_ipc_close(void *dev_ptr, uint64_t offset);
+int hq_exchange_float32(float *src_re, float *src_im, float *dst_re, float *dst_im, unsigned int n_local,
+                        const unsigned int *perm, int *result_in_src);
+int hq_exchange_float64(double *src_re, double *src_im, double *dst_re, double *dst_im, unsigned int n_local,
+                        const unsigned int *perm, int *result_in_src);
+
 /* sum_i re[i]^2 + im[i]^2 accumulated in double, written to *out (host).
  * Synchronises the stream.  Device pointers only. */
 int hq_norm2_float32(const float *psi_re, const float *psi_im, uint64_t size, double *out);

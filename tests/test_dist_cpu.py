@@ -105,8 +105,8 @@ def _worker(rank, world, port, n, seed, ct, out_dir):
         sched = sh.plan(gates)
         sh.run(sched)
         psi = sh.state_numpy()
-        n_x = sum(1 for op in sched if op[0] == 'X')
-        n_p = sum(1 for op in sched if op[0] == 'P')
+        n_x = sum(1 for op in sched if op[0] in ('X', 'XP'))
+        n_p = sum(1 for op in sched if op[0] in ('P', 'XP'))
         # second circuit from the permuted placement + a mixed '01+-' initial state
         sh2 = ShardedEvolution(n, complex_type=ct, initial_state=('-+10+' * n)[:n], backend=CpuBackend(ft))
         g2 = random_dense(n, 25, kmax=3, seed=seed + 2)

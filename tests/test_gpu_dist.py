@@ -58,7 +58,7 @@ def _worker(rank, world, port, n, ct, out_dir):
         nb = sum(1 for op in schedb if op[0] == 'B')
         if rank == 0:
             np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psib=psib, nb=nb,
-                     n_x=sum(1 for op in sched if op[0] == 'X'), n_p=sum(1 for op in sched if op[0] == 'P'))
+                     n_x=sum(1 for op in sched if op[0] in ('X', 'XP')), n_p=sum(1 for op in sched if op[0] in ('P', 'XP')))
     finally:
         dist.destroy_process_group()
 
