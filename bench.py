@@ -64,7 +64,11 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--qubits', type=int, default=None, help='qubits per GPU shard + log2(gpus); default 30 per GPU')
     ap.add_argument('--depth', type=int, default=40)
-    ap.add_argument('--workload', default='rqc_1q2q', choices=['rqc_1q2q', 'dense_k34'])
+    ap.add_argument('--workload', default='rqc_1q2q', choices=['rqc_1q2q', 'dense_k34', 'dm'],
+                    help='rqc_1q2q: BASELINE configs 2/3; dense_k34: config 4; dm: config 5 (noisy circuit as a 2n-qubit state vector)')
+    ap.add_argument('--sweep', default=None, help="'A..B': also report gate-apps/s of the rqc_1q2q generator for every n in "
+                    'A..B that fits (north_star: n=30..36), short depth, as a `sweep` list in the JSON line')
+    ap.add_argument('--sweep-depth', type=int, default=8)
     ap.add_argument('--dtype', default='complex64', choices=['complex64', 'complex128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fused', action='store_true', help='skip the fused (compress=4) variant')
@@ -198,8 +202,29 @@ def main():
     n = n_local + g
     if args.workload == 'rqc_1q2q':
         gates = rqc_1q2q(n, depth=args.depth, seed=n)
-    else:
+        workload_name = f'n={n} random circuit, depth {args.depth}, Haar 1q/2q gates, {args.dtype}, no fusion'
+    elif args.workload == 'dense_k34':
         gates = dense_kq(n, n_gates=200, seed=34)
+        workload_name = f'n={n}, 200 Haar 3q/4q dense gates, {args.dtype}'
+    else:
+        # BASELINE config 5: nq-qubit noisy circuit = 2 nq-qubit state vector through the dm
+        # front-end: every gate U becomes U on the left copy and conj(U) on the right copy, followed by a
+        # depolarizing superoperator (one dense NON-unitary 2k-qubit gate).  n must be even: nq = 15 on one
+        # GPU (n = 30), 16 on 2 and 4 GPUs, 17 on 8 GPUs (n = 34, 31 local qubits per GPU).
+        from hybridq_amd.dm import depolarizing, to_statevector_circuit
+        nq = (15 + (g + 1) // 2) if args.qubits is None else args.qubits // 2
+        n, n_local = 2 * nq, 2 * nq - g
+        depth = args.depth if args.depth != 40 else 10
+        noisy = []
+        for U, qs in rqc_1q2q(nq, depth=depth, seed=nq):
+            noisy.append((U, qs))
+            noisy.append(depolarizing(qs, 0.01 if len(qs) == 1 else 0.02))
+        sv = to_statevector_circuit(noisy)
+        labels = sorted({q for _, qs in sv for q in qs})  # (0, q) < (1, q): left copies are the high index bits
+        index = {lab: i for i, lab in enumerate(labels)}
+        gates = [(U, tuple(index[q] for q in qs)) for U, qs in sv]
+        workload_name = (f'{nq}-qubit noisy circuit (depth {depth}, depolarizing noise after every gate) as an n={n} state '
+                         f'vector via hybridq_amd.dm, {args.dtype}, no fusion: k=1..4 gates, superoperators non-unitary')
     ft = np.dtype('float32') if args.dtype == 'complex64' else np.dtype('float64')
     vb = 2 if ft == np.dtype('float32') else 1
     bytes_per_gate = 2 * (1 << n_local) * 2 * ft.itemsize  # read+write both planes (per GPU)
@@ -242,6 +267,8 @@ def main():
         n_permutes = sum(1 for op in schedules[-1] if op[0] in ('P', 'XP'))
         step_no = [0]
 
+        OP_NAMES = {'P': 'permute_bits', 'X': 'exchange', 'XP': 'exchange_with_folded_permutation'}
+
         class OpTimer:
             """HIP events around every op of the sharded schedule (torch's current stream IS the
             library stream, set above); 'G' ops are labelled with the kernel they dispatched to."""
@@ -256,8 +283,7 @@ def main():
 
             def stop(self, tok):
                 tok[2].record()
-                self.rows.append((core.last_kernel_desc() if tok[0] == 'G' else {'P': 'permute_bits', 'X': 'all_to_all'}.get(tok[0], tok[0]),
-                                  tok[1], tok[2]))
+                self.rows.append((core.last_kernel_desc() if tok[0] == 'G' else OP_NAMES.get(tok[0], tok[0]), tok[1], tok[2]))
 
         op_timer = OpTimer() if not args.no_events else None
 
@@ -309,8 +335,7 @@ def main():
         'dtype': 'f32' if ft == np.dtype('float32') else 'f64',
         'data': 'synthetic',
         'config': {
-            'workload': (f'n={n} random circuit, depth {args.depth}, Haar 1q/2q gates, {args.dtype}, no fusion'
-                         if args.workload == 'rqc_1q2q' else f'n={n}, 200 Haar 3q/4q dense gates, {args.dtype}'),
+            'workload': workload_name,
             'n_qubits': n,
             'gate_applications_per_step': len(gates),
             'state_bytes_per_gpu': 2 * (1 << n_local) * ft.itemsize,
@@ -326,23 +351,31 @@ def main():
             # the exchange on its own: every rank sends (G-1)/G of both planes, one
             # distinct chunk per peer, so the per-link figure is chunk bytes / time
             reps = 3
-            barrier()
-            t0x = time.perf_counter()
-            for _ in range(2 * reps):  # an even count leaves the state where it was
-                sharded.run([('X',)], update_map=False)
-            barrier()
-            tx = (time.perf_counter() - t0x) / (2 * reps)
-            perm = np.arange(n_local, dtype=np.uint32)
-            if n_local >= 2:
-                perm[n_local - 1], perm[n_local - 2] = n_local - 2, n_local - 1
-            barrier()
-            t0p = time.perf_counter()
-            for _ in range(2 * reps):
-                sharded.run([('P', perm)], update_map=False)
-            barrier()
-            tp = (time.perf_counter() - t0p) / (2 * reps)
             shard_bytes = 2 * (1 << n_local) * ft.itemsize
             chunk_bytes = shard_bytes // max(world, 1)
+
+            def time_op(op):
+                barrier()
+                t0_ = time.perf_counter()
+                for _ in range(2 * reps):  # an even count leaves the placement where it was
+                    sharded.run([op], update_map=False)
+                barrier()
+                dt = (time.perf_counter() - t0_) / (2 * reps)
+                if world > 1:
+                    tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt.item())
+                return dt
+
+            tx = time_op(('X',))
+            perm = np.arange(n_local, dtype=np.uint32)
+            if n_local >= 2 * g + 2 and g:  # the eviction pattern: two mid qubits swapped into the top-g slots
+                a, b = n_local - 1, n_local // 2
+                perm[a], perm[b] = b, a
+            elif n_local >= 2:
+                perm[n_local - 1], perm[n_local - 2] = n_local - 2, n_local - 1
+            tp = time_op(('P', perm))
+            txp = time_op(('XP', perm))
             # cache-blocked local passes between the exchanges (same circuit; reported separately)
             if n_local >= 14 and not args.no_fused:
                 sharded.pos = dict(pos_after_main)
@@ -370,15 +403,20 @@ def main():
                     'exchanges_per_step': sum(1 for op in bsched[-1] if op[0] in ('X', 'XP')),
                 }
             result['exchange'] = {
+                'transport': getattr(sharded.backend, 'transport', None),
+                'transport_note': getattr(sharded.backend, 'transport_note', ''),
                 'ms_per_exchange': 1e3 * tx,
+                'ms_per_exchange_with_folded_permutation': 1e3 * txp,
+                'ms_per_permutation_pass_alone': 1e3 * tp,
                 'bytes_sent_per_gpu': shard_bytes - chunk_bytes,
                 'bytes_per_link': chunk_bytes,
                 'GBps_per_link': chunk_bytes / tx / 1e9 if world > 1 else None,
+                'GBps_per_link_with_folded_permutation': chunk_bytes / txp / 1e9 if world > 1 else None,
                 'GBps_per_gpu_out': (shard_bytes - chunk_bytes) / tx / 1e9 if world > 1 else None,
                 'xgmi_link_peak_GBps': 153.0,
-                'ms_per_permutation_pass': 1e3 * tp,
+                'link_frac_of_peak': chunk_bytes / tx / 1e9 / 153.0 if world > 1 else None,
                 'exchanges_per_step': n_exchanges,
-                'permutation_passes_per_step': n_permutes,
+                'of_which_with_folded_permutation': n_permutes,
             }
         except Exception as e:  # noqa: BLE001
             result['extras_error'] = repr(e)
@@ -391,7 +429,7 @@ def main():
         else:  # sharded: rank 0's local gate kernels (exchange / permutation passes reported on their own)
             other = {}
             for kname, e0, e1 in op_timer.rows:
-                (per_class if kname not in ('permute_bits', 'all_to_all') else other).setdefault(kname, []).append(e0.elapsed_time(e1))
+                (per_class if kname not in OP_NAMES.values() else other).setdefault(kname, []).append(e0.elapsed_time(e1))
             result['in_loop_ms'] = {c: {'launches': len(v), 'avg_ms': float(np.mean(v)), 'total_ms_per_step': float(np.sum(v)) / args.steps}
                                     for c, v in sorted(other.items())}
         total = {c: float(np.sum(v)) for c, v in per_class.items()}
@@ -577,6 +615,64 @@ def main():
             result['parity_check'] = parity_check(args.dtype, args.depth)
         except Exception as e:
             result['parity_check'] = {'error': repr(e)}
+    if args.sweep:
+        # north_star: gate-applications/s for n = 30..36 random circuits.  Same generator, short depth,
+        # every size that fits this job's HBM (single GPU: one state; sharded: two shard buffers per rank).
+        try:
+            lo, hi = (int(x) for x in args.sweep.split('..'))
+            if not sharded_path:
+                del state
+            else:
+                del sharded
+            torch.cuda.empty_cache()
+            rows = []
+            for n_s in range(lo, hi + 1):
+                m_s = n_s - g
+                need = 2 * (1 << m_s) * ft.itemsize * (2 if sharded_path and world > 1 else 1)
+                free_b, _total = torch.cuda.mem_get_info()
+                if m_s < 2 * g + 2 or need > 0.92 * free_b:
+                    rows.append({'n_qubits': n_s, 'skipped': f'needs {need / 2**30:.0f} GiB per GPU, {free_b / 2**30:.0f} GiB free'})
+                    continue
+                gs = rqc_1q2q(n_s, depth=args.sweep_depth, seed=n_s)
+                if not sharded_path:
+                    from hybridq_amd.simulation import EvolutionState
+                    st_s = EvolutionState(list(range(n_s)), complex_type=args.dtype, initial_state='0' * n_s)
+                    plan_s = [(U, [st_s.map[q] for q in reversed(qs)]) for U, qs in gs]
+
+                    def once():
+                        for U, pos in plan_s:
+                            core.apply_U(st_s.planes[0], st_s.planes[1], U, pos, n_s)
+                    n_x_s = 0
+                else:
+                    from hybridq_amd.dist import ShardedEvolution
+                    st_s = ShardedEvolution(n_s, complex_type=args.dtype, initial_state='0' * n_s)
+                    scheds = []
+                    for _ in range(2):
+                        scheds.append(st_s.plan(gs))
+                        st_s.pos = dict(st_s._planned_final_pos)
+                    n_x_s = sum(1 for op in scheds[1] if op[0] in ('X', 'XP'))
+                    it_s = iter(scheds)
+
+                    def once():
+                        st_s.run(next(it_s), update_map=False)
+                once()
+                barrier()
+                t0s = time.perf_counter()
+                once()
+                barrier()
+                dt = time.perf_counter() - t0s
+                if world > 1:
+                    tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt.item())
+                rows.append({'n_qubits': n_s, 'gate_applications': len(gs), 'exchanges': n_x_s, 'ms': 1e3 * dt,
+                             'gate_apps_per_s': len(gs) / dt, 'amplitudes_per_s': len(gs) / dt * float(1 << n_s),
+                             'hbm_frac_of_peak_per_gpu': len(gs) / dt * 4 * (1 << m_s) * ft.itemsize / 1e9 / HBM_PEAK_GBS})
+                del st_s
+                torch.cuda.empty_cache()
+            result['sweep'] = {'depth': args.sweep_depth, 'n_gpus': world, 'rows': rows}
+        except Exception as e:  # noqa: BLE001 -- a reported extra
+            result['sweep_error'] = repr(e)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist.is_initialized():

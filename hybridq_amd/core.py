@@ -144,6 +144,8 @@ _shard_p2p_register = _define_function(_lib, 'hq_shard_p2p_register', ctypes.c_i
 _shard_info = _define_function(_lib, 'hq_shard_info', ctypes.c_int, ctypes.POINTER(ctypes.c_uint),
                                ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_int))
 _shard_free = _define_function(_lib, 'hq_shard_free', ctypes.c_int)
+_shard_rccl_selftest = _define_function(_lib, 'hq_shard_rccl_selftest', ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_uint64)
 _ipc_export = _define_function(_lib, 'hq_ipc_export', ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                ctypes.POINTER(ctypes.c_uint64))
 _ipc_open = _define_function(_lib, 'hq_ipc_open', ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
@@ -175,7 +177,7 @@ EXPORTED = [
     'hq_vdot_float32', 'hq_vdot_float64', 'hq_apply_blocked_float32', 'hq_apply_blocked_float64',
     'hq_program_begin', 'hq_program_end', 'hq_program_size', 'hq_program_run', 'hq_program_free',
     'hq_shard_unique_id', 'hq_shard_init_rccl', 'hq_shard_attach_rccl', 'hq_shard_init_p2p', 'hq_shard_p2p_register',
-    'hq_shard_info', 'hq_shard_free', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
+    'hq_shard_info', 'hq_shard_free', 'hq_shard_rccl_selftest', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
     'hq_exchange_float32', 'hq_exchange_float64',
 ]
 
@@ -410,6 +412,12 @@ def shard_info():
     w, r, t = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_int(0)
     _shard_info(ctypes.byref(w), ctypes.byref(r), ctypes.byref(t))
     return {'world': w.value, 'rank': r.value, 'transport': {0: None, 1: 'rccl', 2: 'p2p'}[t.value]}
+
+
+def shard_rccl_selftest(src, dst):
+    """Grouped ncclSend/ncclRecv of `src` into `dst` with this rank as its own peer (plumbing check)."""
+    nbytes = src.numel() * src.element_size()
+    _check(_shard_rccl_selftest(_ptr(src), _ptr(dst), nbytes), 'hq_shard_rccl_selftest')
 
 
 def shard_free():

@@ -77,7 +77,7 @@ static int fail(const std::string& msg) {
   do {                                                                                 \
     hipError_t _e = (expr);                                                            \
     if (_e != hipSuccess)                                                              \
-      return fail(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+      return hq::fail(std::string(#expr) + ": " + hipGetErrorString(_e));              \
   } while (0)
 
 // Launch now, or append to the program being recorded (arguments are captured by value).
@@ -1921,7 +1921,7 @@ int hq_shard_init_rccl(unsigned int world, unsigned int rank, const void* id128)
   std::lock_guard<std::mutex> lock(c.mu);
   hq::Shard& sh = hq::shard();
   if (hq::shard_common_init(c, sh, world, rank)) return 1;
-  if (world == 1) { sh.transport = 0; return 0; }
+  if (world == 1 && !id128) { sh.transport = 0; return 0; }
   if (!id128) return hq::fail("hq_shard_init_rccl: null id");
   if (hq::load_rccl(sh)) return 1;
   if (sh.comm && sh.own_comm) { (void)sh.api.CommDestroy(sh.comm); sh.comm = nullptr; }
@@ -1929,7 +1929,27 @@ int hq_shard_init_rccl(unsigned int world, unsigned int rank, const void* id128)
   memcpy(&id, id128, sizeof(id));
   HQ_NCCL_CHECK(sh, sh.api.CommInitRank(&sh.comm, (int)world, id, (int)rank));
   sh.own_comm = true;
-  sh.transport = 1;
+  sh.transport = world > 1 ? 1 : 0;  // a one-rank communicator is legal (hq_shard_rccl_selftest); the exchange needs none
+  return 0;
+}
+
+// Plumbing check of the RCCL transport that needs no second GPU: one grouped ncclSend + ncclRecv of
+// `bytes` from `src` to `dst` with THIS rank as the peer, on the communication stream, ordered
+// against the library stream with the same events the exchange uses.
+int hq_shard_rccl_selftest(const void* src, void* dst, uint64_t bytes) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::Shard& sh = hq::shard();
+  if (!sh.comm) return hq::fail("hq_shard_rccl_selftest: no communicator");
+  if (!src || !dst) return hq::fail("hq_shard_rccl_selftest: null pointer");
+  HQ_HIP_CHECK(hipEventRecord(sh.ev[0], c.stream));
+  HQ_HIP_CHECK(hipStreamWaitEvent(sh.comm_stream, sh.ev[0], 0));
+  HQ_NCCL_CHECK(sh, sh.api.GroupStart());
+  HQ_NCCL_CHECK(sh, sh.api.Send(src, (size_t)bytes, ncclChar, (int)sh.rank, sh.comm, sh.comm_stream));
+  HQ_NCCL_CHECK(sh, sh.api.Recv(dst, (size_t)bytes, ncclChar, (int)sh.rank, sh.comm, sh.comm_stream));
+  HQ_NCCL_CHECK(sh, sh.api.GroupEnd());
+  HQ_HIP_CHECK(hipEventRecord(sh.ev[2], sh.comm_stream));
+  HQ_HIP_CHECK(hipStreamWaitEvent(c.stream, sh.ev[2], 0));
   return 0;
 }
 
@@ -1951,8 +1971,9 @@ int hq_shard_init_p2p(unsigned int world, unsigned int rank) {
   hq::Context& c = hq::ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   hq::Shard& sh = hq::shard();
+  const bool same = sh.transport == 2 && sh.world == world && sh.rank == rank;
   if (hq::shard_common_init(c, sh, world, rank)) return 1;
-  sh.registry.clear();
+  if (!same) sh.registry.clear();  // a second state of the same job keeps the planes already registered
   sh.transport = world > 1 ? 2 : 0;
   return 0;
 }

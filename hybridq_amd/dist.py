@@ -218,6 +218,8 @@ class HipBackend:
       'torch'  permute_bits + torch.distributed.all_to_all_single per plane (the round-1 path; kept
                as a cross-check and as the fallback when the library's transports cannot start)."""
 
+    _ipc_mappings = {}  # (peer rank, exported handle) -> base address of the mapping in this process
+
     def __init__(self, float_type, device=None, transport=None):
         import os
         import torch
@@ -231,7 +233,6 @@ class HipBackend:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.transport = transport or os.environ.get('HQ_SHARD_TRANSPORT', 'auto')
         self.transport_note = ''
-        self._peer_maps = []  # keeps the IPC mappings alive
         core.use_torch_stream()
 
     def empty_planes(self, m):
@@ -280,7 +281,7 @@ class HipBackend:
         everyone = [None] * self.world
         dist.all_gather_object(everyone, [(h, o) for h, o, _ in mine], group=group)
         core.shard_init_p2p(self.world, self.rank)
-        opened = {}
+        opened = HipBackend._ipc_mappings  # process-wide: an exported allocation is mapped once
         for i, t in enumerate(planes):
             addrs = []
             for r in range(self.world):
@@ -292,7 +293,6 @@ class HipBackend:
                     opened[(r, h)] = core.ipc_open(h, 0)
                 addrs.append(opened[(r, h)] + o)
             core.shard_p2p_register(t, addrs)
-        self._peer_maps.append(opened)
 
     def exchange(self, src, dst, perm, m, group):
         """Exchange the top-g local bits with the rank bits, applying the local permutation `perm`
@@ -522,6 +522,17 @@ class ShardedEvolution:
         return self
 
     # -- results -----------------------------------------------------------------
+    def to_complex(self):
+        """This rank's shard as ONE interleaved complex tensor on the device (the sharded
+        counterpart of to_complex64/128, python_U.cpp:114-123): after restore_order() rank r's
+        tensor is the slice [r * 2^m, (r+1) * 2^m) of the canonical state."""
+        be = self.backend
+        torch = be.torch
+        cdt = {np.dtype('complex64'): torch.complex64, np.dtype('complex128'): torch.complex128}[self.complex_type]
+        out = torch.empty(1 << self.m, dtype=cdt, device=be.device)
+        be.interleave(self.planes, out)
+        return out
+
     def norm2(self):
         """Global squared norm (all-reduce of the local ones)."""
         import torch

@@ -71,7 +71,8 @@ def to_statevector_circuit(circuit):
 def simulate(circuit, initial_state=None, **kwargs):
     """rho after `circuit` as an array of shape (2,)*2n (left indices first), through the
     evolution core.  `initial_state`: '01+-' string for the n qubits (or 2n), or psi as an
-    array of 2^n amplitudes (rho0 = psi (x) psi, simulation.py:259-261)."""
+    array of 2^n amplitudes (rho0 = psi (x) psi, simulation.py:259-261).  ``devices=N`` shards the
+    2n-qubit state over the N ranks of the torch.distributed job (BASELINE config 5)."""
     circuit = list(circuit)
     sv = to_statevector_circuit(circuit)
     lq = sorted({q for _, qs in sv for (side, q) in qs if side == 0})

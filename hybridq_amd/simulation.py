@@ -320,7 +320,9 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     ``max_largest_intermediate`` (default 2**36 amplitudes: one MI355X holds n=34 in
     complex64), ``compress`` (max qubits of a fused gate, default 4 like simulation.py:314;
     0 applies the gates as given; a dict may carry ``max_n_qubits`` plus the keyword
-    arguments of ``fusion.fuse``), ``device``, ``blocked`` (default False; True or a dict of
+    arguments of ``fusion.fuse``), ``device``, ``devices`` / ``shard_bits`` (N = 2^g ranks of the current
+    torch.distributed job hold one shard each: hybridq_amd.dist; strings as initial state, no
+    FunctionalGates), ``blocked`` (default False; True or a dict of
     ``blocking.plan_blocked`` options: apply many gates per HBM pass through LDS tiles,
     n >= 14 -- see hybridq_amd/blocking.py).  ``simplify`` / ``remove_id_gates`` / ``atol`` as in the
     reference (simulation.py:290-305): identity gates are dropped and `fusion.simplify` (the
@@ -362,6 +364,8 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
         raise MemoryError("Memory for the given number of qubits exceeds the 'max_largest_intermediate'.")
 
     torch = _torch()
+    if _wants_shards(kwargs):
+        return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs)
     state = EvolutionState(qubits, complex_type=complex_type, initial_state=initial_state,
                            device=kwargs['device'])
     info = {}
@@ -382,6 +386,63 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
         psi = out.cpu().numpy().reshape((2,) * n)
     else:
         psi = state
+    return (psi, info) if kwargs['return_info'] else psi
+
+
+def _wants_shards(kwargs):
+    """``devices=N`` / ``shard_bits=g`` (N = 2^g): run on the N ranks of the current
+    torch.distributed job (one process per GPU).  Without either argument a job with more than one
+    rank still runs REPLICATED -- every rank its own full state -- like any single-GPU call."""
+    devices, bits = kwargs.get('devices'), kwargs.get('shard_bits')
+    if devices is None and bits is None:
+        return False
+    want = int(devices) if devices is not None else 1 << int(bits)
+    if bits is not None and devices is not None and want != 1 << int(bits):
+        raise ValueError("'devices' and 'shard_bits' disagree")
+    if want == 1:
+        return False
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world != want:
+        raise RuntimeError(f'devices={want} needs a torch.distributed job of {want} ranks, one process per GPU '
+                           f'(python -m torch.distributed.run --nproc-per-node {want} ...); this job has {world}')
+    return True
+
+
+def _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs):
+    """The sharded counterpart of the gate loop: the state is split by its top log2(world) index
+    bits over the ranks (hybridq_amd.dist), gates on global qubits are preceded by an exchange
+    (hq_exchange_*), the canonical qubit order is restored at the end like the reference's final
+    un-permute (simulation.py:655-663).  Returns, on every rank, the full state as a numpy array
+    (``return_numpy_array=True``: small states only) or the :class:`ShardedEvolution` itself."""
+    from .dist import ShardedEvolution
+    if any(_is_functional(g) for g in circuit):
+        raise NotImplementedError('FunctionalGates are not supported on a sharded state')
+    if not isinstance(initial_state, str):
+        raise NotImplementedError("sharded states start from a '01+-' string")
+    gates = [(U, qs) for qs, U in (_gate_qubits_matrix(g) for g in circuit)]
+    compress = kwargs['compress']
+    comp_n = compress.get('max_n_qubits', 4) if isinstance(compress, dict) else compress
+    sh = ShardedEvolution(n, complex_type=ctype, initial_state=initial_state, qubits=qubits)
+    sched = sh.plan(gates, compress=comp_n or 0, blocked=kwargs.get('blocked', False))
+    info = {}
+    sh.backend.sync()
+    t0 = time.perf_counter()
+    sh.run(sched)
+    sh.restore_order()
+    sh.backend.sync()
+    info['runtime (s)'] = time.perf_counter() - t0
+    info['n_gates'] = sum(1 for op in sched if op[0] in ('G', 'B'))
+    info['n_passes'] = info['n_gates']
+    info['n_exchanges'] = sum(1 for op in sched if op[0] in ('X', 'XP'))
+    info['n_gates_given'] = len(circuit)
+    info['n_qubits'] = n
+    info['n_ranks'] = sh.world
+    info['exchange_transport'] = getattr(sh.backend, 'transport', None)
+    if kwargs['return_numpy_array']:
+        psi = sh.state_numpy().reshape((2,) * n).astype(ctype, copy=False)
+    else:
+        psi = sh
     return (psi, info) if kwargs['return_info'] else psi
 
 

@@ -176,6 +176,10 @@ int hq_shard_init_p2p(unsigned int world, unsigned int rank);
 int hq_shard_p2p_register(const void *local_plane, void *const *peer_planes);
 int hq_shard_info(unsigned int *world, unsigned int *rank, int *transport /* 0 none, 1 rccl, 2 p2p */);
 int hq_shard_free(void);
+/* Plumbing check that needs no second GPU: one grouped ncclSend + ncclRecv of `bytes` (device buffers)
+ * with this rank as its own peer, through the same stream / event ordering as the exchange.  Needs a
+ * communicator (a one-rank hq_shard_init_rccl with a unique id is legal). */
+int hq_shard_rccl_selftest(const void *src, void *dst, uint64_t bytes);
 int hq_ipc_export(const void *dev_ptr, void *handle64, uint64_t *offset);
 int hq_ipc_open(const void *handle64, uint64_t offset, void **dev_ptr);
 int hq_ipc_close(void *dev_ptr, uint64_t offset);

@@ -1,7 +1,9 @@
-"""Two ranks sharing ONE GPU: the sharded evolution with the real HIP backend (kernels,
-bit-permutation, device buffers).  RCCL refuses two ranks on one device, so the exchange
-is staged through the host over gloo here; the 8-GPU run uses RCCL all_to_all_single on
-the same buffers (hybridq_amd.dist.HipBackend.all_to_all)."""
+"""Two and four ranks sharing ONE GPU: the sharded evolution with the real HIP backend and the
+library's own exchange (hq_exchange_*, include/hq_hip.h).  RCCL refuses two ranks on one device,
+so the transport here is the peer-to-peer one (the other ranks' planes mapped through HIP IPC, one
+pack pass storing straight into them); the RCCL transport shares the pack / layout / self-chunk
+code and is checked as far as one GPU allows by test_rccl_transport_plumbing.  The round-1 path
+(permute_bits + all_to_all staged through the host over gloo) runs as the cross-check."""
 import os
 import socket
 import sys
@@ -45,19 +47,33 @@ def _worker(rank, world, port, n, ct, out_dir):
 
         ft = np.float32 if ct == 'complex64' else np.float64
         gates = rqc_1q2q(n, depth=8, seed=11) + random_dense(n, 40, kmax=5, seed=12)
-        sh = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, backend=HostStagedExchange(ft))
+        # (a) the library's own exchange: hq_exchange_* with peer-to-peer stores into the other ranks'
+        #     planes (HIP IPC), eviction permutation folded into the pack pass -- the transport 'auto'
+        #     selects for ranks that share a GPU (gloo group)
+        sh = ShardedEvolution(n, complex_type=ct, initial_state='0' * n)
+        transport = sh.backend.transport + (' | ' + sh.backend.transport_note if sh.backend.transport_note else '')
         sched = sh.plan(gates)
         sh.run(sched)
         psi = sh.state_numpy()
+        sh.restore_order()  # exchanges + permutation passes back to the canonical placement
+        assert all(sh.pos[q] == n - 1 - q for q in range(n))
+        loc = torch.from_numpy(np.ascontiguousarray(sh.backend.to_numpy(sh.planes)))
+        parts = [torch.empty_like(loc) for _ in range(world)]
+        dist.all_gather(parts, loc)
+        raw = np.concatenate([p[0].numpy() + 1j * p[1].numpy() for p in parts])
+        # (b) the round-1 path as the cross-check: permute_bits + all_to_all staged through the host
+        shh = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, backend=HostStagedExchange(ft, transport='torch'))
+        shh.run(shh.plan(gates))
+        psi_h = shh.state_numpy()
         # same circuit, cache-blocked local passes between the exchanges, then canonical order
-        shb = ShardedEvolution(n + 2, complex_type=ct, initial_state='0' * (n + 2), backend=HostStagedExchange(ft))
+        shb = ShardedEvolution(n + 2, complex_type=ct, initial_state='0' * (n + 2))
         gb = rqc_1q2q(n + 2, depth=8, seed=13)
         schedb = shb.plan(gb, blocked=True)
         shb.run(schedb)
         psib = shb.state_numpy()
         nb = sum(1 for op in schedb if op[0] == 'B')
         if rank == 0:
-            np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psib=psib, nb=nb,
+            np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psib=psib, nb=nb, raw=raw, psi_h=psi_h, transport=transport,
                      n_x=sum(1 for op in sched if op[0] in ('X', 'XP')), n_p=sum(1 for op in sched if op[0] in ('P', 'XP')))
     finally:
         dist.destroy_process_group()
@@ -73,8 +89,128 @@ def test_sharded_hip_backend_two_ranks_one_gpu(torch_cuda, tmp_path, world, n, c
     gates = rqc_1q2q(n, depth=8, seed=11) + random_dense(n, 40, kmax=5, seed=12)
     exp = oracle.evolve_tensordot(gates, n)
     tol = 1e-6 if ct == 'complex64' else 1e-12
+    assert str(out['transport']) == 'p2p', str(out['transport'])  # the C-ABI exchange really ran
     assert np.abs(out['psi'] - exp).max() / np.abs(exp).max() < tol
-    assert int(out['n_x']) >= 1
+    assert np.abs(out['raw'] - exp).max() / np.abs(exp).max() < tol  # restore_order: raw shards ARE the canonical state
+    assert np.array_equal(out['psi'], out['psi_h'])  # same kernels, different transport: bit-identical
+    assert int(out['n_x']) >= 1 and int(out['n_p']) >= 1  # exchanges, some with a folded permutation
     expb = oracle.evolve_tensordot(rqc_1q2q(n + 2, depth=8, seed=13), n + 2)
     assert np.abs(out['psib'] - expb).max() / np.abs(expb).max() < 5 * tol
     assert int(out['nb']) >= 1  # blocked passes were really used
+
+
+def test_exchange_one_rank_is_the_permutation(torch_cuda):
+    """hq_exchange_* with one rank: no permutation = nothing to do (result stays in src), with a
+    permutation = exactly hq_permute_bits on both planes (the pack pass alone)."""
+    from hybridq_amd import core
+    torch = torch_cuda
+    rng = np.random.default_rng(4)
+    core.shard_free()
+    for dt, m in ((torch.float32, 20), (torch.float64, 18)):
+        src = torch.from_numpy(rng.standard_normal((2, 1 << m))).to(dt).cuda()
+        dst = torch.zeros_like(src)
+        assert core.exchange(src[0], src[1], dst[0], dst[1], None, m) is True
+        for perm in (rng.permutation(m), np.roll(np.arange(m), 3), np.concatenate([[1, 0], np.arange(2, m)])):
+            where = core.exchange(src[0], src[1], dst[0], dst[1], perm, m)
+            assert where is False
+            ref = torch.empty_like(src)
+            core.permute_bits(src[0], ref[0], perm, m)
+            core.permute_bits(src[1], ref[1], perm, m)
+            core.sync()
+            assert torch.equal(dst, ref), list(perm)
+
+
+def test_rccl_transport_plumbing(torch_cuda):
+    """What of the RCCL transport can run on one GPU: librccl is found and bound at run time
+    (dlopen), a communicator is created from a unique id, and a grouped ncclSend/ncclRecv (this
+    rank as its own peer) moves a plane on the communication stream, ordered against the library
+    stream by the same events hq_exchange_* uses."""
+    from hybridq_amd import core
+    torch = torch_cuda
+    core.use_torch_stream()
+    uid = core.shard_unique_id()
+    assert len(uid) == 128 and any(uid)
+    core.shard_init_rccl(1, 0, uid)
+    try:
+        a = torch.arange(1 << 22, dtype=torch.float32, device='cuda')
+        b = torch.zeros_like(a)
+        a.mul_(2.0)  # pending work on the library stream that the transfer must wait for
+        core.shard_rccl_selftest(a, b)
+        b.add_(1.0)  # and work after it that must wait for the transfer
+        core.sync()
+        exp = torch.arange(1 << 22, dtype=torch.float32, device='cuda') * 2.0 + 1.0
+        assert torch.equal(b, exp)
+    finally:
+        core.shard_free()
+
+
+def _api_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import golden_util as gu
+        from hybridq_amd.circuits import random_dense
+        from hybridq_amd.dm import Kraus
+        from hybridq_amd.dm import simulate as dm_simulate
+        from hybridq_amd.simulation import simulate
+        z = gu.load('e2e_dm_circuit.npz')
+        circuit = []
+        for i, kind in enumerate(bytes(z['kinds']).decode()):
+            qs = tuple(int(q) for q in z[f'q{i}'])
+            circuit.append(Kraus(list(z[f'L{i}']), qs, s=z[f's{i}']) if kind == 'K' else (z[f'U{i}'], qs))
+        rho, info = dm_simulate(circuit, initial_state='0', complex_type='complex64', devices=world, return_info=True)
+        # a plain circuit from a mixed '01+-' string, fused to 4 qubits like the reference's default
+        n = 14
+        init = ('+-01-' * n)[:n]
+        gates = random_dense(n, 60, kmax=3, seed=31, unitary=True)
+        psi = simulate(gates, initial_state=init, complex_type='complex128', devices=world, qubits=list(range(n)))
+        # device-resident result: every rank keeps its slice of the canonical state
+        sh = simulate(gates, initial_state=init, complex_type='complex128', shard_bits=int(np.log2(world)),
+                      qubits=list(range(n)), return_numpy_array=False)
+        mine = sh.to_complex().cpu().numpy()
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, 'api.npz'), rho=rho.reshape(-1), psi=psi.reshape(-1), cat=np.concatenate(parts),
+                     n_x=info['n_exchanges'], transport=str(info['exchange_transport']))
+        try:
+            simulate(gates, initial_state=init, devices=2 * world, qubits=list(range(n)))
+            raise SystemExit('devices != world size must be refused')
+        except RuntimeError:
+            pass
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_simulate_and_dm_simulate_sharded_api(torch_cuda, tmp_path, world):
+    """simulate(..., devices=N) / dm.simulate(..., devices=N): BASELINE config 5 in miniature (noisy
+    6-qubit circuit = 12-qubit state vector, the reference's rho from e2e_dm_circuit.npz) and a
+    mixed-string circuit, sharded over N ranks on one GPU through the library's exchange."""
+    import torch.multiprocessing as mp
+    import golden_util as gu
+    import oracle
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.dm import Kraus, to_statevector_circuit
+    from tolerances import circuit_tol
+    mp.spawn(_api_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out = np.load(os.path.join(str(tmp_path), 'api.npz'))
+    z = gu.load('e2e_dm_circuit.npz')
+    circuit = []
+    for i, kind in enumerate(bytes(z['kinds']).decode()):
+        qs = tuple(int(q) for q in z[f'q{i}'])
+        circuit.append(Kraus(list(z[f'L{i}']), qs, s=z[f's{i}']) if kind == 'K' else (z[f'U{i}'], qs))
+    sv = to_statevector_circuit(circuit)
+    assert str(out['transport']) == 'p2p' and int(out['n_x']) >= 1
+    assert np.abs(out['rho'] - z['rho']).max() / np.abs(z['rho']).max() < circuit_tol(sv, sv)
+    n = 14
+    init = ('+-01-' * n)[:n]
+    gates = random_dense(n, 60, kmax=3, seed=31, unitary=True)
+    exp = oracle.evolve_tensordot(gates, n, initial_state=init, qubits=list(range(n)))
+    assert np.abs(out['psi'] - exp).max() / np.abs(exp).max() < 1e-12
+    assert np.abs(out['cat'] - exp).max() / np.abs(exp).max() < 1e-12  # rank-ordered shards = canonical state
