@@ -189,9 +189,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
         args.gpus = world
+    # HQ_BENCH_SHARE_GPU=1 (development): every rank uses GPU 0 and the process group runs on gloo, which
+    # exercises the whole N > 1 path of this file on a one-GPU box (the exchange then takes the
+    # peer-to-peer transport; RCCL refuses two ranks per device).  The numbers mean nothing.
+    share_gpu = os.environ.get('HQ_BENCH_SHARE_GPU') == '1'
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if share_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from hybridq_amd import core
     from hybridq_amd.circuits import rqc_1q2q, dense_kq
@@ -232,6 +241,8 @@ def main():
     core.set_stream(torch.cuda.current_stream().cuda_stream)
     sharded_path = world > 1 or os.environ.get('HQ_BENCH_FORCE_SHARDED') == '1'  # env: smoke-test the N>1 code on one GPU
     if world == 1 and sharded_path:
+        for var, val in (('RANK', '0'), ('WORLD_SIZE', '1'), ('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29533')):
+            os.environ.setdefault(var, val)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if not sharded_path:
         from hybridq_amd.simulation import EvolutionState
@@ -345,6 +356,13 @@ def main():
         },
     }
 
+    try:
+        from hybridq_amd import simulation as _sim
+        if _sim.last_placement:
+            result['state_placement'] = dict(_sim.last_placement, note='tuned placement of the state planes (hybridq_amd/simulation.py: '
+                                             'VMM_MIN_BYTES); HQ_STATE_ALLOC=torch disables it')
+    except Exception as e:  # noqa: BLE001
+        result['state_placement_error'] = repr(e)
     if sharded_path:
         # everything in this block is a reported extra: a failure here must never cost the headline line
         try:

@@ -158,6 +158,13 @@ _exchange = {
     for b in (32, 64)
 }
 
+_alloc = _define_function(_lib, 'hq_alloc', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64, ctypes.c_int)
+_free = _define_function(_lib, 'hq_free', ctypes.c_int, ctypes.c_void_p)
+_alloc_mapped = _define_function(_lib, 'hq_alloc_mapped', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64,
+                                 ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64))
+_alloc_scattered = _define_function(_lib, 'hq_alloc_scattered', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64,
+                                    ctypes.c_uint64, ctypes.c_uint64)
+
 _program_begin = _define_function(_lib, 'hq_program_begin', ctypes.c_int)
 _program_end = _define_function(_lib, 'hq_program_end', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p))
 _program_size = _define_function(_lib, 'hq_program_size', ctypes.c_int, ctypes.c_void_p)
@@ -178,7 +185,7 @@ EXPORTED = [
     'hq_program_begin', 'hq_program_end', 'hq_program_size', 'hq_program_run', 'hq_program_free',
     'hq_shard_unique_id', 'hq_shard_init_rccl', 'hq_shard_attach_rccl', 'hq_shard_init_p2p', 'hq_shard_p2p_register',
     'hq_shard_info', 'hq_shard_free', 'hq_shard_rccl_selftest', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
-    'hq_exchange_float32', 'hq_exchange_float64',
+    'hq_exchange_float32', 'hq_exchange_float64', 'hq_alloc', 'hq_free',
 ]
 
 
@@ -454,6 +461,51 @@ def exchange(src_re, src_im, dst_re, dst_im, perm=None, n_local=None):
     rc = _exchange[ft](_ptr(src_re), _ptr(src_im), _ptr(dst_re), _ptr(dst_im), m, pp, ctypes.byref(where))
     _check(rc, 'exchange')
     return bool(where.value)
+
+
+class DeviceBuffer:
+    """Device memory from hq_alloc, visible to torch through ``__cuda_array_interface__``
+    (``torch.as_tensor(buf, device='cuda')`` aliases it; the buffer must outlive the tensor --
+    `as_tensor` keeps a reference to this object)."""
+
+    def __init__(self, nbytes, contiguous=True, scattered=None, seed=1, va_slots=None):
+        """`scattered` = granule size in bytes: physical granules mapped in a shuffled order (VMM);
+        with `va_slots` (permutation, one entry per granule) the placement is explicit."""
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p(None)
+        if va_slots is not None:
+            slots = np.ascontiguousarray(va_slots, dtype=np.uint32)
+            gmin = ctypes.c_uint64(0)
+            _check(_alloc_mapped(ctypes.byref(p), int(scattered), len(slots), slots.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                 ctypes.byref(gmin)), 'hq_alloc_mapped')
+            self.granule_min = int(gmin.value)
+        elif scattered:
+            _check(_alloc_scattered(ctypes.byref(p), self.nbytes, int(scattered), int(seed)), 'hq_alloc_scattered')
+        else:
+            _check(_alloc(ctypes.byref(p), self.nbytes, 1 if contiguous else 0), 'hq_alloc')
+        self.ptr = int(p.value)
+        self.contiguous = bool(contiguous) and not scattered
+
+    def view(self, offset_bytes, shape, typestr):
+        """An object torch.as_tensor can wrap: `shape` elements of `typestr` ('<f4', '<f8') at an offset."""
+        owner = self
+
+        class _View:
+            __cuda_array_interface__ = {'shape': tuple(int(d) for d in shape), 'typestr': typestr,
+                                        'data': (owner.ptr + int(offset_bytes), False), 'version': 2, 'strides': None}
+            _owner = owner
+        return _View()
+
+    def free(self):
+        if self.ptr:
+            _free(ctypes.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def pack_blocked(gates, complex_type='complex64'):

@@ -235,9 +235,17 @@ class HipBackend:
         self.transport_note = ''
         core.use_torch_stream()
 
+    def _wanted_transport(self):
+        dist = self.dist
+        if self.transport != 'auto' or not dist.is_initialized() or dist.get_world_size() == 1:
+            return self.transport
+        return 'rccl' if dist.get_backend() == 'nccl' else 'p2p'
+
     def empty_planes(self, m):
         from .simulation import alloc_planes
-        return alloc_planes(m, self.tdt, self.device)  # re/im rows offset by PLANE_PAD_BYTES
+        # re/im rows offset by PLANE_PAD_BYTES.  Planes that other ranks map through HIP IPC (p2p transport)
+        # must come from hipMalloc: hipIpcGetMemHandle does not export the library's VMM mappings.
+        return alloc_planes(m, self.tdt, self.device, vmm=self._wanted_transport() != 'p2p')
 
     # -- exchange transport ---------------------------------------------------------------
     def setup_exchange(self, group, buffers):

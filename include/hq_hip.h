@@ -115,6 +115,13 @@ const char *hq_last_kernel_desc(void);
 int hq_to_complex64(float *psi_re, float *psi_im, float *psi_out, uint64_t size);
 int hq_to_complex128(double *psi_re, double *psi_im, double *psi_out, uint64_t size);
 
+/* State memory owned by the library (counterpart of the aligned planes of simulation.py:491-494).
+ * flags bit 0: physically contiguous VRAM -- falls back to the caller when the driver cannot find a
+ * contiguous range (returns 1).  Any device memory may be passed to the other entry points; this
+ * allocator exists because placement is worth ~14 % of HBM bandwidth. */
+int hq_alloc(void **dev_ptr, uint64_t bytes, int flags);
+int hq_free(void *dev_ptr);
+
 /* Device-side initial states (counterpart of prepare_state,
  * hybridq/circuit/simulation/utils.py:106-113): kind 0 -> |basis> (re[basis]=1),
  * kind 1 -> uniform |+...+> (re[i] = 2^{-n/2}).  Device pointers only. */
