@@ -472,7 +472,7 @@ def main():
             'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic,
             'traffic_source': (None if traffic is None else
-                               'stored PMC measurement (profiles/traffic.json <- profiles/r01_pmc_hbm_traffic_v2.csv: '
+                               'stored PMC measurement (profiles/traffic.json <- profiles/r02_pmc_hbm_traffic.csv: '
                                '2 x FETCH_SIZE + WRITE_SIZE of this kernel at this n, separate rocprofv3 --pmc passes), '
                                'not a counter of this run'),
             'algorithmic_bytes_per_launch': bytes_per_gate,
@@ -620,6 +620,49 @@ def main():
             result['per_k'] = per_k
         except Exception as e:  # noqa: BLE001
             result['per_k_error'] = repr(e)
+    if rank == 0 and not sharded_path and not args.no_fused:
+        try:  # a reported extra
+            # the data-movement primitives of the boundary on the same resident state (north_star names the
+            # index-swap primitive): algorithmic bytes = one read + one write of what they touch
+            tdt = torch.float32 if ft == np.dtype('float32') else torch.float64
+            P = (1 << n) * ft.itemsize  # bytes of one plane
+            aux = {}
+
+            def time_aux(name, fn, nbytes, reps=4):
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                aux[name] = {'ms': ms, 'GBps': nbytes / ms / 1e6, 'frac_of_hbm_peak': nbytes / ms / 1e6 / HBM_PEAK_GBS}
+
+            rng_a = np.random.default_rng(3)
+            re_, im_ = state.planes[0], state.planes[1]
+            order8 = np.array([0, 1, 5, 6, 7, 2, 3, 4])  # what the reference driver issues (simulation.py:584-594)
+            time_aux('swap_pair_s8_reference_order', lambda: (core.swap(re_, order8, n), core.swap(im_, order8, n)), 4 * P)
+            for s_ in (12, 13, 14, 16):
+                pos_ = rng_a.permutation(s_)
+                time_aux(f'swap_one_plane_s{s_}', lambda: core.swap(re_, pos_, n), 2 * P)
+            out_c = torch.empty(1 << n, dtype=torch.complex64 if tdt == torch.float32 else torch.complex128, device='cuda')
+            time_aux('to_complex', lambda: core.to_complex(re_, im_, out_c), 4 * P)
+            del out_c
+            tmp_ = torch.empty(1 << n, dtype=tdt, device='cuda')
+            perm_ = np.arange(n)
+            perm_[n - 1], perm_[n // 2] = n // 2, n - 1
+            time_aux('permute_bits_one_plane_top_with_mid', lambda: core.permute_bits(re_, tmp_, perm_, n), 2 * P)
+            time_aux('permute_bits_one_plane_random_perm_above_bit4', lambda p=np.concatenate([np.arange(4), 4 + rng_a.permutation(n - 4)]):
+                     core.permute_bits(re_, tmp_, p, n), 2 * P)
+            del tmp_
+            time_aux('norm2', lambda: core.norm2(re_, im_), 2 * P)
+            time_aux('probabilities_k3', lambda: core.probabilities(re_, im_, [3, n // 2, n - 2], n), 2 * P)
+            time_aux('init_state', lambda: core.init_state(re_, im_, 'plus'), 2 * P)
+            result['aux'] = aux
+        except Exception as e:  # noqa: BLE001
+            result['aux_error'] = repr(e)
     if rank == 0 and not sharded_path and not args.no_cpu_baseline:
         try:
             result['cpu_baseline'] = cpu_baseline(gates, n, args.cpu_seconds, args.dtype)

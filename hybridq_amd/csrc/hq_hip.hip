@@ -777,7 +777,9 @@ static int launch_gemm(Context& c, T* re, T* im, const T* U, const unsigned* pos
     case 2 * 16 + 2: rc = launch_gemm_rc<T, 2, 2>(c, re, im, Ap, Op, a, ntiles); break;
     case 4 * 16 + 2: rc = launch_gemm_rc<T, 4, 2>(c, re, im, Ap, Op, a, ntiles); break;
     case 4 * 16 + 1: rc = launch_gemm_rc<T, 4, 1>(c, re, im, Ap, Op, a, ntiles); break;
-    case 8 * 16 + 1: rc = launch_gemm_rc<T, 8, 1>(c, re, im, Ap, Op, a, ntiles); break;
+    case 8 * 16 + 1:  // k = 10 with 16 columns: float32 only (gemm_ok stops complex128 at k = 9; the f64 form would spill)
+      if constexpr (sizeof(T) == 4) rc = launch_gemm_rc<T, 8, 1>(c, re, im, Ap, Op, a, ntiles);
+      break;
     default: break;
   }
   if (rc < 0) return fail("gemm: unsupported shape");
@@ -949,6 +951,92 @@ static int apply_U_entry(T* re, T* im, const T* U, const unsigned* pos, unsigned
 // ---------------------------------------------------------------------------------
 // swap
 // ---------------------------------------------------------------------------------
+// One in-place pass of tile_permute_kernel: the index bits `tile` (ascending, starting with the vector bits)
+// are permuted inside LDS tiles, bit tile[i] of the destination index reading bit src_of[tile[i]] of the source.
+template <typename E>
+static int launch_tile_permute(Context& c, E* a, unsigned n, const std::vector<unsigned>& tile, const unsigned* src_of) {
+  constexpr int VEC = 16 / (int)sizeof(E);
+  TilePermArg ta;
+  memset(&ta, 0, sizeof(ta));
+  ta.tb = (unsigned)tile.size();
+  bool identity = true;
+  for (unsigned i = 0; i < ta.tb; ++i) {
+    ta.apos[i] = tile[i];
+    const unsigned sp = src_of[tile[i]];
+    const unsigned li = (unsigned)(std::find(tile.begin(), tile.end(), sp) - tile.begin());
+    if (li >= ta.tb) return fail("tile_permute: source bit outside the tile");
+    ta.lp[i] = li;
+    identity = identity && li == i;
+  }
+  if (identity) return 0;
+  const uint64_t ntiles = 1ull << (n - ta.tb);
+  for (unsigned i = 0; i < ta.tb; ++i)
+    if (ta.apos[i] >= 32) return fail("tile_permute: tile bits must lie below bit 32");
+  const size_t lds = ((((size_t)2 << ta.tb) + 15) & ~(size_t)15) + (((((size_t)4 << ta.tb) / VEC) + 15) & ~(size_t)15) +
+                     ((size_t)sizeof(E) << ta.tb);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)tile_permute_kernel<uint32_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)tile_permute_kernel<uint64_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
+  HQ_LAUNCH(c, (tile_permute_kernel<E, VEC>), dim3(grid), dim3(kBlock), lds, a, ta, ntiles);
+  HQ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// A permutation pi of the low s index bits (destination bit i reads source bit pi[i]) that does not fit one
+// LDS tile of t bits, as TWO in-place tile passes: the first permutes the bit set T1 = S \ O1, the second
+// T2 = S \ O2 (first(x) = old[alpha(x)], new(x) = first[beta(x)], alpha o beta = pi).  O1 = the highest
+// s - t bits, so that the first pass is the plain low-bit kernel; O2 = the highest bits outside
+// O1, pi^-1(O1) and the vector bits.  Feasible up to s = 18 (4-byte) / 17 (8-byte elements).
+template <typename E>
+static bool plan_two_pass_swap(const unsigned* pi, unsigned s, unsigned t, std::vector<unsigned>& T1, std::vector<unsigned>& alpha,
+                               std::vector<unsigned>& T2, std::vector<unsigned>& beta) {
+  constexpr unsigned VB = sizeof(E) == 4 ? 2 : 1;
+  if (s <= t || s > 31) return false;
+  const unsigned no = s - t;
+  std::vector<int> inv(s);
+  for (unsigned i = 0; i < s; ++i) inv[pi[i]] = (int)i;
+  std::vector<char> inO1(s, 0), inO2(s, 0), banned(s, 0);
+  for (unsigned a = s - no; a < s; ++a) { inO1[a] = 1; banned[a] = 1; banned[inv[a]] = 1; }
+  for (unsigned b = 0; b < VB; ++b) banned[b] = 1;
+  unsigned got = 0;
+  for (int cbit = (int)s - 1; cbit >= 0 && got < no; --cbit)
+    if (!banned[cbit]) { inO2[cbit] = 1; ++got; }
+  if (got < no) return false;
+  // beta: fixes O2, sends pi^-1(a) to a for a in O1, identity wherever that is still free, the rest in order
+  beta.assign(s, ~0u);
+  std::vector<char> used(s, 0);
+  for (unsigned cbit = 0; cbit < s; ++cbit)
+    if (inO2[cbit]) { beta[cbit] = cbit; used[cbit] = 1; }
+  for (unsigned a = 0; a < s; ++a)
+    if (inO1[a]) { beta[inv[a]] = a; used[a] = 1; }
+  for (unsigned i = 0; i < s; ++i)
+    if (beta[i] == ~0u && !used[i]) { beta[i] = i; used[i] = 1; }
+  unsigned nxt = 0;
+  for (unsigned i = 0; i < s; ++i)
+    if (beta[i] == ~0u) {
+      while (used[nxt]) ++nxt;
+      beta[i] = nxt;
+      used[nxt] = 1;
+    }
+  std::vector<unsigned> binv(s);
+  for (unsigned i = 0; i < s; ++i) binv[beta[i]] = i;
+  alpha.assign(s, 0);
+  for (unsigned x = 0; x < s; ++x) alpha[x] = pi[binv[x]];  // alpha = pi o beta^-1
+  T1.clear();
+  T2.clear();
+  for (unsigned b = 0; b < s; ++b) {
+    if (!inO1[b]) T1.push_back(b);
+    if (!inO2[b]) T2.push_back(b);
+    if (inO1[b] && alpha[b] != b) return false;
+    if (inO2[b] && beta[b] != b) return false;
+  }
+  return T1.size() == t && T2.size() == t;
+}
+
 template <typename E>
 static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsigned s) {
   SwapArg sa;
@@ -962,6 +1050,18 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
   if (identity) return 0;
   const unsigned table_bits = sizeof(E) == 4 ? 13 : 12;  // 32 KiB of elements + index table
   const unsigned max_lds_bits = sizeof(E) == 4 ? 15 : 14;  // 128 KiB of elements, index computed inline
+  static const bool two_pass = !(getenv("HQ_SWAP_TWO_PASS") && atoi(getenv("HQ_SWAP_TWO_PASS")) == 0);
+  if (s > table_bits && two_pass && reinterpret_cast<uintptr_t>(a) % 16 == 0) {
+    // 14 <= s <= 18 (17 for 8-byte elements): two in-place passes through 32 KiB LDS tiles, each at the rate of
+    // the small-s kernel, instead of one 128 KiB-tile pass with the index computed inline (2.1 TB/s) or the
+    // out-of-place gather + copy (1.7 TB/s)
+    std::vector<unsigned> T1, T2, alpha, beta;
+    if (plan_two_pass_swap<E>(pos, s, table_bits, T1, alpha, T2, beta)) {
+      // T1 = the low `table_bits` bits: the first pass is a plain low-bit swap of its own
+      if (swap_device<E>(c, a, alpha.data(), n, table_bits)) return 1;
+      return launch_tile_permute<E>(c, a, n, T2, beta.data());
+    }
+  }
   if (s <= table_bits || (s <= max_lds_bits && reinterpret_cast<uintptr_t>(a) % 16 == 0)) {
     const bool table = s <= table_bits;
     const unsigned tile_bits = std::min<unsigned>(n, std::max<unsigned>(s, 11));

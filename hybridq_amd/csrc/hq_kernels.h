@@ -1190,6 +1190,66 @@ swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
   }
 }
 
+// In-place permutation of the TB index bits `apos` (ascending; the lowest ones are the index bits
+// 0..log2(VEC)-1, so every global access is a 16-byte vector of a contiguous run) inside tiles staged
+// through LDS: new tile element x = old tile element whose tile-local index has bit i of x at bit
+// lp[i].  A low-bit permutation of up to 16 bits (swap_*, transpose()) that does not fit one LDS
+// tile is the product of TWO such passes over different bit sets (host: plan_two_pass_swap).
+constexpr int kTilePermBits = 13;
+struct TilePermArg {
+  unsigned tb;
+  unsigned apos[kTilePermBits];  // global positions of the tile-local bits
+  unsigned lp[kTilePermBits];    // tile-local bit i of the destination index -> tile-local bit of the source index
+};
+
+template <typename E, int VEC> struct PackOf { typedef E type __attribute__((ext_vector_type(VEC))); };
+template <typename E> struct PackOf<E, 1> { typedef E type; };
+
+template <typename E, int VEC>
+__global__ void __launch_bounds__(kBlock)
+tile_permute_kernel(E* __restrict__ a, const TilePermArg ta, const uint64_t ntiles) {
+  using Pack = typename PackOf<E, VEC>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr unsigned VBITS = VEC == 4 ? 2 : (VEC == 2 ? 1 : 0);
+  const unsigned TILE = 1u << ta.tb, NV = TILE >> VBITS;
+  uint16_t* src = reinterpret_cast<uint16_t*>(smem);                                        // TILE entries: permuted tile-local index
+  uint32_t* goff = reinterpret_cast<uint32_t*>(smem + (((size_t)TILE * 2 + 15) & ~(size_t)15));  // NV entries: element offset of vector v
+  E* buf = reinterpret_cast<E*>(reinterpret_cast<unsigned char*>(goff) + (((size_t)NV * 4 + 15) & ~(size_t)15));
+  const unsigned tid = threadIdx.x;
+  for (unsigned x = tid; x < TILE; x += kBlock) {
+    unsigned y = 0;
+    for (unsigned i = 0; i < ta.tb; ++i) y |= ((x >> i) & 1u) << ta.lp[i];
+    src[x] = (uint16_t)y;
+  }
+  for (unsigned v = tid; v < NV; v += kBlock) {  // the tile's bits all sit below bit 32 (swap: s <= 18)
+    uint32_t g = 0;
+    for (unsigned m = VBITS; m < ta.tb; ++m) g |= ((v >> (m - VBITS)) & 1u) << ta.apos[m];
+    goff[v] = g;
+  }
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    uint64_t base = t;  // element index with zeros at the tile's positions
+    for (unsigned m = 0; m < ta.tb; ++m) {
+      const uint64_t lo = (1ull << ta.apos[m]) - 1;
+      base = ((base & ~lo) << 1) | (base & lo);
+    }
+    E* __restrict__ at = a + base;
+    __syncthreads();
+    for (unsigned v = tid; v < NV; v += kBlock)
+      *reinterpret_cast<Pack*>(buf + v * VEC) = __builtin_nontemporal_load(reinterpret_cast<const Pack*>(at + goff[v]));
+    __syncthreads();
+    for (unsigned v = tid; v < NV; v += kBlock) {
+      Pack p;
+      if constexpr (VEC == 1) {
+        p = buf[src[v]];
+      } else {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) p[c] = buf[src[v * VEC + c]];
+      }
+      __builtin_nontemporal_store(p, reinterpret_cast<Pack*>(at + goff[v]));
+    }
+  }
+}
+
 // Out-of-place gather for large s: out[x] = in[(x & ~(S-1)) | perm(x & (S-1))].
 template <typename E>
 __global__ void __launch_bounds__(kBlock)

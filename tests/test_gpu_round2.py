@@ -219,3 +219,28 @@ def test_apply_U_directly_against_reference_core(torch_cuda, oracle_ref):
                 scale = max(np.abs(pl[0]).max(), np.abs(pl[1]).max())
                 err = max(np.abs(dre.cpu().numpy() - pl[0]).max(), np.abs(dim_.cpu().numpy() - pl[1]).max()) / scale
                 assert err <= BAR[np.dtype('complex64' if ft == np.dtype('float32') else 'complex128')], (ft, k, list(pos), err)
+
+
+@pytest.mark.parametrize('dt', ['float32', 'float64', 'int32', 'int64'])
+def test_swap_large_s_two_pass(torch_cuda, dt):
+    """swap_* beyond one LDS tile (s = 14..18 for 4-byte, 13..17 for 8-byte elements): two in-place tile
+    passes (plan_two_pass_swap) instead of the gather + copy fallback; exact for random, rotated and
+    nearly-sorted permutations, n = s and n > s (several chunks), and still exact past the two-pass range
+    (s = 19/20: fallback)."""
+    import oracle
+    from hybridq_amd import core
+    torch = torch_cuda
+    dt = np.dtype(dt)
+    rng = np.random.default_rng(23)
+    first = 14 if dt.itemsize == 4 else 13
+    for s in range(first, first + 7):
+        n = s if s >= 18 else s + int(rng.integers(0, 3))
+        perms = [rng.permutation(s), np.roll(np.arange(s), 5), np.concatenate([np.arange(s - 3), rng.permutation(3) + s - 3]),
+                 np.concatenate([rng.permutation(4), np.arange(4, s)])[::1], np.arange(s)[::-1].copy()]
+        for pos in perms:
+            a = rng.integers(0, 2**31 - 1, 1 << n).astype(dt)
+            exp = oracle.swap_numpy(a, pos)
+            t = torch.from_numpy(a.copy()).cuda()
+            core.swap(t, pos, n)
+            core.sync()
+            assert (t.cpu().numpy() == exp).all(), (dt, s, n, list(pos))

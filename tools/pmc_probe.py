@@ -13,7 +13,8 @@ from hybridq_amd.circuits import haar_unitary  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 core.set_stream(torch.cuda.current_stream().cuda_stream)
-planes = torch.empty((2, 1 << n), dtype=torch.float32, device='cuda')
+from hybridq_amd.simulation import alloc_planes  # noqa: E402
+planes = alloc_planes(n, torch.float32, 'cuda')  # the product's own (tuned) placement
 rng = np.random.default_rng(0)
 core.init_state(planes[0], planes[1], 'plus')
 print('norm2', core.norm2(planes[0], planes[1]))
