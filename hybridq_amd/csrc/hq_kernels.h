@@ -698,8 +698,13 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     for (unsigned e = tid; e < nvec; e += BLOCK) {
       uint64_t g = base;
       for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+#ifdef HQ_BLOCKED_PLAIN_IO
       reinterpret_cast<V*>(xr)[blocked_swz(e)] = vre[g];
       reinterpret_cast<V*>(xi)[blocked_swz(e)] = vim[g];
+#else  // streamed once per pass: keep the tile out of the caches
+      reinterpret_cast<V*>(xr)[blocked_swz(e)] = __builtin_nontemporal_load(vre + g);
+      reinterpret_cast<V*>(xi)[blocked_swz(e)] = __builtin_nontemporal_load(vim + g);
+#endif
     }
     __syncthreads();
     for (unsigned gi = 0; gi < ngates; ++gi) {
@@ -734,8 +739,13 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     for (unsigned e = tid; e < nvec; e += BLOCK) {
       uint64_t g = base;
       for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+#ifdef HQ_BLOCKED_PLAIN_IO
       vre[g] = reinterpret_cast<V*>(xr)[blocked_swz(e)];
       vim[g] = reinterpret_cast<V*>(xi)[blocked_swz(e)];
+#else
+      __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[blocked_swz(e)], vre + g);
+      __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[blocked_swz(e)], vim + g);
+#endif
     }
     __syncthreads();
   }

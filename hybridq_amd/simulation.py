@@ -35,10 +35,15 @@ class FunctionalGate:
     state ``psi`` of shape (2,) + (2,)*n (simulation.py:525-554).  Reference FunctionalGate
     objects (anything with ``.qubits`` and ``.apply`` but no ``.matrix``) are accepted too."""
 
-    def __init__(self, qubits, apply, name='FN'):
+    def __init__(self, qubits, apply, name='FN', on_device=False):
+        """``on_device=True``: `apply` receives the state as a torch CUDA tensor of the same shape
+        (2,)+(2,)*n -- a VIEW of the planes in HBM -- instead of a numpy copy, so that
+        ``hybridq_amd.dot(U, psi, axes_b=..., b_as_complex_array=True, inplace=True)`` (the pattern of the
+        reference's test_simulation_2__fn, tests.py:2037-2110) runs in HBM with no PCIe traffic."""
         self.qubits = tuple(qubits)
         self.apply = apply
         self.name = name
+        self.on_device = bool(on_device)
 
 
 def _is_functional(gate):
@@ -270,15 +275,26 @@ class EvolutionState:
     def apply_functional(self, gate):
         """FunctionalGate branch of the loop (simulation.py:525-554): the gate receives the raw
         (2,)+(2,)*n real array and the current qubit order.  Reference functional gates are
-        host numpy code, so the state makes a D2H/H2D round trip here (rare; device-side
-        projection/measurement are the "next" row of SURVEY 8f)."""
+        host numpy code, so for them the state makes a D2H/H2D round trip here; gates built with
+        ``FunctionalGate(..., on_device=True)`` get a device VIEW of the planes instead, and the
+        built-in Projection / Measure (hybridq_amd.functional) run as device kernels."""
         core.use_torch_stream()
         if callable(getattr(gate, 'apply_device', None)):
             gate.apply_device(self)
             return
         torch = _torch()
-        core.sync()
         order = tuple(q for q, _ in sorted(self.map.items(), key=lambda x: x[1])[::-1])  # :528-530
+        if getattr(gate, 'on_device', False):
+            view = self.planes.view((2,) + (2,) * self.n)  # aliases the planes: axis a+1 <-> qubit order[a]
+            new_psi, new_order = gate.apply(psi=view, order=order)
+            if any(x != y for x, y in zip(order, new_order)):  # :552-554
+                raise RuntimeError("'order' has changed.")
+            if not (hasattr(new_psi, 'data_ptr') and new_psi.data_ptr() == self.planes.data_ptr()):
+                # a new array came back (:545-550): bring it into the planes (device to device)
+                new_psi = torch.as_tensor(new_psi, device=self.planes.device).to(self.planes.dtype)
+                self.planes.copy_(new_psi.reshape(2, -1))
+            return
+        core.sync()
         host = self.planes.cpu().numpy().reshape((2,) + (2,) * self.n)
         new_psi, new_order = gate.apply(psi=host, order=order)
         if any(x != y for x, y in zip(order, new_order)):  # :552-554
@@ -387,6 +403,52 @@ def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
     return gates
 
 
+#: Cost model of the schedules (ms per pass over a complex64 state of 2^30 amplitudes on MI355X, tuned
+#: placement; profiles/r02_v1_bench.json `per_k`, `blocked`): a pass costs the same for every k <= 4, k = 5 is
+#: HBM-bound with the matrix cores at 66 %, k >= 6 is matrix-core bound; a cache-blocked pass costs one HBM
+#: round trip plus matrix-core time per inner gate.  Times scale with 2^n and with the element size.
+PASS_MS = {1: 2.70, 2: 2.70, 3: 2.70, 4: 2.76, 5: 3.08, 6: 4.70, 7: 10.4, 8: 18.7, 9: 36.1, 10: 73.7}
+BLOCKED_BASE_MS = 2.9
+BLOCKED_INNER_MS = {1: 0.38, 2: 0.75, 3: 0.75, 4: 1.27}
+LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)
+
+
+def estimate_ms(ops, n, ctype):
+    """Modelled device time of an op list of _plan_ops (functional gates cost nothing here)."""
+    scale = 2.0 ** (n - 30) * (2.0 if np.dtype(ctype) == np.dtype('complex128') else 1.0)
+    t = 0.0
+    for g in ops:
+        if _is_functional(g):
+            continue
+        if isinstance(g[0], str):
+            if g[0] == 'B':
+                ms = BLOCKED_BASE_MS + sum(BLOCKED_INNER_MS[len(p)] for _, p in g[2])
+            else:
+                ms = PASS_MS[len(g[2])]
+        else:
+            ms = PASS_MS[min(len(g[0]), 10)]
+        t += max(ms * scale, LAUNCH_FLOOR_MS)  # small states: a launch costs more than the pass
+    return t
+
+
+def choose_schedule(circuit, qubits, n, ctype):
+    """Plan the circuit every way this driver knows -- gate by gate, fused to 4 qubits (the reference's
+    default, simulation.py:314), fused to 5, cache-blocked -- and keep the plan with the smallest
+    modelled time.  Host work only, outside the timed loop like the reference's own compression
+    (simulation.py:436-454 precede :519).  Returns (ops, info)."""
+    cands = {'per_gate': dict(compress=0, blocked=False), 'fused_4': dict(compress=4, blocked=False),
+             'fused_5': dict(compress=5, blocked=False)}
+    if n >= 14:
+        cands['blocked'] = dict(compress=5, blocked=True)
+    plans, est = {}, {}
+    for name, kw in cands.items():
+        plans[name] = _plan_ops(circuit, qubits, n, ctype, kw['compress'], kw['blocked'])
+        est[name] = estimate_ms(plans[name], n, ctype)
+    best = min(est, key=est.get)
+    return plans[best], {'chosen': best, 'modelled_ms': {k: round(v, 4) for k, v in est.items()},
+                         'passes': {k: sum(1 for g in v if not _is_functional(g)) for k, v in plans.items()}}
+
+
 def _execute_ops(state, gates):
     """The gate loop (simulation.py:522-646); returns the number of passes over the state."""
     n = state.n
@@ -435,10 +497,11 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     kwargs.setdefault('return_info', False)
     kwargs.setdefault('return_numpy_array', True)
     kwargs.setdefault('max_largest_intermediate', 2**36)
+    auto_schedule = optimize == 'evolution-hip' and 'blocked' not in kwargs and 'compress' not in kwargs
     if optimize == 'evolution-hip':
-        # the settings measured fastest on MI355X instead of the reference's defaults: cache-blocked
-        # passes (214 ms for the n=30 benchmark circuit) and, where blocking does not apply (n < 14),
-        # fusion to width 5 -- a k = 5 pass costs ~10 % more than a k <= 4 pass (337 vs 441 ms)
+        # this GPU's own schedule instead of the reference's defaults: the cost model below picks between
+        # gate-by-gate passes, fusion to width 4 / 5 (a k = 5 pass costs ~15 % more than a k <= 4 pass) and
+        # cache-blocked passes (many gates per HBM pass); explicit `compress=` / `blocked=` override it
         kwargs.setdefault('blocked', True)
         kwargs.setdefault('compress', 5)
     kwargs.setdefault('compress', 4)  # simulation.py:314
@@ -460,7 +523,11 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
             raise ValueError("Active qubits have changed after simplification. Forcing stop.")
     ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
     # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519)
-    gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
+    schedule_info = None
+    if auto_schedule:
+        gates, schedule_info = choose_schedule(circuit, qubits, n, ctype)
+    else:
+        gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
     if 2**n > kwargs['max_largest_intermediate']:  # simulation.py:409-412
         raise MemoryError("Memory for the given number of qubits exceeds the 'max_largest_intermediate'.")
 
@@ -476,6 +543,8 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     core.sync()  # the ONLY synchronisation of the loop
     t1 = time.perf_counter()  # simulation.py:666
     info['runtime (s)'] = t1 - t0
+    if schedule_info is not None:
+        info['schedule'] = schedule_info
     info['n_gates'] = len(gates)  # apply_U calls issued (after fusion)
     info['n_passes'] = n_passes  # passes over the state (blocked passes count once)
     info['n_gates_given'] = n_given

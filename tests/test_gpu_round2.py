@@ -244,3 +244,75 @@ def test_swap_large_s_two_pass(torch_cuda, dt):
             core.swap(t, pos, n)
             core.sync()
             assert (t.cpu().numpy() == exp).all(), (dt, s, n, list(pos))
+
+
+def test_functional_gates_with_dot_inplace_on_device(torch_cuda):
+    """Mirror of the reference's test_simulation_2__fn (tests.py:2037-2110): n = 14, 400 random NON-unitary
+    gates, about half of them wrapped as FunctionalGates whose body is ``dot(U, psi, axes_b=axes,
+    b_as_complex_array=True, inplace=True)`` on the raw split-plane state; mixed '01+-' initial state.  Here
+    the functional gates see a DEVICE view of the planes (on_device=True), so every inner dot() is one
+    kernel in HBM; the same gates written against numpy (host round trip per gate) must agree, and both
+    must equal the plain circuit and an independent complex128 evolution."""
+    import oracle
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.dot import dot
+    from hybridq_amd.simulation import FunctionalGate, simulate
+    n, depth = 14, 400
+    rng = np.random.default_rng(77)
+    gates = random_dense(n, depth, kmax=2, seed=78)
+    calls = {'device': 0, 'host': 0}
+
+    def as_fn(U, qubits, on_device):
+        def f(psi, order):
+            if psi.ndim - len(order) != 1:
+                raise ValueError("'psi' is not consistent with order")
+            axes = [next(i for i, y in enumerate(order) if y == x) for x in qubits]
+            calls['device' if on_device else 'host'] += 1
+            if on_device:
+                assert psi.is_cuda
+            else:
+                assert isinstance(psi, np.ndarray)
+            return dot(a=U, b=psi, axes_b=axes, b_as_complex_array=True, inplace=True), order
+        return FunctionalGate(qubits, f, on_device=on_device)
+
+    pick = rng.random(len(gates)) < 0.5
+    circ_dev = [as_fn(U, qs, True) if p else (U, qs) for (U, qs), p in zip(gates, pick)]
+    init = ''.join(rng.choice(list('01+-'), size=n))
+    exp = oracle.evolve_tensordot(gates, n, initial_state=init, qubits=list(range(n)))
+    scale = np.abs(exp).max()
+    tol = circuit_tol(gates)
+    psi = simulate(gates, initial_state=init, complex_type='complex64', qubits=list(range(n))).reshape(-1)
+    psi_fn = simulate(circ_dev, initial_state=init, complex_type='complex64', qubits=list(range(n))).reshape(-1)
+    assert calls['device'] == int(pick.sum()) and calls['host'] == 0
+    assert np.abs(psi - exp).max() / scale < tol
+    assert np.abs(psi_fn - exp).max() / scale < tol
+    # complex128 and the host variant of the same functional gates (a shorter circuit: every host gate is a
+    # D2H + H2D round trip of the state)
+    short = gates[:60]
+    circ_host = [as_fn(U, qs, False) if p else (U, qs) for (U, qs), p in zip(short, pick)]
+    circ_dev2 = [as_fn(U, qs, True) if p else (U, qs) for (U, qs), p in zip(short, pick)]
+    exp2 = oracle.evolve_tensordot(short, n, initial_state=init, qubits=list(range(n)))
+    a = simulate(circ_host, initial_state=init, complex_type='complex128', qubits=list(range(n))).reshape(-1)
+    b = simulate(circ_dev2, initial_state=init, complex_type='complex128', qubits=list(range(n))).reshape(-1)
+    assert calls['host'] == int(pick[:60].sum())
+    assert np.abs(a - exp2).max() / np.abs(exp2).max() < 1e-12
+    assert np.abs(b - exp2).max() / np.abs(exp2).max() < 1e-12
+
+
+def test_evolution_hip_chooses_a_schedule(torch_cuda):
+    """optimize='evolution-hip': the cost model picks between gate-by-gate / fused 4 / fused 5 / cache-blocked
+    and records the choice; whatever it picks, the state is the circuit's."""
+    import oracle
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    for n, gates in ((12, rqc_1q2q(12, depth=10, seed=1)), (20, rqc_1q2q(20, depth=12, seed=2)),
+                     (18, random_dense(18, 24, kmax=6, seed=3, unitary=True))):
+        psi, info = simulate(gates, initial_state='0' * n, optimize='evolution-hip', return_info=True, qubits=list(range(n)))
+        sch = info['schedule']
+        assert sch['chosen'] in sch['modelled_ms'] and sch['modelled_ms'][sch['chosen']] == min(sch['modelled_ms'].values())
+        assert ('blocked' in sch['modelled_ms']) == (n >= 14)
+        exp = oracle.evolve_tensordot(gates, n, qubits=list(range(n)))
+        assert np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max() < circuit_tol(gates), (n, sch)
+    # an explicit setting overrides the model
+    _, info = simulate(rqc_1q2q(16, depth=6, seed=4), initial_state='0' * 16, optimize='evolution-hip', compress=3, return_info=True)
+    assert 'schedule' not in info

@@ -1,0 +1,39 @@
+"""A/B of the cache-blocked schedule of the n = 30 benchmark circuit (HQ_HIP_LIBRARY selects the build)."""
+import os
+import sys
+import time
+
+os.environ.setdefault('OPENBLAS_NUM_THREADS', '8')
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hybridq_amd import core  # noqa: E402
+from hybridq_amd.blocking import blocked_stats, plan_blocked  # noqa: E402
+from hybridq_amd.circuits import rqc_1q2q  # noqa: E402
+from hybridq_amd.simulation import EvolutionState  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+gates = rqc_1q2q(n, depth=40, seed=n)
+state = EvolutionState(list(range(n)), complex_type='complex64', initial_state='0' * n)
+for kw in (dict(), dict(inner_max=0)):
+    ops = plan_blocked(gates, state.map, n, tile_bits=13, low_bits=5, complex_type='complex64', **kw)
+    packed = [('B', op[1], core.pack_blocked(op[2], 'complex64')) if op[0] == 'B' else op for op in ops]
+
+    def run():
+        for op in packed:
+            if op[0] == 'G':
+                core.apply_U(state.planes[0], state.planes[1], op[1], op[2], n)
+            else:
+                core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
+    run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    st = blocked_stats(ops)
+    print(os.path.basename(os.environ.get('HQ_HIP_LIBRARY', 'in-tree')), kw, f"passes {st['blocked_passes']} + {st['plain_gates']} plain, inner {st['inner_gates']}:",
+          ' '.join('%.1f' % t for t in ts), 'ms', flush=True)
