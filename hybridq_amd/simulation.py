@@ -101,6 +101,9 @@ PLANE_PAD_BYTES = 12288
 #: winner of 4-6 draws: 2.68-2.76 ms per gate against 3.04 ms (6.2-6.4 vs 5.6 TB/s).
 #: HQ_STATE_ALLOC=torch switches the mechanism off, HQ_STATE_TRIES sets the number of draws.
 VMM_MIN_BYTES = 1 << 28
+#: a draw that streams at least this fast (TB/s in the probe) ends the search early; slower ones are
+#: what torch / hipMalloc memory gives anyway, so the search goes on to its draw limit
+GOOD_DRAW_TBPS = 5.9
 #: what the last tuned allocation found (bench.py reports it)
 last_placement = {}
 
@@ -151,9 +154,10 @@ def _probe_ms(planes, n, float_type):
 
 
 def _tuned_planes(n, stride, itemsize, dev, tries):
-    """Draw `tries` VMM placements (alternating 2 MiB granules in creation order and 8 MiB granules
-    shuffled), probe each, keep the fastest.  The rejected draws are held until the search ends so
-    that every draw sees different physical memory."""
+    """Draw up to `tries` VMM placements (alternating 8 MiB granules shuffled and 2 MiB granules in
+    creation order), probe each, keep the fastest; stop after three draws once one is clearly faster
+    than the median (> 7 %) or all agree within 3 %.  The rejected draws are held until the search
+    ends so that every draw sees different physical memory."""
     torch = _torch()
     core.use_torch_stream()
     typestr = '<f4' if itemsize == 4 else '<f8'
@@ -163,6 +167,11 @@ def _tuned_planes(n, stride, itemsize, dev, tries):
     tries = max(1, min(tries, int(0.6 * free_b // nbytes)))
     cands, log = [], []
     for k in range(tries):
+        if k >= 3:  # enough evidence?  a clear winner among slower draws, or draws that do not differ
+            ms_all = sorted(c[0] for c in cands)
+            fast = 4 * (1 << n) * itemsize / ms_all[0] / 1e9 >= GOOD_DRAW_TBPS
+            if fast and (ms_all[0] < 0.93 * ms_all[len(ms_all) // 2] or ms_all[-1] < 1.03 * ms_all[0]):
+                break
         owner = _VmmPlanes(nbytes, (2, stride), typestr, (2 << 20) if k % 2 else (8 << 20), 0 if k % 2 else 100 + k)
         raw = torch.as_tensor(owner, device=dev)
         if raw.data_ptr() != owner.buf.ptr:
@@ -194,7 +203,7 @@ def alloc_planes(n, torch_dtype, device, vmm=True):
     nbytes = 2 * stride * itemsize
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
     if vmm and nbytes >= VMM_MIN_BYTES and os.environ.get('HQ_STATE_ALLOC', 'vmm') == 'vmm' and dev.index in (None, torch.cuda.current_device()):
-        default_tries = 4 if nbytes <= (16 << 30) else (2 if nbytes <= (64 << 30) else 1)
+        default_tries = 8 if nbytes <= (16 << 30) else (3 if nbytes <= (64 << 30) else 1)
         try:
             return _tuned_planes(n, stride, itemsize, dev, int(os.environ.get('HQ_STATE_TRIES', default_tries)))
         except Exception as e:  # noqa: BLE001 -- the driver refused (fragmented HBM, VMM unavailable): torch's allocator
