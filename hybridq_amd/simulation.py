@@ -172,7 +172,10 @@ def _tuned_planes(n, stride, itemsize, dev, tries):
             fast = 4 * (1 << n) * itemsize / ms_all[0] / 1e9 >= GOOD_DRAW_TBPS
             if fast and (ms_all[0] < 0.93 * ms_all[len(ms_all) // 2] or ms_all[-1] < 1.03 * ms_all[0]):
                 break
-        owner = _VmmPlanes(nbytes, (2, stride), typestr, (2 << 20) if k % 2 else (8 << 20), 0 if k % 2 else 100 + k)
+        # families that were fast at least sometimes (profiles/r02_placement_3_vmm_layouts.txt): 2 MiB granules in
+        # creation order, 4 / 8 / 16 MiB granules shuffled; which one wins differs from box to box and draw to draw
+        gran = (2 << 20) if k % 2 else ((8 << 20), (4 << 20), (16 << 20), (8 << 20))[(k // 2) % 4]
+        owner = _VmmPlanes(nbytes, (2, stride), typestr, gran, 0 if k % 2 else 100 + k)
         raw = torch.as_tensor(owner, device=dev)
         if raw.data_ptr() != owner.buf.ptr:
             raise RuntimeError('torch did not alias the mapped buffer')
