@@ -121,6 +121,14 @@ int hq_to_complex128(double *psi_re, double *psi_im, double *psi_out, uint64_t s
  * allocator exists because placement is worth ~14 % of HBM bandwidth. */
 int hq_alloc(void **dev_ptr, uint64_t bytes, int flags);
 int hq_free(void *dev_ptr);
+/* The same through HIP's virtual-memory-management calls: n_granules physical granules of `granule` bytes (a multiple
+ * of the driver minimum, returned in *granule_min when non-NULL) are created in sequence and granule i is mapped at
+ * virtual slot va_slot[i] (a permutation of 0..n_granules-1) of ONE contiguous virtual range.  hq_alloc_scattered:
+ * ceil(bytes / granule) granules in creation order (seed 0) or shuffled by `seed`.  Free with hq_free (the physical
+ * granules are released, the virtual range is retired).  hybridq_amd.simulation.alloc_planes draws a few such
+ * placements, probes each with gate applications and keeps the fastest. */
+int hq_alloc_mapped(void **dev_ptr, uint64_t granule, uint64_t n_granules, const uint32_t *va_slot, uint64_t *granule_min);
+int hq_alloc_scattered(void **dev_ptr, uint64_t bytes, uint64_t granule, uint64_t seed);
 
 /* Device-side initial states (counterpart of prepare_state,
  * hybridq/circuit/simulation/utils.py:106-113): kind 0 -> |basis> (re[basis]=1),

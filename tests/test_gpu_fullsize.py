@@ -189,3 +189,33 @@ def test_full_size_permute_bits_and_exchange_layout(torch_cuda):
     g = 3
     view = src.view(1 << g, 1 << (m - g))
     assert int(view[5, 123].view(torch.int32)) == (5 << (m - g)) + 123
+
+
+@pytest.mark.parametrize('n', [34])
+def test_n34_on_one_gpu_tuned_placement(torch_cuda, n):
+    """north_star's upper sizes: n = 34 (128 GiB of planes, the density-matrix config's size) on one GPU through
+    simulation.alloc_planes (VMM-backed, 64-bit indexing everywhere): U then U^dagger restores a spread state for
+    every kernel family (k = 1..7, targets on the top index bits), marginals and samples stay uniform."""
+    torch = torch_cuda
+    from hybridq_amd import core
+    from hybridq_amd.circuits import haar_unitary
+    from hybridq_amd.simulation import alloc_planes
+    free, _ = torch.cuda.mem_get_info()
+    if free < 1.1 * 8 * (1 << n):
+        pytest.skip(f'needs {8 * (1 << n) >> 30} GiB of free HBM')
+    core.use_torch_stream()
+    rng = np.random.default_rng(n)
+    planes = alloc_planes(n, torch.float32, 'cuda')
+    core.init_state(planes[0], planes[1], 'plus')
+    for pos in ([3], [n - 1], [0, n - 1], [5, 17, n - 2], [1, 9, n - 3, n - 1], [2, 11, 20, n - 2, n - 1],
+                [4, 8, 15, 22, n - 2, n - 1], [0, 6, 12, 18, 24, n - 3, n - 1]):
+        U = haar_unitary(1 << len(pos), rng)
+        core.apply_U(planes[0], planes[1], U, pos, n)
+        mid = planes[0][:: (1 << n) // 4096][:4096].double().cpu().numpy() * 2.0 ** (n / 2)
+        assert np.abs(mid - 1).max() > 1e-3, pos  # the gate did something
+        core.apply_U(planes[0], planes[1], U.conj().T, pos, n)
+        back = planes[0][:: (1 << n) // 4096][:4096].double().cpu().numpy() * 2.0 ** (n / 2)
+        assert np.abs(back - 1).max() < 1e-5, (pos, np.abs(back - 1).max())
+    assert abs(core.norm2(planes[0], planes[1]) - 1.0) < 1e-5
+    pr = core.probabilities(planes[0], planes[1], [3, 17, n - 2, n - 1], n)
+    assert np.abs(pr - 1 / 16).max() < 1e-6
