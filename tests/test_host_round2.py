@@ -1,0 +1,111 @@
+"""CPU tests of the round-2 host logic: schedule cost model, eviction folding, restore planning with few
+moved bits, the tolerance model, compress validation, the reference-shaped dot/transpose numpy routes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_choose_schedule_cost_model():
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    from hybridq_amd.simulation import PASS_MS, choose_schedule, estimate_ms
+    n = 30
+    gates = rqc_1q2q(n, depth=40, seed=n)
+    ops, info = choose_schedule(gates, list(range(n)), n, np.dtype('complex64'))
+    est = info['modelled_ms']
+    # measured on MI355X (profiles/r02_v2_bench.json): 2431 / 399-408 / 307 / 213-219 ms
+    assert abs(est['per_gate'] - 2431) < 50 and abs(est['fused_4'] - 400) < 25 and abs(est['fused_5'] - 307) < 15
+    assert abs(est['blocked'] - 216) < 15 and info['chosen'] == 'blocked'
+    assert est['per_gate'] == pytest.approx(900 * PASS_MS[1], rel=1e-6)
+    # complex128 costs twice the bytes, one qubit less halves them
+    assert estimate_ms(ops, n, np.dtype('complex128')) == pytest.approx(2 * estimate_ms(ops, n, np.dtype('complex64')))
+    # tiny states: the launch floor decides, i.e. the fewest calls win; blocking needs n >= 14
+    _, small = choose_schedule(rqc_1q2q(10, depth=8, seed=1), list(range(10)), 10, np.dtype('complex64'))
+    assert 'blocked' not in small['modelled_ms'] and small['chosen'] in ('fused_4', 'fused_5')
+    assert small['passes'][small['chosen']] == min(small['passes'].values())
+    # wide gates are priced by their own width
+    wide = [g for g in random_dense(20, 40, kmax=7, seed=3) if len(g[1]) >= 6][:3]
+    _, w = choose_schedule(wide, list(range(20)), 20, np.dtype('complex64'))
+    assert w['modelled_ms']['per_gate'] >= sum(PASS_MS[len(q)] for _, q in wide) * 2.0 ** (20 - 30) - 1e-9
+
+
+def test_fuse_evictions_and_restore_moves_few_bits():
+    from hybridq_amd.dist import fuse_evictions, plan_restore, plan_schedule
+    sched = [('G', 0), ('P', [1, 0, 2]), ('X',), ('G', 1), ('X',), ('P', [2, 1, 0]), ('G', 2), ('P', [0, 2, 1]), ('X',)]
+    out = fuse_evictions(sched)
+    assert [op[0] for op in out] == ['G', 'XP', 'G', 'X', 'P', 'G', 'XP'] and out[1][1] == [1, 0, 2]
+    # restore after a depth-40 circuit at the target scale: every permutation pass keeps the qubits that are
+    # already in place (the old planner refilled every untouched qubit and moved 19-29 bits)
+    from hybridq_amd.circuits import rqc_1q2q
+    for n, g in ((30, 3), (33, 3), (24, 2)):
+        gq = [tuple(qs) for _, qs in rqc_1q2q(n, depth=40, seed=n)]
+        _, pos = plan_schedule(gq, list(range(n)), g)
+        ops, final = plan_restore(pos, list(range(n)), g)
+        assert all(final[q] == n - 1 - q for q in range(n))
+        wrong = sum(pos[q] != n - 1 - q for q in range(n))
+        for op in ops:
+            if op[0] == 'P':
+                moved = sum(1 for i, p in enumerate(op[1]) if p != i)
+                assert moved <= wrong + 2 * g, (n, moved, wrong)
+
+
+def test_tolerance_model():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from tolerances import BAR, circuit_tol, rounding_bound, widths
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    short = rqc_1q2q(10, depth=4, seed=1)  # 30 gates: the bar itself
+    assert circuit_tol(short) == BAR[np.dtype('complex64')] and circuit_tol(short, short, 'complex128') == 1e-12
+    long_ = rqc_1q2q(24, depth=40, seed=24)
+    one, two = circuit_tol(long_), circuit_tol(long_, long_)
+    assert 1e-6 < one < two < 6e-6 and two == pytest.approx(one * np.sqrt(2))
+    assert rounding_bound([1] * 100) == pytest.approx(rounding_bound([(1, 1.0)] * 100))
+    # unitary gates have kappa = 1, Ginibre ones loosen the bound
+    assert all(k == 1.0 for _, k in widths(long_[:50]))
+    nonu = random_dense(12, 50, kmax=2, seed=2)
+    assert rounding_bound(widths(nonu)) > rounding_bound([len(q) for _, q in nonu])
+
+
+def test_compress_options_validated_before_planning():
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import _plan_ops
+    g = rqc_1q2q(8, depth=4, seed=1)
+    with pytest.raises(ValueError, match='limited to 10 qubits'):
+        _plan_ops(g, list(range(8)), 8, np.dtype('complex64'), 11, False)
+    with pytest.raises(ValueError, match='skip_compression'):
+        _plan_ops(g, list(range(8)), 8, np.dtype('complex64'), {'max_n_qubits': 4, 'skip_compression': ['X']}, False)
+    a = _plan_ops(g, list(range(8)), 8, np.dtype('complex64'), {'max_n_qubits': 4, 'exclude_qubits': [0, 1]}, False)
+    b = _plan_ops(g, list(range(8)), 8, np.dtype('complex64'), 4, False)
+    assert len(a) > len(b)  # gates on the excluded qubits stay on their own
+
+
+def test_dot_and_transpose_numpy_routes():
+    from hybridq_amd.dot import dot, to_complex_array
+    from hybridq_amd.transpose import transpose
+    rng = np.random.default_rng(0)
+    n = 7
+    psi = (rng.standard_normal((2,) * n) + 1j * rng.standard_normal((2,) * n)).astype(np.complex64)
+    for axes in ([3], [5, 1], [0, 6, 2]):
+        k = len(axes)
+        U = (rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k))).astype(np.complex64)
+        exp = np.moveaxis(np.tensordot(U.reshape((2,) * (2 * k)), psi, axes=(list(range(k, 2 * k)), axes)), list(range(k)), axes)
+        got = dot(U, psi, axes, force_numpy=True)
+        assert np.abs(got - exp).max() < 1e-5
+        split = dot(U, to_complex_array(psi), axes, b_as_complex_array=True, force_numpy=True)
+        assert np.abs(split[0] + 1j * split[1] - exp).max() < 1e-5
+    with pytest.raises(IndexError):
+        dot(np.eye(2), psi, [n], force_numpy=True)
+    with pytest.raises(ValueError):
+        dot(np.eye(4), psi, [1], force_numpy=True)
+    a = rng.standard_normal((2,) * 9).astype(np.float32)
+    ax = [0, 1, 6, 3, 8, 2, 7, 4, 5]
+    assert np.array_equal(transpose(a, ax, force_numpy=True), np.transpose(a, ax))
+    assert transpose(a, list(range(9))) is not None  # already ordered: returned as is
+    with pytest.raises(NotImplementedError):
+        transpose(a, [0, 1, 2, 3, 4, 5, 6, 8, 7])  # two unordered trailing axes: outside the core's domain
+    with pytest.raises(ValueError):
+        transpose(a, [0, 0, 1, 2, 3, 4, 5, 6, 7])
