@@ -6,8 +6,8 @@ circuit for :func:`hybridq_amd.simulation.simulate`.
 
 Gate matrices follow hybridq/gate/gate.py:127-348 (fixed gates; SQRT_* and P/T through
 scipy's sqrtm / fractional power like the reference; rotations exp(-i r P / 2),
-property.py:676) and the aliases of gate.py:351-365.  ``#@`` extension blocks (qubit maps,
-powers, tags, explicit matrices) are not supported and raise."""
+property.py:676) and the aliases of gate.py:351-365, plus the ``#@`` extension blocks of the reference's writer
+(qubit maps, powers, conj / T, explicit matrices; tags are dropped)."""
 import numpy as np
 from scipy.linalg import fractional_matrix_power, sqrtm
 
@@ -51,16 +51,59 @@ PARAM = {
 }
 
 
+def _parse_extensions(lines):
+    """Split the text into (extensions, gate line) records.  HybridQ's QASM extensions are comment lines that
+    start with ``#@`` (hybridq/extras/io/qasm.py:57-75, written by to_qasm :160-233): ``#@ key =`` followed by a
+    JSON value spread over ``#@`` lines (``qubits``: QASM index -> label, ``tags``, ``U``: the matrix of a ``matrix``
+    gate), ``#@ power = p``, ``#@ conj``, ``#@ T``.  Extensions apply to the next gate line; ``qubits`` is global."""
+    import json
+    pending, records, qmap = {}, [], None
+    i = 0
+    while i < len(lines):
+        raw = lines[i].strip()
+        i += 1
+        if not raw.startswith('#@'):
+            if raw and not raw.startswith('#'):
+                records.append((pending, raw, i))
+                pending = {}
+            continue
+        body = raw[2:].strip()
+        if body in ('conj', 'T'):
+            pending[body] = True
+            continue
+        if '=' not in body:
+            raise ValueError(f'line {i}: unknown extension {body!r}')
+        key, val = (x.strip() for x in body.split('=', 1))
+        if not val:  # JSON value on the following #@ lines: read until it parses
+            buf = ''
+            while i < len(lines) and lines[i].strip().startswith('#@'):
+                buf += lines[i].strip()[2:] + '\n'
+                i += 1
+                try:
+                    val = json.loads(buf)
+                    break
+                except json.JSONDecodeError:
+                    val = None
+            if val is None:
+                raise ValueError(f'extension {key!r}: malformed JSON value')
+        else:
+            val = json.loads(val)
+        if key == 'qubits':
+            qmap = {int(k): (int(v) if str(v).lstrip('-').isdigit() else v) for k, v in val.items()}
+        else:
+            pending[key] = val
+    return records, qmap
+
+
 def from_qasm(text):
-    """Parse `text` into ``[(U, qubits), ...]`` (identity gates are kept as explicit matrices)."""
+    """Parse `text` into ``[(U, qubits), ...]`` (identity gates are kept as explicit matrices).  Supports the
+    ``#@`` extensions of HybridQ's writer: the qubits map (labels instead of QASM indices), ``power`` (matrix
+    power through scipy like gate/property.py:433), ``conj``, ``T``, ``U`` for ``matrix`` gates; ``tags`` are
+    read and dropped.  A gate without qubits (``.``) cannot be simulated and raises."""
+    records, qmap = _parse_extensions(text.splitlines())
     gates = []
     first = True
-    for ln, raw in enumerate(text.splitlines(), 1):
-        line = raw.strip()
-        if line.startswith('#@'):
-            raise NotImplementedError(f'line {ln}: #@ extension blocks are not supported by this reader')
-        if not line or line.startswith('#'):
-            continue
+    for ext, line, ln in records:
         tok = line.split()
         if first and len(tok) == 1 and tok[0].isdigit():
             first = False
@@ -69,19 +112,43 @@ def from_qasm(text):
         name = tok[0].upper()
         name = ALIASES.get(name, name)
         args = tok[1:]
+        if args and args[0] == '.':
+            raise ValueError(f"line {ln}: gate '{tok[0]}' has no qubits ('.'): nothing to simulate")
+
+        def labels(idx):
+            out = tuple(int(q) for q in idx)
+            return tuple(qmap.get(q, q) for q in out) if qmap else out
+
         if name == 'I':
-            qs = tuple(int(q) for q in args)
-            gates.append((np.eye(1 << len(qs), dtype=np.complex128), qs))
+            qs = labels(args)
+            U = np.eye(1 << len(qs), dtype=np.complex128)
+        elif name == 'MATRIX':
+            if 'U' not in ext:
+                raise ValueError(f"line {ln}: 'matrix' needs a '#@ U =' block")
+            U = np.asarray([[complex(str(x).replace(' ', '')) for x in row] for row in ext['U']], dtype=np.complex128)
+            qs = labels(args)
+            if U.shape != (1 << len(qs),) * 2:
+                raise ValueError(f'line {ln}: matrix shape {U.shape} does not fit {len(qs)} qubit(s)')
         elif name in FIXED:
             k, U = FIXED[name]
             if len(args) != k:
                 raise ValueError(f'line {ln}: {name} takes {k} qubit(s)')
-            gates.append((U, tuple(int(q) for q in args)))
+            qs = labels(args)
         elif name in PARAM:
             k, npar, gen = PARAM[name]
             if len(args) != k + npar:
                 raise ValueError(f'line {ln}: {name} takes {k} qubit(s) and {npar} parameter(s)')
-            gates.append((np.asarray(gen(*args[k:]), dtype=np.complex128), tuple(int(q) for q in args[:k])))
+            U = np.asarray(gen(*args[k:]), dtype=np.complex128)
+            qs = labels(args[:k])
         else:
             raise ValueError(f"line {ln}: gate '{tok[0]}' is not supported")
+        U = np.asarray(U, dtype=np.complex128)
+        if 'power' in ext and float(ext['power']) != 1:
+            p = float(ext['power'])
+            U = np.linalg.matrix_power(U, int(p)) if p == int(p) else fractional_matrix_power(U, p)
+        if ext.get('conj'):
+            U = U.conj()
+        if ext.get('T'):
+            U = U.T
+        gates.append((np.ascontiguousarray(U), qs))
     return gates

@@ -491,7 +491,8 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     ``'evolution-hip'``: same path with this GPU's fastest settings, ``blocked=True`` /
     ``compress=5``, as defaults); everything the reference routes elsewhere (einsum, tensor
     networks, Clifford) is out of scope.
-    Supported kwargs: ``return_info``, ``return_numpy_array`` (default True),
+    Supported kwargs: ``allow_sampling`` / ``sampling_seed`` (stochastic gates = objects with ``.sample()``, as
+    at simulation.py:241-256), ``return_info``, ``return_numpy_array`` (default True),
     ``max_largest_intermediate`` (default 2**36 amplitudes: one MI355X holds n=34 in
     complex64), ``compress`` (max qubits of a fused gate, default 4 like simulation.py:314;
     0 applies the gates as given; a dict may carry ``max_n_qubits`` plus the keyword
@@ -524,6 +525,19 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
         raise ValueError("'initial_state' must be specified for optimize='evolution'.")
 
     circuit = list(circuit)
+    # Stochastic gates (simulation.py:241-256): anything with a ``.sample()`` method -- the reference's
+    # ``StochasticGate`` duck-typed -- is replaced by one draw when `allow_sampling` is set; `sampling_seed`
+    # seeds numpy's global generator for the draws and the previous state is restored afterwards.
+    if kwargs.pop('allow_sampling', False):
+        seed = kwargs.pop('sampling_seed', None)
+        saved = np.random.get_state() if seed is not None else None
+        if seed is not None:
+            np.random.seed(int(seed))
+        circuit = [g.sample() if callable(getattr(g, 'sample', None)) and not isinstance(g, (tuple, list)) else g for g in circuit]
+        if saved is not None:
+            np.random.set_state(saved)
+    else:
+        kwargs.pop('sampling_seed', None)
     qubits = kwargs.get('qubits') or all_qubits(circuit)
     n = len(qubits)
     n_given = len(circuit)

@@ -498,7 +498,42 @@ def matrix_vectors():
     print('e2e_matrix.npz:', {k: v.shape for k, v in out.items() if k.endswith('matrix')})
 
 
+def qasm_vectors():
+    """e2e_qasm_ext.npz: a circuit with string / tuple-free labels, powers, conj / T and a MATRIX gate written
+    by the reference's to_qasm (hybridq/extras/io/qasm.py:160) -- the text it produced (output data) and every
+    gate's matrix and qubits, for the reader's ``#@`` extension blocks."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    from hybridq.circuit import Circuit
+    from hybridq.extras.io.qasm import to_qasm
+    from hybridq.gate import Gate
+    np.random.seed(1234)
+    rnd = np.random.standard_normal((4, 4)) + 1j * np.random.standard_normal((4, 4))
+    U, _ = np.linalg.qr(rnd)
+    c = Circuit([
+        Gate('H', qubits=[42]),
+        Gate('RZ', qubits=[7], params=[0.5])**1.23,
+        Gate('CX', qubits=[42, 7]).conj(),
+        Gate('ISWAP', qubits=[7, 3]).T(),
+        Gate('SQRT_X', qubits=[3], tags={'a': 1})**2,
+        Gate('MATRIX', qubits=[3, 42], U=U),
+        Gate('MATRIX', qubits=[7], U=U[:2, :2] * 0.5)**0.5,
+        Gate('CPHASE', qubits=[3, 7], params=[0.25]).conj().T(),
+        Gate('U3', qubits=[42], params=[0.1, 0.2, 0.3]),
+    ])
+    text = to_qasm(c)
+    out = {'text': np.frombuffer(text.encode(), dtype=np.uint8), 'n_gates': len(c)}
+    for i, g in enumerate(c):
+        out[f'U{i}'] = np.asarray(g.matrix(), dtype=np.complex128)
+        out[f'q{i}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, 'e2e_qasm_ext.npz'), **out)
+    print(text)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'qasm':
+        qasm_vectors()
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'matrix':
         matrix_vectors()
         raise SystemExit(0)

@@ -109,3 +109,54 @@ def test_dot_and_transpose_numpy_routes():
         transpose(a, [0, 1, 2, 3, 4, 5, 6, 8, 7])  # two unordered trailing axes: outside the core's domain
     with pytest.raises(ValueError):
         transpose(a, [0, 0, 1, 2, 3, 4, 5, 6, 7])
+
+
+def test_allow_sampling_replaces_stochastic_gates(monkeypatch):
+    """simulate(allow_sampling=True, sampling_seed=s): gates with .sample() are drawn once with numpy's global
+    generator seeded by s (simulation.py:241-256) and the generator's state is restored; without the flag they stay."""
+    import hybridq_amd.simulation as sim
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    z = np.diag([1, -1]).astype(complex)
+
+    class Flip:
+        qubits = (0,)
+
+        def sample(self):
+            return (x if np.random.random() < 0.5 else z, (0,))
+
+    seen = {}
+
+    def fake_plan(circuit, qubits, n, ctype, compress, blocked):
+        seen['circuit'] = list(circuit)
+        raise RuntimeError('stop before the device')
+
+    monkeypatch.setattr(sim, '_plan_ops', fake_plan)
+    np.random.seed(123)
+    before = np.random.get_state()[1].copy()
+    picks = []
+    for seed in (5, 5, 6, 7, 8, 9):
+        with pytest.raises(RuntimeError, match='stop before'):
+            sim.simulate([Flip(), (z, (1,))], initial_state='00', allow_sampling=True, sampling_seed=seed, simplify=False)
+        U = seen['circuit'][0][0]
+        picks.append(bool(np.array_equal(U, x)))
+        assert np.array_equal(np.random.get_state()[1], before)  # the caller's stream is untouched
+    assert picks[0] == picks[1] and len(set(picks)) == 2  # same seed, same draw; both outcomes occur
+
+
+def test_qasm_extension_blocks_from_reference_writer():
+    """The ``#@`` blocks of the reference's to_qasm (qubits map, power, conj, T, U for MATRIX, tags): the text in
+    e2e_qasm_ext.npz was written by the reference; every parsed gate must equal the reference's matrix."""
+    import golden_util as gu
+    from hybridq_amd.qasm import from_qasm
+    z = gu.load('e2e_qasm_ext.npz')
+    gates = from_qasm(bytes(z['text']).decode())
+    assert len(gates) == int(z['n_gates'])
+    for i, (U, qs) in enumerate(gates):
+        assert tuple(qs) == tuple(int(q) for q in z[f'q{i}']), i
+        assert np.abs(U - z[f'U{i}']).max() < 1e-12, i
+    with pytest.raises(ValueError):
+        from_qasm('h .')  # a gate without qubits
+    with pytest.raises(ValueError):
+        from_qasm('matrix 0')  # MATRIX without its U block
+    with pytest.raises(ValueError):
+        from_qasm('#@ qubits =\n#@ {\nh 0')  # unterminated JSON
