@@ -1373,9 +1373,10 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   const size_t per_cu = std::min<size_t>(std::max<size_t>(1, (160 * 1024) / tile_bytes), 4);
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[] = {(const void*)apply_blocked_kernel<float, 256, false>, (const void*)apply_blocked_kernel<float, 512, false>,
-                         (const void*)apply_blocked_kernel<double, 256, false>, (const void*)apply_blocked_kernel<double, 512, false>,
-                         (const void*)apply_blocked_kernel<float, 512, true>, (const void*)apply_blocked_kernel<double, 512, true>};
+    const void* fns[] = {(const void*)apply_blocked_kernel<float, 256, false, false>, (const void*)apply_blocked_kernel<float, 512, false, false>,
+                         (const void*)apply_blocked_kernel<double, 256, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false>,
+                         (const void*)apply_blocked_kernel<float, 512, true, false>, (const void*)apply_blocked_kernel<double, 512, true, false>,
+                         (const void*)apply_blocked_kernel<float, 512, true, true>, (const void*)apply_blocked_kernel<float, 512, false, true>};
     for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -1387,22 +1388,34 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
   // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
   const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) <= a_budget;
+  // register prefetch of the next tile (f32, 512 threads, 4 vectors per thread and plane = 13 tile bits)
+  static int use_pref = getenv("HQ_BLOCKED_PREF") ? atoi(getenv("HQ_BLOCKED_PREF")) : 1;
+  const bool pref = use_pref && sizeof(T) == 4 && block_threads != 256 && tb == 13;
   if (fits) {
     void *dG = nullptr, *dA = nullptr;
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
     if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
     const size_t lds = tile_bytes + Atab.size() * sizeof(T);
-    HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
-              n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+    if (pref) {
+      if constexpr (sizeof(T) == 4)
+        HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
+                  n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+    } else {
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
+                n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+    }
   } else {
     void *dG = nullptr, *dA = nullptr;
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
     if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
     const size_t lds = tile_bytes;
     if (block_threads == 256)
-      HQ_LAUNCH(c, (apply_blocked_kernel<T, 256, false>), dim3(grid), dim3(256), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
-    else
-      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 256, false, false>), dim3(grid), dim3(256), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+    else if (pref) {
+      if constexpr (sizeof(T) == 4)
+        HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, false, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+    } else
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, false, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
   }
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "blocked";

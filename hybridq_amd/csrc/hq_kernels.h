@@ -517,7 +517,8 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
   constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS;
   constexpr int FMASK = ~VMASK & (NCOMP - 1);
-  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned q = lane >> 4, j = lane & 15;
   const MfmaRoles& ro = G.ro;
   T a[NRB][NSTEP];
@@ -525,34 +526,50 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
   for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
+  // Slot addressing.  The SIMD issues about one instruction per 4 cycles, i.e. 8 per 32-cycle MFMA, and this loop
+  // runs only 2 iterations per gate and wave: the address arithmetic IS the budget (PMC before: 4.2 VALU + 1.4 SALU
+  // per MFMA, matrix pipe 58 % busy).  Everything is XOR-linear -- the zero-bit deposit moves every index bit on its
+  // own, the bank swizzle XORs bits 4..7 into bits 0..3, the digits occupy disjoint bits -- so
+  //   address(iteration t, register digit ld) = L ^ S(t) ^ OFF[ld]
+  // with L per lane and gate (deposit of wave/slot bits, q digits, plane), S(t) and OFF[ld] wave-uniform:
+  // one v_xor per vector and iteration instead of a deposit and a swizzle each.  Byte units throughout.
+  auto deposit = [&](unsigned v) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const unsigned lo = (1u << ro.pos[m]) - 1;  // unused digits carry 31: no-op
+      v = ((v & ~lo) << 1) | (v & lo);
+    }
+    return v;
+  };
+  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);  // log2(waves per workgroup)
+  static_assert(BLOCK == 64u << WB, "workgroup size");
   const unsigned lane_off = ((q & 1) ? ro.q_off[0] : 0u) | ((q & 2) ? ro.q_off[1] : 0u);
   const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
-  unsigned off[NL], pl[NL];
+  const unsigned L = (blocked_swz(deposit((wave << 4) | j) | lane_off) | (lane_plane << tile_vec_bits)) << 4;
+  unsigned OFF[NL];
 #pragma unroll
   for (int ld = 0; ld < NL; ++ld) {
     unsigned o = 0;
 #pragma unroll
     for (int b = 0; b < NR; ++b)
       if ((ld >> b) & 1) o |= ro.r_off[b];
-    off[ld] = o;
-    pl[ld] = ro.r_plane >= 0 ? ((ld >> ro.r_plane) & 1u) : 0u;
+    const unsigned pl = ro.r_plane >= 0 ? ((ld >> ro.r_plane) & 1u) : 0u;
+    OFF[ld] = (blocked_swz(o) | (pl << tile_vec_bits)) << 4;
   }
+  unsigned char* const tile = reinterpret_cast<unsigned char*>(xr);  // xi = xr + one plane: the plane is bit tile_vec_bits
   const unsigned niter = (1u << (tile_vec_bits - G.n_addr)) >> 4;  // 16 slots per wave iteration
-  for (unsigned it = wave; it < niter; it += BLOCK / 64) {
-    unsigned v = it * 16 + j;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const unsigned lo = (1u << ro.pos[m]) - 1;  // unused digits carry 31: no-op
-      v = ((v & ~lo) << 1) | (v & lo);
-    }
-    v |= lane_off;
-    V* ptr[NL];
+  for (unsigned t = 0; (t << WB) + wave < niter; ++t) {
+    const unsigned Lt = L ^ (blocked_swz(deposit(t << (4 + WB))) << 4);
+    unsigned addr[NL];
     V x[NL];
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
-      ptr[ld] = reinterpret_cast<V*>((lane_plane | pl[ld]) ? xi : xr) + blocked_swz(v | off[ld]);
-      x[ld] = *ptr[ld];
+      addr[ld] = Lt ^ OFF[ld];
+      x[ld] = *reinterpret_cast<V*>(tile + addr[ld]);
     }
+#ifdef HQ_EXP_READS_FIRST
+    __builtin_amdgcn_sched_barrier(0);  // all reads of the iteration in flight before the first MFMA
+#endif
     Acc acc[NCB][NRB];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf)
@@ -585,7 +602,7 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
 #ifdef HQ_EXP_NO_WRITE  // experiment: keep the result alive without the LDS store
       asm volatile("" ::"v"(y));
 #else
-      *ptr[ld] = y;
+      *reinterpret_cast<V*>(tile + addr[ld]) = y;
 #endif
     }
   }
@@ -670,7 +687,13 @@ __device__ __forceinline__ void blocked_inner_gate_valu(T* __restrict__ xr, T* _
 // ALDS: the A-operand tables of all gates of the pass (a_elems elements) are staged once per
 // (persistent) workgroup in LDS behind the tile; a table read from global memory puts an L2 round
 // trip (~1500 clk, as long as the gate's MFMAs) in front of every gate of every tile.
-template <typename T, int BLOCK, bool ALDS>
+// PREF (tiles of exactly 4 * BLOCK vectors per plane): serial phases -- load a tile (one HBM round trip), run the
+// gates, store -- run in step on the whole chip, so HBM idles while the gates run and the matrix cores idle while
+// tiles move: a pass costs HBM time PLUS gate time.  With PREF the next tile's vectors are requested into registers
+// before the gates of the current tile start and dropped into LDS after its stores were issued.  Needs the
+// no-scratch register budget: a scratch reload is a vector-memory load and would queue (vmcnt is in order) behind
+// the prefetch it was supposed to overlap.
+template <typename T, int BLOCK, bool ALDS, bool PREF>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* __restrict__ gates,
                      const unsigned ngates, const T* __restrict__ Atab, const unsigned a_elems,
@@ -689,22 +712,66 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
   const unsigned tvb = ba.tb - CB, nvec = 1u << tvb;
   V* __restrict__ vre = reinterpret_cast<V*>(re);
   V* __restrict__ vim = reinterpret_cast<V*>(im);
-  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  constexpr unsigned NPV = 4;  // PREF: vectors per thread and plane
+  auto tile_base = [&](uint64_t tile) {
     uint64_t base = tile;  // in 16-byte vector units: tile positions minus the component bits
     for (unsigned m = CB; m < ba.tb; ++m) {
       const uint64_t lo = (1ull << (ba.apos[m] - CB)) - 1;
       base = ((base & ~lo) << 1) | (base & lo);
     }
-    for (unsigned e = tid; e < nvec; e += BLOCK) {
-      uint64_t g = base;
-      for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+    return base;
+  };
+  auto vec_off = [&](unsigned e) {  // OR-linear in e
+    uint64_t g = 0;
+    for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+    return g;
+  };
+  V pr[PREF ? NPV : 1], pi[PREF ? NPV : 1];
+  const uint64_t off_tid = vec_off(tid);
+  uint64_t off_blk[NPV];  // wave-uniform
+#pragma unroll
+  for (unsigned i = 0; i < NPV; ++i) off_blk[i] = vec_off(i * BLOCK);
+  // unconditional (callers clamp the tile): a conditional request merges "new" and "old" register values and the
+  // compiler then copies every vector right after its load, i.e. waits for HBM on the spot
+  auto prefetch = [&](uint64_t tile) {
+    const uint64_t b = tile_base(tile) | off_tid;
+#pragma unroll
+    for (unsigned i = 0; i < (PREF ? NPV : 1); ++i) {
+      pr[i] = __builtin_nontemporal_load(vre + (b | off_blk[i]));
+      pi[i] = __builtin_nontemporal_load(vim + (b | off_blk[i]));
+    }
+  };
+  const unsigned fs = blocked_swz(tid);  // the swizzle only touches bits 0..3: swz(tid + i * BLOCK) = fs + i * BLOCK
+  auto fill = [&]() {
+#pragma unroll
+    for (unsigned i = 0; i < (PREF ? NPV : 1); ++i) {
+      reinterpret_cast<V*>(xr)[fs + i * BLOCK] = pr[i];
+      reinterpret_cast<V*>(xi)[fs + i * BLOCK] = pi[i];
+    }
+  };
+  const uint64_t stride = gridDim.x;
+  if constexpr (PREF) {
+    if (blockIdx.x >= ntiles) return;
+    // the tile is filled at the END of the loop body, right after the stores of the previous tile were issued: on
+    // every path the wait for the prefetched vectors then sees "8 loads, then 8 stores" in the (in-order) vmcnt
+    // queue and does not drain the stores
+    prefetch(blockIdx.x);
+    fill();
+    prefetch(blockIdx.x + stride < ntiles ? blockIdx.x + stride : blockIdx.x);
+  }
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += stride) {
+    const uint64_t base = tile_base(tile);
+    if constexpr (!PREF) {
+      for (unsigned e = tid; e < nvec; e += BLOCK) {
+        const uint64_t g = base | vec_off(e);
 #ifdef HQ_BLOCKED_PLAIN_IO
-      reinterpret_cast<V*>(xr)[blocked_swz(e)] = vre[g];
-      reinterpret_cast<V*>(xi)[blocked_swz(e)] = vim[g];
+        reinterpret_cast<V*>(xr)[blocked_swz(e)] = vre[g];
+        reinterpret_cast<V*>(xi)[blocked_swz(e)] = vim[g];
 #else  // streamed once per pass: keep the tile out of the caches
-      reinterpret_cast<V*>(xr)[blocked_swz(e)] = __builtin_nontemporal_load(vre + g);
-      reinterpret_cast<V*>(xi)[blocked_swz(e)] = __builtin_nontemporal_load(vim + g);
+        reinterpret_cast<V*>(xr)[blocked_swz(e)] = __builtin_nontemporal_load(vre + g);
+        reinterpret_cast<V*>(xi)[blocked_swz(e)] = __builtin_nontemporal_load(vim + g);
 #endif
+      }
     }
     __syncthreads();
     for (unsigned gi = 0; gi < ngates; ++gi) {
@@ -736,18 +803,30 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
       }
       __syncthreads();
     }
-    for (unsigned e = tid; e < nvec; e += BLOCK) {
-      uint64_t g = base;
-      for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+    if constexpr (PREF) {
+#pragma unroll
+      for (unsigned i = 0; i < NPV; ++i) {
+        const uint64_t g = base | off_tid | off_blk[i];
+        __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[fs + i * BLOCK], vre + g);
+        __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[fs + i * BLOCK], vim + g);
+      }
+    } else {
+      for (unsigned e = tid; e < nvec; e += BLOCK) {
+        const uint64_t g = base | vec_off(e);
 #ifdef HQ_BLOCKED_PLAIN_IO
-      vre[g] = reinterpret_cast<V*>(xr)[blocked_swz(e)];
-      vim[g] = reinterpret_cast<V*>(xi)[blocked_swz(e)];
+        vre[g] = reinterpret_cast<V*>(xr)[blocked_swz(e)];
+        vim[g] = reinterpret_cast<V*>(xi)[blocked_swz(e)];
 #else
-      __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[blocked_swz(e)], vre + g);
-      __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[blocked_swz(e)], vim + g);
+        __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[blocked_swz(e)], vre + g);
+        __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[blocked_swz(e)], vim + g);
 #endif
+      }
     }
     __syncthreads();
+    if constexpr (PREF) {
+      fill();  // tile + stride (a repeat of a finished tile past the end: never used)
+      prefetch(tile + 2 * stride < ntiles ? tile + 2 * stride : tile);
+    }
   }
 }
 
