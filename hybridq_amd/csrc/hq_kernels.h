@@ -713,10 +713,13 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
   V* __restrict__ vre = reinterpret_cast<V*>(re);
   V* __restrict__ vim = reinterpret_cast<V*>(im);
   constexpr unsigned NPV = 4;  // PREF: vectors per thread and plane
+  // constant trip count: the positions are read from the kernel arguments once (a runtime loop re-fetches
+  // ba.apos[m] with a scalar load + wait per digit, twice per tile, in every wave)
   auto tile_base = [&](uint64_t tile) {
     uint64_t base = tile;  // in 16-byte vector units: tile positions minus the component bits
-    for (unsigned m = CB; m < ba.tb; ++m) {
-      const uint64_t lo = (1ull << (ba.apos[m] - CB)) - 1;
+#pragma unroll
+    for (unsigned m = CB; m < (PREF ? CB + 11u : (unsigned)kBlockedMaxTileBits); ++m) {  // PREF: exactly 4 * 512 vectors
+      const uint64_t lo = (PREF || m < ba.tb) ? (1ull << (ba.apos[m] - CB)) - 1 : ~0ull;  // ~0: no-op
       base = ((base & ~lo) << 1) | (base & lo);
     }
     return base;
@@ -733,12 +736,16 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
   for (unsigned i = 0; i < NPV; ++i) off_blk[i] = vec_off(i * BLOCK);
   // unconditional (callers clamp the tile): a conditional request merges "new" and "old" register values and the
   // compiler then copies every vector right after its load, i.e. waits for HBM on the spot
+  // (tile base | uniform offset) is pinned to scalar registers: left alone the compiler hoists off_tid | off_blk[i]
+  // out of the tile loop -- 8 more vector registers alive across the gates, i.e. spills inside the loop
   auto prefetch = [&](uint64_t tile) {
-    const uint64_t b = tile_base(tile) | off_tid;
+    const uint64_t b = tile_base(tile);
 #pragma unroll
     for (unsigned i = 0; i < (PREF ? NPV : 1); ++i) {
-      pr[i] = __builtin_nontemporal_load(vre + (b | off_blk[i]));
-      pi[i] = __builtin_nontemporal_load(vim + (b | off_blk[i]));
+      uint64_t sb = b | off_blk[i];
+      asm volatile("" : "+s"(sb));
+      pr[i] = __builtin_nontemporal_load(vre + (sb | off_tid));
+      pi[i] = __builtin_nontemporal_load(vim + (sb | off_tid));
     }
   };
   const unsigned fs = blocked_swz(tid);  // the swizzle only touches bits 0..3: swz(tid + i * BLOCK) = fs + i * BLOCK
@@ -750,13 +757,27 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     }
   };
   const uint64_t stride = gridDim.x;
+#ifdef HQ_EXP_STAGGER  // experiment: start half of the workgroups late (HQ_EXP_STAGGER_ODD: by parity, else second half of the grid)
+#ifdef HQ_EXP_STAGGER_ODD
+  if (blockIdx.x & 1) __builtin_amdgcn_s_sleep(HQ_EXP_STAGGER);
+#else
+  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(HQ_EXP_STAGGER);
+#endif
+#endif
   if constexpr (PREF) {
     if (blockIdx.x >= ntiles) return;
     // the tile is filled at the END of the loop body, right after the stores of the previous tile were issued: on
     // every path the wait for the prefetched vectors then sees "8 loads, then 8 stores" in the (in-order) vmcnt
     // queue and does not drain the stores
-    prefetch(blockIdx.x);
-    fill();
+    {
+      const uint64_t b = tile_base(blockIdx.x) | off_tid;  // first tile: straight into LDS, one vector pair at a time
+#pragma unroll 1
+      for (unsigned i = 0; i < NPV; ++i) {
+        const uint64_t g = b | vec_off(i * BLOCK);
+        reinterpret_cast<V*>(xr)[fs + i * BLOCK] = __builtin_nontemporal_load(vre + g);
+        reinterpret_cast<V*>(xi)[fs + i * BLOCK] = __builtin_nontemporal_load(vim + g);
+      }
+    }
     prefetch(blockIdx.x + stride < ntiles ? blockIdx.x + stride : blockIdx.x);
   }
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += stride) {
@@ -806,7 +827,9 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     if constexpr (PREF) {
 #pragma unroll
       for (unsigned i = 0; i < NPV; ++i) {
-        const uint64_t g = base | off_tid | off_blk[i];
+        uint64_t sb = base | off_blk[i];
+        asm volatile("" : "+s"(sb));
+        const uint64_t g = sb | off_tid;
         __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[fs + i * BLOCK], vre + g);
         __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[fs + i * BLOCK], vim + g);
       }
