@@ -13,7 +13,8 @@ back to HBM.  This module decides which bits and which gates:
     spend spare capacity on the ready gate that needs the fewest new positions, repeat;
     several visiting orders are tried per pass and the one absorbing most gates wins;
   * the gates of a pass are fused (``fusion.fuse``) up to ``inner_max`` qubits, because an
-    inner gate costs matrix-core time only (k <= 3: ~0.75 ms, k = 4: ~1.3 ms at n = 30);
+    inner gate costs matrix-core time only (k <= 3: ~0.76 ms, k = 4: ~1.2 ms at n = 30); the default
+    ``'auto'`` fuses to 3 qubits and widens to 4 where the second round saves more gates than it costs;
   * passes that would hold fewer than ``min_gates`` gates are emitted as plain gates.
 
 There is no reference counterpart (the reference applies one fused gate per pass,
@@ -26,7 +27,11 @@ import numpy as np
 from .fusion import fuse
 
 
-def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_gates=3, tries=16, seed=0,
+#: relative cost of an inner gate by width (measured, n = 30 complex64: 0.76 ms for k <= 3, 1.21 ms for k = 4)
+INNER_COST = {1: 1.0, 2: 1.0, 3: 1.0, 4: 1.6}
+
+
+def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', min_gates=3, tries=32, seed=0,
                  complex_type='complex64'):
     """Schedule `gates` ([(U, qubits), ...]) given the placement ``pos_of[qubit] = position``.
 
@@ -120,7 +125,14 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max=3, min_ga
             if p not in S:
                 S.add(p)
             p += 1
-        if inner_max:
+        if inner_max == 'auto':
+            # an inner gate costs about the same for k <= 3 and 1.6x that for k = 4 (INNER_COST): fuse to 3 qubits,
+            # then let a second round merge neighbours into 4-qubit gates and keep it where that is cheaper
+            inner = fuse([gates[gi] for gi in chosen], 3, complex_type=complex_type)
+            wider = fuse(inner, 4, complex_type=complex_type)
+            if sum(INNER_COST[len(qs)] for _, qs in wider) < sum(INNER_COST[len(qs)] for _, qs in inner):
+                inner = wider
+        elif inner_max:
             inner = fuse([gates[gi] for gi in chosen], inner_max, complex_type=complex_type)
         else:
             inner = [(np.asarray(gates[gi][0]), gq[gi]) for gi in chosen]

@@ -18,12 +18,15 @@ def test_choose_schedule_cost_model():
     gates = rqc_1q2q(n, depth=40, seed=n)
     ops, info = choose_schedule(gates, list(range(n)), n, np.dtype('complex64'))
     est = info['modelled_ms']
-    # measured on MI355X (profiles/r02_v2_bench.json): 2431 / 399-408 / 307 / 213-219 ms
+    # measured on MI355X (profiles/r02_v3_bench.json): 2431-2509 / 399-408 / 307-311 / 170 ms
     assert abs(est['per_gate'] - 2431) < 50 and abs(est['fused_4'] - 400) < 25 and abs(est['fused_5'] - 307) < 15
-    assert abs(est['blocked'] - 216) < 15 and info['chosen'] == 'blocked'
+    assert abs(est['blocked'] - 170) < 12 and info['chosen'] == 'blocked'
     assert est['per_gate'] == pytest.approx(900 * PASS_MS[1], rel=1e-6)
     # complex128 costs twice the bytes, one qubit less halves them
-    assert estimate_ms(ops, n, np.dtype('complex128')) == pytest.approx(2 * estimate_ms(ops, n, np.dtype('complex64')))
+    # complex128: twice the bytes; the blocked passes additionally lose the register prefetch (no overlap term)
+    assert estimate_ms(ops, n, np.dtype('complex128')) >= 2 * estimate_ms(ops, n, np.dtype('complex64'))
+    plain = [(g[1], g[0]) if isinstance(g[0], str) else g for g in ops if not (isinstance(g[0], str) and g[0] == 'B')]
+    assert estimate_ms(plain, n, np.dtype('complex128')) == pytest.approx(2 * estimate_ms(plain, n, np.dtype('complex64')))
     # tiny states: the launch floor decides, i.e. the fewest calls win; blocking needs n >= 14
     _, small = choose_schedule(rqc_1q2q(10, depth=8, seed=1), list(range(10)), 10, np.dtype('complex64'))
     assert 'blocked' not in small['modelled_ms'] and small['chosen'] in ('fused_4', 'fused_5')
