@@ -27,8 +27,19 @@ import numpy as np
 from .fusion import fuse
 
 
-#: relative cost of an inner gate by width (measured, n = 30 complex64: 0.76 ms for k <= 3, 1.21 ms for k = 4)
-INNER_COST = {1: 1.0, 2: 1.0, 3: 1.0, 4: 1.6}
+#: relative cost of an inner gate by width (measured, n = 30 complex64: 0.63 ms for k <= 3, 1.20 ms for k = 4)
+INNER_COST = {1: 1.0, 2: 1.0, 3: 1.0, 4: 1.9}
+
+
+#: LDS next to a 64 KiB tile with two workgroups per CU (hq_hip.hip: a_budget), and what a gate needs of it:
+#: its MFMA A-operand table (k = 2, 3: 256 elements, k = 4: 1024; k = 1 runs on the VALU from scalar registers)
+#: plus 136 32-bit words of slot-address tables
+LDS_TABLE_BUDGET = 15 * 1024
+
+
+def lds_bytes(gate_list, complex_type='complex64'):
+    elem = 4 if np.dtype(complex_type) == np.dtype('complex64') else 8
+    return sum({1: 0, 2: 256, 3: 256, 4: 1024}[len(qs)] * elem + 544 for _, qs in gate_list)
 
 
 def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', min_gates=3, tries=32, seed=0,
@@ -130,7 +141,11 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', m
             # then let a second round merge neighbours into 4-qubit gates and keep it where that is cheaper
             inner = fuse([gates[gi] for gi in chosen], 3, complex_type=complex_type)
             wider = fuse(inner, 4, complex_type=complex_type)
-            if sum(INNER_COST[len(qs)] for _, qs in wider) < sum(INNER_COST[len(qs)] for _, qs in inner):
+
+            def cost(gl):  # a pass whose operand + address tables overflow the LDS left beside the tile runs the
+                c = sum(INNER_COST[len(qs)] for _, qs in gl)  # slower global-memory variant of every gate
+                return c * (1.0 if lds_bytes(gl, complex_type) <= LDS_TABLE_BUDGET else 1.25)
+            if cost(wider) < cost(inner):
                 inner = wider
         elif inner_max:
             inner = fuse([gates[gi] for gi in chosen], inner_max, complex_type=complex_type)

@@ -1387,7 +1387,8 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   const size_t a_budget = (160 * 1024) / per_cu - tile_bytes > 2048 ? (160 * 1024) / per_cu - tile_bytes - 1024 : 0;
   // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
   // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
-  const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) <= a_budget;
+  const size_t tab_bytes = (((size_t)n_gates * kBlockedTabWords * sizeof(BlockedTabT)) + 15) & ~(size_t)15;  // per-gate address tables (built in-kernel)
+  const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
   // register prefetch of the next tile (f32, 512 threads, 4 vectors per thread and plane = 13 tile bits)
   static int use_pref = getenv("HQ_BLOCKED_PREF") ? atoi(getenv("HQ_BLOCKED_PREF")) : 1;
   const bool pref = use_pref && sizeof(T) == 4 && block_threads != 256 && tb == 13;
@@ -1395,7 +1396,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     void *dG = nullptr, *dA = nullptr;
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
     if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
-    const size_t lds = tile_bytes + Atab.size() * sizeof(T);
+    const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes;
     if (pref) {
       if constexpr (sizeof(T) == 4)
         HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
@@ -2343,3 +2344,9 @@ extern "C" int hq_pointer_info(const void* p, int* type, int* device, int* err) 
   if (device) *device = attr.device;
   return e == hipSuccess ? 0 : 1;
 }
+
+#ifdef HQ_EXP_TIMELINE
+extern "C" int hq_debug_timeline(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hq::hq_timeline), sizeof(unsigned long long) * 256);
+}
+#endif

@@ -507,10 +507,24 @@ struct BlockedGate {
   unsigned pad_;
 };
 
+#ifdef HQ_EXP_TIMELINE  // experiment: s_memtime stamps of one workgroup's waves through one inner gate
+__device__ unsigned long long hq_timeline[16 * 16];
+__device__ int hq_timeline_on;  // set by the kernel for the (workgroup, tile, gate) being recorded
+#define HQ_STAMP(i)                                                                                              \
+  do {                                                                                                           \
+    if (hq_tl_rec) hq_timeline[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter();                      \
+  } while (0)
+#else
+#define HQ_STAMP(i) do {} while (0)
+#endif
 template <typename T, int KBITS, int VMASK, int BLOCK>
 __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __restrict__ xi,
                                                    const BlockedGate& G, const T* __restrict__ A,
-                                                   const unsigned tile_vec_bits) {
+                                                   const unsigned tile_vec_bits
+#ifdef HQ_EXP_TIMELINE
+                                                   , const bool hq_tl_flag = false
+#endif
+) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
   constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;
@@ -519,6 +533,10 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
   constexpr int FMASK = ~VMASK & (NCOMP - 1);
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef HQ_EXP_TIMELINE
+  const bool hq_tl_rec = hq_tl_flag && lane == 0;
+#endif
+  HQ_STAMP(1);
   const unsigned q = lane >> 4, j = lane & 15;
   const MfmaRoles& ro = G.ro;
   T a[NRB][NSTEP];
@@ -558,6 +576,7 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
   }
   unsigned char* const tile = reinterpret_cast<unsigned char*>(xr);  // xi = xr + one plane: the plane is bit tile_vec_bits
   const unsigned niter = (1u << (tile_vec_bits - G.n_addr)) >> 4;  // 16 slots per wave iteration
+  HQ_STAMP(2);
   for (unsigned t = 0; (t << WB) + wave < niter; ++t) {
     const unsigned Lt = L ^ (blocked_swz(deposit(t << (4 + WB))) << 4);
     unsigned addr[NL];
@@ -569,6 +588,13 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
     }
 #ifdef HQ_EXP_READS_FIRST
     __builtin_amdgcn_sched_barrier(0);  // all reads of the iteration in flight before the first MFMA
+#endif
+#ifdef HQ_EXP_TIMELINE
+    __builtin_amdgcn_sched_barrier(0);
+    HQ_STAMP(3 + 4 * t);  // reads issued
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    HQ_STAMP(4 + 4 * t);  // reads returned
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     Acc acc[NCB][NRB];
 #pragma unroll
@@ -602,10 +628,189 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
 #ifdef HQ_EXP_NO_WRITE  // experiment: keep the result alive without the LDS store
       asm volatile("" ::"v"(y));
 #else
+#ifdef HQ_EXP_TIMELINE
+      if (ld == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        HQ_STAMP(5 + 4 * t);  // MFMAs done (first result consumed)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       *reinterpret_cast<V*>(tile + addr[ld]) = y;
 #endif
     }
+#ifdef HQ_EXP_TIMELINE
+    __builtin_amdgcn_sched_barrier(0);
+    HQ_STAMP(6 + 4 * t);  // writes issued
+#endif
   }
+}
+
+// Table-driven form of blocked_inner_gate (the default: tables of a pass in LDS next to its A operands).
+// s_memtime stamps through one gate (tools/blocked_timeline.py) showed where the 42 % idle matrix pipe comes from:
+// a SIMD issues roughly one instruction per 4 cycles for ALL its waves, and with only two 16-MFMA bursts per gate
+// and wave the ~190 scalar + vector instructions of descriptor decoding and address arithmetic around them
+// (x 4 waves) cost as much issue time as the MFMAs cost pipe time -- segments of 15-30 instructions took 900-1300
+// cycles.  So every per-gate quantity that does not depend on the data is read from a table the workgroup builds
+// ONCE per kernel: address(lane, iteration it, register digit ld) = LANE[lane] ^ ITER[it] ^ OFF[ld] (see the XOR
+// argument in blocked_inner_gate), one ds_read_b32 + one v_xor3 per vector, and the result rows go back with
+// ds_write2_b32 pairs straight from the accumulators instead of 15 v_mov + 4 ds_write_b128.
+// Two elements from two unrelated registers to consecutive element slots `first`, `first + 1` after LDS byte address `a`.
+__device__ __forceinline__ void lds_write2(unsigned a, float v0, float v1, int first) {
+  if (first == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(a), "v"(v0), "v"(v1) : "memory");
+  else asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" ::"v"(a), "v"(v0), "v"(v1) : "memory");
+}
+__device__ __forceinline__ void lds_write2(unsigned a, double v0, double v1, int) {
+  asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" ::"v"(a), "v"(v0), "v"(v1) : "memory");
+}
+typedef unsigned BlockedTabT;  // 16-bit entries were tried: more passes fit their tables, each gate 7 % slower
+constexpr unsigned kBlockedTabLane = 0, kBlockedTabIter = 64, kBlockedTabOff = 128, kBlockedTabWords = 136;
+
+template <typename T, int BLOCK>
+__device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ tabs, const BlockedGate* __restrict__ gates,
+                                                     const unsigned ngates, const unsigned tile_vec_bits,
+                                                     const unsigned lds_base) {
+  // the tile's LDS address is folded into the lane entries: XOR = ADD needs it aligned to the two planes (it is 0:
+  // the tile opens the dynamic LDS segment and the kernel has no static one)
+  if (lds_base & ((2u << (tile_vec_bits + 4)) - 1)) __builtin_trap();
+  const unsigned tid = threadIdx.x;
+  for (unsigned g = 0; g < ngates; ++g) {
+    const MfmaRoles& ro = gates[g].ro;
+    auto deposit = [&](unsigned v) {
+      for (int m = 0; m < 4; ++m) {
+        const unsigned lo = (1u << ro.pos[m]) - 1;
+        v = ((v & ~lo) << 1) | (v & lo);
+      }
+      return v;
+    };
+    BlockedTabT* tb = tabs + g * kBlockedTabWords;
+    for (unsigned e = tid; e < kBlockedTabWords; e += BLOCK) {
+      unsigned val;
+      if (e < kBlockedTabIter) {  // lane part: slot bits j, q digits, plane
+        const unsigned q = e >> 4, j = e & 15;
+        const unsigned lane_off = ((q & 1) ? ro.q_off[0] : 0u) | ((q & 2) ? ro.q_off[1] : 0u);
+        const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
+        val = ((blocked_swz(deposit(j) | lane_off) | (lane_plane << tile_vec_bits)) << 4) | lds_base;
+      } else if (e < kBlockedTabOff) {  // wave-iteration part
+        val = blocked_swz(deposit((e - kBlockedTabIter) << 4)) << 4;
+      } else {  // register-digit part
+        const unsigned ld = e - kBlockedTabOff;
+        unsigned o = 0;
+        for (int b = 0; b < 3; ++b)
+          if ((ld >> b) & 1) o |= ro.r_off[b];
+        const unsigned pl = ro.r_plane >= 0 ? ((ld >> ro.r_plane) & 1u) : 0u;
+        val = (blocked_swz(o) | (pl << tile_vec_bits)) << 4;
+      }
+      tb[e] = (BlockedTabT)val;
+    }
+  }
+}
+
+template <typename T, int KBITS, int VMASK, int BLOCK>
+__device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
+                                                       const BlockedTabT* __restrict__ tab, const unsigned niter
+#ifdef HQ_EXP_TIMELINE
+                                                       , const bool hq_tl_flag = false
+#endif
+) {
+  using V = typename Vec<T>::type;
+  using Acc = typename Mfma<T>::acc;
+  constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;
+  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
+  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS;
+  constexpr int FMASK = ~VMASK & (NCOMP - 1);
+  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef HQ_EXP_TIMELINE
+  const bool hq_tl_rec = hq_tl_flag && lane == 0;
+  int hq_t = 0;
+#endif
+  HQ_STAMP(1);
+  T a[NRB][NSTEP];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
+  const unsigned L = tab[kBlockedTabLane + lane];
+  unsigned OFF[NL];
+#pragma unroll
+  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
+  typedef __attribute__((address_space(3))) V LdsV;  // addresses are absolute LDS byte addresses (base folded in LANE)
+  HQ_STAMP(2);
+  for (unsigned it = wave; it < niter; it += 1u << WB) {
+    const unsigned Lt = L ^ tab[kBlockedTabIter + it];
+    unsigned addr[NL];
+    V x[NL];
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      addr[ld] = Lt ^ OFF[ld];
+      x[ld] = *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]);
+    }
+#ifdef HQ_EXP_TIMELINE
+    __builtin_amdgcn_sched_barrier(0);
+    HQ_STAMP(3 + 4 * hq_t);  // reads issued
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    HQ_STAMP(4 + 4 * hq_t);  // reads returned
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    Acc acc[NCB][NRB];
+#pragma unroll
+    for (int cf = 0; cf < NCB; ++cf)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Acc{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const int ck = s & ((1 << KV) - 1), ld = s >> KV;
+#pragma unroll
+      for (int cf = 0; cf < NCB; ++cf) {
+        const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Mfma<T>::run(a[rb][s], x[ld][comp], acc[cf][rb]);
+      }
+    }
+    // component c of vector ld sits in accumulator block (cf, so >> 2), register so & 3.  A 16-byte store wants 4
+    // consecutive registers, i.e. a transpose by 15 v_mov per iteration (and the compiler re-vectorises element
+    // stores into exactly that); ds_write2 takes its two elements from any two registers.  Inline assembly: the
+    // compiler neither counts these stores (lgkmcnt is drained by hand after the loop) nor pads the
+    // MFMA-result -> LDS-read hazard in front of them (s_nop by hand: 8-pass MFMA, 16 wait states cover it).
+#ifdef HQ_BLOCKED_WRITE2
+    // (each accumulator block passes through an empty volatile asm first: volatile asms keep their order, so every
+    // MFMA is issued before the s_nop and every store after it)
+#pragma unroll
+    for (int cf = 0; cf < NCB; ++cf)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) asm volatile("" : "+v"(acc[cf][rb]));
+    asm volatile("s_nop 15" ::: "memory");
+    HQ_STAMP(5 + 4 * hq_t);  // MFMAs issued
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      const unsigned la = addr[ld];
+#pragma unroll
+      for (int c2 = 0; c2 < NCOMP; c2 += 2) {
+        const int so0 = pext_c(c2, VMASK) | (ld << KV), so1 = pext_c(c2 + 1, VMASK) | (ld << KV);
+        lds_write2(la, acc[pext_c(c2, FMASK)][so0 >> 2][so0 & 3], acc[pext_c(c2 + 1, FMASK)][so1 >> 2][so1 & 3], c2);
+      }
+    }
+#else
+    HQ_STAMP(5 + 4 * hq_t);
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      V y;
+#pragma unroll
+      for (int comp = 0; comp < NCOMP; ++comp) {
+        const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
+        const int so = ck | (ld << KV);
+        y[comp] = acc[cf][so >> 2][so & 3];
+      }
+      *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]) = y;
+    }
+#endif
+#ifdef HQ_EXP_TIMELINE
+    HQ_STAMP(6 + 4 * hq_t);  // writes issued
+    ++hq_t;
+#endif
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // Pin a wave-uniform value to SGPRs (the optimiser does not always prove uniformity of loads).
@@ -705,11 +910,13 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
   T* xi = xr + (1u << ba.tb);
   T* als = xi + (1u << ba.tb);
   const unsigned tid = threadIdx.x;
+  const unsigned tvb = ba.tb - CB, nvec = 1u << tvb;
+  BlockedTabT* const tabs = reinterpret_cast<BlockedTabT*>(als + a_elems);  // ALDS: address tables of all gates (built here)
   if (ALDS) {
     for (unsigned i = tid; i < a_elems; i += BLOCK) als[i] = Atab[i];
+    blocked_build_tables<T, BLOCK>(tabs, gates, ngates, tvb, (unsigned)reinterpret_cast<uintptr_t>(xr));
     __syncthreads();
   }
-  const unsigned tvb = ba.tb - CB, nvec = 1u << tvb;
   V* __restrict__ vre = reinterpret_cast<V*>(re);
   V* __restrict__ vim = reinterpret_cast<V*>(im);
   constexpr unsigned NPV = 4;  // PREF: vectors per thread and plane
@@ -798,11 +1005,30 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedGate& G = gates[gi];
       const T* A = ALDS ? als + G.a_off : Atab + G.a_off;
+#ifdef HQ_EXP_TIMELINE
+      const bool hq_tl_flag = blockIdx.x == 7 && tile == blockIdx.x + 3 * stride && gi == 3;
+      const bool hq_tl_rec = hq_tl_flag && (threadIdx.x & 63) == 0;
+      HQ_STAMP(0);
+      if (!ALDS && G.kv == 16) blocked_inner_gate<T, 4, 0, BLOCK>(xr, xi, G, A, tvb, hq_tl_flag);
+      else
+#endif
+#ifdef HQ_EXP_TIMELINE
+#define HQ_TL_ARG , hq_tl_flag
+#else
+#define HQ_TL_ARG
+#endif
+#define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
+  do {                                                                                                  \
+    if constexpr (ALDS)                                                                                 \
+      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * kBlockedTabWords, (1u << (tvb - G.n_addr)) >> 4 HQ_TL_ARG); \
+    else                                                                                                \
+      blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
+  } while (0)
       switch (G.kv) {
-        case 16: blocked_inner_gate<T, 4, 0, BLOCK>(xr, xi, G, A, tvb); break;
-        case 17: blocked_inner_gate<T, 4, 1, BLOCK>(xr, xi, G, A, tvb); break;
-        case 20: blocked_inner_gate<T, 5, 0, BLOCK>(xr, xi, G, A, tvb); break;
-        case 21: blocked_inner_gate<T, 5, 1, BLOCK>(xr, xi, G, A, tvb); break;
+        case 16: HQ_BLOCKED_MFMA_GATE(4, 0); break;
+        case 17: HQ_BLOCKED_MFMA_GATE(4, 1); break;
+        case 20: HQ_BLOCKED_MFMA_GATE(5, 0); break;
+        case 21: HQ_BLOCKED_MFMA_GATE(5, 1); break;
         case 64 + 4 + 0: blocked_inner_gate_valu<T, 1, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
         case 64 + 4 + 1: blocked_inner_gate_valu<T, 1, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
         case 64 + 8 + 0: blocked_inner_gate_valu<T, 2, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
@@ -810,10 +1036,10 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
         default:
           if constexpr (CB == 2) {
             switch (G.kv) {
-              case 18: blocked_inner_gate<T, 4, 2, BLOCK>(xr, xi, G, A, tvb); break;
-              case 19: blocked_inner_gate<T, 4, 3, BLOCK>(xr, xi, G, A, tvb); break;
-              case 22: blocked_inner_gate<T, 5, 2, BLOCK>(xr, xi, G, A, tvb); break;
-              case 23: blocked_inner_gate<T, 5, 3, BLOCK>(xr, xi, G, A, tvb); break;
+              case 18: HQ_BLOCKED_MFMA_GATE(4, 2); break;
+              case 19: HQ_BLOCKED_MFMA_GATE(4, 3); break;
+              case 22: HQ_BLOCKED_MFMA_GATE(5, 2); break;
+              case 23: HQ_BLOCKED_MFMA_GATE(5, 3); break;
               case 64 + 4 + 2: blocked_inner_gate_valu<T, 1, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
               case 64 + 8 + 2: blocked_inner_gate_valu<T, 2, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
               case 64 + 8 + 3: blocked_inner_gate_valu<T, 2, 3, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
@@ -822,7 +1048,13 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
           }
           break;
       }
+#ifdef HQ_EXP_TIMELINE
+      HQ_STAMP(11);
+#endif
       __syncthreads();
+#ifdef HQ_EXP_TIMELINE
+      HQ_STAMP(12);
+#endif
     }
     if constexpr (PREF) {
 #pragma unroll

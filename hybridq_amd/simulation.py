@@ -215,13 +215,16 @@ def alloc_planes(n, torch_dtype, device, vmm=True):
     return raw[:, :1 << n]
 
 
-def prepare_state_planes(initial_state, n, float_type, device):
+def prepare_state_planes(initial_state, n, float_type, device, placement='tuned'):
     """Planes for an initial state given as a '01+-' string (hybridq/circuit/simulation/
     utils.py:41-156) or as an array of 2^n amplitudes.  Strings are written by device kernels
-    (basis, uniform, and the mixed '01+-' product state); arrays are uploaded."""
+    (basis, uniform, and the mixed '01+-' product state); arrays are uploaded.
+    ``placement``: 'tuned' (VMM granules, best for the streaming per-gate kernels) or 'plain' (torch's
+    allocator: the cache-blocked passes gather 128-byte runs from all over the state and run 7 % FASTER
+    from it -- 156 vs 167 ms for the n = 30 benchmark circuit on the same box)."""
     torch = _torch()
     tdt = {np.dtype('float32'): torch.float32, np.dtype('float64'): torch.float64}[float_type]
-    planes = alloc_planes(n, tdt, device)
+    planes = alloc_planes(n, tdt, device, vmm=placement == 'tuned')
     if isinstance(initial_state, str):
         s = initial_state
         if len(s) == 1:
@@ -255,7 +258,7 @@ def prepare_state_planes(initial_state, n, float_type, device):
 class EvolutionState:
     """Split-plane state vector resident in HBM plus the logical->physical qubit map."""
 
-    def __init__(self, qubits, complex_type='complex64', initial_state='0', device=None):
+    def __init__(self, qubits, complex_type='complex64', initial_state='0', device=None, placement='tuned'):
         torch = _torch()
         self.complex_type = np.dtype(complex_type)
         if self.complex_type not in _FLOAT_OF:
@@ -269,7 +272,7 @@ class EvolutionState:
         self.map = {q: self.n - x - 1 for x, q in enumerate(self.qubits)}  # simulation.py:512
         with torch.cuda.device(self.device):
             core.use_torch_stream()
-            self.planes = prepare_state_planes(initial_state, self.n, self.float_type, self.device)
+            self.planes = prepare_state_planes(initial_state, self.n, self.float_type, self.device, placement)
 
     @property
     def re(self):
@@ -421,10 +424,10 @@ def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
 #: round trip plus matrix-core time per inner gate.  Times scale with 2^n and with the element size.
 PASS_MS = {1: 2.70, 2: 2.70, 3: 2.70, 4: 2.76, 5: 3.08, 6: 4.70, 7: 10.4, 8: 18.7, 9: 36.1, 10: 73.7}
 BLOCKED_BASE_MS = 3.0  # a blocked pass whose gates hide behind the HBM stream (tools/blocked_scaling.py: G <= 2)
-BLOCKED_OVERLAP_MS = 1.6  # ... what of the stream does NOT hide behind the gates once they dominate (complex64: the
-#                            next tile is prefetched into registers; 0.95 ms for a tile on the 8 lowest bits, 1.6 ms
+BLOCKED_OVERLAP_MS = 1.3  # ... what of the stream does NOT hide behind the gates once they dominate (complex64: the
+#                            next tile is prefetched into registers; 0.95 ms for a tile on the 8 lowest bits, 1.3 ms
 #                            fitted on the benchmark circuit's tiles; complex128 has no prefetch: the whole base stays)
-BLOCKED_INNER_MS = {1: 0.38, 2: 0.76, 3: 0.76, 4: 1.21}
+BLOCKED_INNER_MS = {1: 0.38, 2: 0.63, 3: 0.63, 4: 1.20}
 LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)
 
 
@@ -567,8 +570,9 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     torch = _torch()
     if _wants_shards(kwargs):
         return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs)
+    n_blocked = sum(1 for g in gates if not _is_functional(g) and isinstance(g[0], str) and g[0] == 'B')
     state = EvolutionState(qubits, complex_type=complex_type, initial_state=initial_state,
-                           device=kwargs['device'])
+                           device=kwargs['device'], placement='plain' if 2 * n_blocked > len(gates) else 'tuned')
     info = {}
     core.sync()
     t0 = time.perf_counter()  # simulation.py:519

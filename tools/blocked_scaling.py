@@ -17,7 +17,9 @@ planes = alloc_planes(n, torch.float32, 'cuda')
 core.init_state(planes[0], planes[1], 'plus')
 tile = list(range(8)) + [12, 15, 19, 22, 27]
 out = []
-for targets in ([5, 12, 19, 27][:k] if k <= 4 else None, [2, 3, 5, 12][:k], [15, 19, 22, 27][:k]):
+sets = [[int(x) for x in a.split(',')] for a in sys.argv[3:]] or [[5, 12, 19, 27][:k], [2, 3, 5, 12][:k], [15, 19, 22, 27][:k]]
+for targets in sets:
+    k = len(targets)
     row = []
     for G in (0, 1, 2, 4, 6, 8, 12, 16):
         gates = []

@@ -14,7 +14,7 @@ rng = np.random.default_rng(0)
 planes = alloc_planes(n, torch.float32, 'cuda', vmm=False) if 'vmm' in alloc_planes.__code__.co_varnames else alloc_planes(n, torch.float32, 'cuda')
 core.init_state(planes[0], planes[1], 'plus')
 tile = list(range(8)) + [12, 15, 19, 22, 27]
-for G in (4, 12):
+for G in (4, 8):
     gates = []
     for _ in range(G):
         q, _r = np.linalg.qr(rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8)))
