@@ -2347,6 +2347,6 @@ extern "C" int hq_pointer_info(const void* p, int* type, int* device, int* err) 
 
 #ifdef HQ_EXP_TIMELINE
 extern "C" int hq_debug_timeline(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hq::hq_timeline), sizeof(unsigned long long) * 256);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hq::hq_timeline), sizeof(unsigned long long) * 512);
 }
 #endif

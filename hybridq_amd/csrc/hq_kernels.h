@@ -508,14 +508,19 @@ struct BlockedGate {
 };
 
 #ifdef HQ_EXP_TIMELINE  // experiment: s_memtime stamps of one workgroup's waves through one inner gate
-__device__ unsigned long long hq_timeline[16 * 16];
+__device__ unsigned long long hq_timeline[2 * 16 * 16];
 __device__ int hq_timeline_on;  // set by the kernel for the (workgroup, tile, gate) being recorded
 #define HQ_STAMP(i)                                                                                              \
   do {                                                                                                           \
     if (hq_tl_rec) hq_timeline[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter();                      \
   } while (0)
+#define HQ_TSTAMP(i)                                                                                             \
+  do {                                                                                                           \
+    if (hq_tile_rec) hq_timeline[128 + (threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter();             \
+  } while (0)
 #else
 #define HQ_STAMP(i) do {} while (0)
+#define HQ_TSTAMP(i) do {} while (0)
 #endif
 template <typename T, int KBITS, int VMASK, int BLOCK>
 __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __restrict__ xi,
@@ -945,8 +950,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
   // compiler then copies every vector right after its load, i.e. waits for HBM on the spot
   // (tile base | uniform offset) is pinned to scalar registers: left alone the compiler hoists off_tid | off_blk[i]
   // out of the tile loop -- 8 more vector registers alive across the gates, i.e. spills inside the loop
-  auto prefetch = [&](uint64_t tile) {
-    const uint64_t b = tile_base(tile);
+  auto prefetch = [&](const uint64_t b) {  // b = tile_base(tile)
 #pragma unroll
     for (unsigned i = 0; i < (PREF ? NPV : 1); ++i) {
       uint64_t sb = b | off_blk[i];
@@ -964,6 +968,12 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     }
   };
   const uint64_t stride = gridDim.x;
+  // PREF walks its tiles by `stride` (a power of two: min(ntiles, 512)): in deposited coordinates that is
+  // next = ((cur | ~M) + D) & M with M = the index bits outside the tile and D = deposit(stride) -- the carry runs
+  // through the filled tile bits -- three 64-bit scalar operations instead of an 11-digit deposit twice per tile
+  // (70 scalar instructions with spilled masks each)
+  const uint64_t dep_mask = tile_base(~0ull), dep_stride = tile_base(stride);
+  auto next_base = [&](uint64_t b) { return ((b | ~dep_mask) + dep_stride) & dep_mask; };
 #ifdef HQ_EXP_STAGGER  // experiment: start half of the workgroups late (HQ_EXP_STAGGER_ODD: by parity, else second half of the grid)
 #ifdef HQ_EXP_STAGGER_ODD
   if (blockIdx.x & 1) __builtin_amdgcn_s_sleep(HQ_EXP_STAGGER);
@@ -985,10 +995,16 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
         reinterpret_cast<V*>(xi)[fs + i * BLOCK] = __builtin_nontemporal_load(vim + g);
       }
     }
-    prefetch(blockIdx.x + stride < ntiles ? blockIdx.x + stride : blockIdx.x);
+    prefetch(blockIdx.x + stride < ntiles ? tile_base(blockIdx.x + stride) : tile_base(blockIdx.x));
   }
+  uint64_t base_cur = tile_base(blockIdx.x);
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += stride) {
-    const uint64_t base = tile_base(tile);
+#ifdef HQ_EXP_TIMELINE
+    const bool hq_tile_rec = blockIdx.x == 7 && tile == blockIdx.x + 3 * stride && (threadIdx.x & 63) == 0;
+#endif
+    HQ_TSTAMP(0);
+    const uint64_t base = PREF ? base_cur : tile_base(tile);
+    HQ_TSTAMP(1);
     if constexpr (!PREF) {
       for (unsigned e = tid; e < nvec; e += BLOCK) {
         const uint64_t g = base | vec_off(e);
@@ -1002,6 +1018,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
       }
     }
     __syncthreads();
+    HQ_TSTAMP(2);
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedGate& G = gates[gi];
       const T* A = ALDS ? als + G.a_off : Atab + G.a_off;
@@ -1056,14 +1073,22 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
       HQ_STAMP(12);
 #endif
     }
+    HQ_TSTAMP(3);
     if constexpr (PREF) {
+      V sr[NPV], si[NPV];  // all LDS reads in flight before the first store (the gates' registers are free here)
+#pragma unroll
+      for (unsigned i = 0; i < NPV; ++i) {
+        sr[i] = reinterpret_cast<V*>(xr)[fs + i * BLOCK];
+        si[i] = reinterpret_cast<V*>(xi)[fs + i * BLOCK];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (unsigned i = 0; i < NPV; ++i) {
         uint64_t sb = base | off_blk[i];
         asm volatile("" : "+s"(sb));
         const uint64_t g = sb | off_tid;
-        __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[fs + i * BLOCK], vre + g);
-        __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[fs + i * BLOCK], vim + g);
+        __builtin_nontemporal_store(sr[i], vre + g);
+        __builtin_nontemporal_store(si[i], vim + g);
       }
     } else {
       for (unsigned e = tid; e < nvec; e += BLOCK) {
@@ -1077,10 +1102,15 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 #endif
       }
     }
+    HQ_TSTAMP(4);
     __syncthreads();
+    HQ_TSTAMP(5);
     if constexpr (PREF) {
       fill();  // tile + stride (a repeat of a finished tile past the end: never used)
-      prefetch(tile + 2 * stride < ntiles ? tile + 2 * stride : tile);
+      HQ_TSTAMP(6);
+      base_cur = next_base(base);
+      prefetch(tile + 2 * stride < ntiles ? next_base(base_cur) : base);
+      HQ_TSTAMP(7);
     }
   }
 }

@@ -24,9 +24,10 @@ packed = core.pack_blocked(gates, 'complex64')
 for _ in range(3):
     core.apply_blocked(planes[0], planes[1], tile, packed=packed, n_qubits=n)
 core.sync()
-buf = (ctypes.c_ulonglong * 256)()
+buf = (ctypes.c_ulonglong * 512)()
 assert core._lib.hq_debug_timeline(buf) == 0
-t = np.array(buf[:], dtype=np.int64).reshape(16, 16)[:8]
+allt = np.array(buf[:], dtype=np.int64).reshape(32, 16)
+t = allt[:8]
 t0 = t[:, 0].min()
 names = ['gate start', 'in gate fn', 'prologue done', 'it1 reads issued', 'it1 reads back', 'it1 MFMAs done', 'it1 writes issued',
          'it2 reads issued', 'it2 reads back', 'it2 MFMAs done', 'it2 writes issued', 'before barrier', 'after barrier']
@@ -34,3 +35,11 @@ idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
 print('%-20s' % 'wave', ' '.join('%7d' % w for w in range(8)))
 for nm, i in zip(names, idx):
     print('%-20s' % nm, ' '.join('%7d' % (t[w, i] - t0) for w in range(8)))
+
+tt = allt[8:16]
+t0 = tt[:, 0].min()
+print()
+print('tile level (same workgroup, 4th tile):')
+for nm, i in zip(['tile start', 'tile base done', 'after barrier (gates start)', 'gates done', 'stores issued', 'after barrier',
+                  'LDS filled (next tile)', 'next prefetch issued'], range(8)):
+    print('%-28s' % nm, ' '.join('%7d' % (tt[w, i] - t0) for w in range(8)))
