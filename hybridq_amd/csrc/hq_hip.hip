@@ -1376,7 +1376,8 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     const void* fns[] = {(const void*)apply_blocked_kernel<float, 256, false, false>, (const void*)apply_blocked_kernel<float, 512, false, false>,
                          (const void*)apply_blocked_kernel<double, 256, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false>,
                          (const void*)apply_blocked_kernel<float, 512, true, false>, (const void*)apply_blocked_kernel<double, 512, true, false>,
-                         (const void*)apply_blocked_kernel<float, 512, true, true>, (const void*)apply_blocked_kernel<float, 512, false, true>};
+                         (const void*)apply_blocked_kernel<float, 512, true, true>, (const void*)apply_blocked_kernel<float, 512, false, true>,
+                         (const void*)apply_blocked_kernel<double, 512, true, true>};
     for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -1389,18 +1390,18 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
   const size_t tab_bytes = (((size_t)n_gates * kBlockedTabWords * sizeof(BlockedTabT)) + 15) & ~(size_t)15;  // per-gate address tables (built in-kernel)
   const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
-  // register prefetch of the next tile (f32, 512 threads, 4 vectors per thread and plane = 13 tile bits)
+  // register prefetch of the next tile (512 threads, 4 vectors per thread and plane = 13 (f32) / 12 (f64) tile bits;
+  // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
   static int use_pref = getenv("HQ_BLOCKED_PREF") ? atoi(getenv("HQ_BLOCKED_PREF")) : 1;
-  const bool pref = use_pref && sizeof(T) == 4 && block_threads != 256 && tb == 13;
+  const bool pref = use_pref && block_threads != 256 && tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits);
   if (fits) {
     void *dG = nullptr, *dA = nullptr;
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
     if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
     const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes;
     if (pref) {
-      if constexpr (sizeof(T) == 4)
-        HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
-                  n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
+                n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
     } else {
       HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
                 n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);

@@ -426,7 +426,7 @@ PASS_MS = {1: 2.70, 2: 2.70, 3: 2.70, 4: 2.76, 5: 3.08, 6: 4.70, 7: 10.4, 8: 18.
 BLOCKED_BASE_MS = 3.0  # a blocked pass whose gates hide behind the HBM stream (tools/blocked_scaling.py: G <= 2)
 BLOCKED_OVERLAP_MS = 1.3  # ... what of the stream does NOT hide behind the gates once they dominate (complex64: the
 #                            next tile is prefetched into registers; 0.95 ms for a tile on the 8 lowest bits, 1.3 ms
-#                            fitted on the benchmark circuit's tiles; complex128 has no prefetch: the whole base stays)
+#                            fitted on the benchmark circuit's tiles; complex128 at n - 1 measures 15 % above the model)
 BLOCKED_INNER_MS = {1: 0.38, 2: 0.63, 3: 0.63, 4: 1.20}
 LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)
 
@@ -441,10 +441,7 @@ def estimate_ms(ops, n, ctype):
         if isinstance(g[0], str):
             if g[0] == 'B':
                 inner = sum(BLOCKED_INNER_MS[len(p)] for _, p in g[2])
-                if np.dtype(ctype) == np.dtype('complex64'):
-                    ms = max(BLOCKED_BASE_MS, BLOCKED_OVERLAP_MS + inner)
-                else:
-                    ms = BLOCKED_BASE_MS + inner
+                ms = max(BLOCKED_BASE_MS, BLOCKED_OVERLAP_MS + inner)
             else:
                 ms = PASS_MS[len(g[2])]
         else:

@@ -23,7 +23,7 @@ def test_choose_schedule_cost_model():
     assert abs(est['blocked'] - 150) < 12 and info['chosen'] == 'blocked'
     assert est['per_gate'] == pytest.approx(900 * PASS_MS[1], rel=1e-6)
     # complex128 costs twice the bytes, one qubit less halves them
-    # complex128: twice the bytes; the blocked passes additionally lose the register prefetch (no overlap term)
+    # complex128: twice the bytes
     assert estimate_ms(ops, n, np.dtype('complex128')) >= 2 * estimate_ms(ops, n, np.dtype('complex64'))
     plain = [(g[1], g[0]) if isinstance(g[0], str) else g for g in ops if not (isinstance(g[0], str) and g[0] == 'B')]
     assert estimate_ms(plain, n, np.dtype('complex128')) == pytest.approx(2 * estimate_ms(plain, n, np.dtype('complex64')))

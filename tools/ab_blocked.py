@@ -14,11 +14,13 @@ from hybridq_amd.circuits import rqc_1q2q  # noqa: E402
 from hybridq_amd.simulation import EvolutionState  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+ctype = sys.argv[2] if len(sys.argv) > 2 else 'complex64'
+tb = 13 if ctype == 'complex64' else 12
 gates = rqc_1q2q(n, depth=40, seed=n)
-state = EvolutionState(list(range(n)), complex_type='complex64', initial_state='0' * n)
-for kw in (dict(), dict(inner_max='auto'), dict(inner_max='auto', tries=64), dict(inner_max='auto', tries=64, low_bits=6), dict(inner_max=0)):
-    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=13, low_bits=5, complex_type='complex64'), **kw})
-    packed = [('B', op[1], core.pack_blocked(op[2], 'complex64')) if op[0] == 'B' else op for op in ops]
+state = EvolutionState(list(range(n)), complex_type=ctype, initial_state='0' * n)
+for kw in (dict(), dict(inner_max=0)):
+    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=tb - 8, complex_type=ctype), **kw})
+    packed = [('B', op[1], core.pack_blocked(op[2], ctype)) if op[0] == 'B' else op for op in ops]
 
     def run():
         for op in packed:
