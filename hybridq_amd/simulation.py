@@ -517,13 +517,13 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     kwargs.setdefault('return_info', False)
     kwargs.setdefault('return_numpy_array', True)
     kwargs.setdefault('max_largest_intermediate', 2**36)
-    auto_schedule = optimize == 'evolution-hip' and 'blocked' not in kwargs and 'compress' not in kwargs
-    if optimize == 'evolution-hip':
-        # this GPU's own schedule instead of the reference's defaults: the cost model below picks between
-        # gate-by-gate passes, fusion to width 4 / 5 (a k = 5 pass costs ~15 % more than a k <= 4 pass) and
-        # cache-blocked passes (many gates per HBM pass); explicit `compress=` / `blocked=` override it
-        kwargs.setdefault('blocked', True)
-        kwargs.setdefault('compress', 5)
+    # 'evolution' is the reference's "best evolution engine available" alias (simulation.py:379-399 picks between
+    # its C++ core and einsum); here it -- and the explicit 'evolution-hip' -- means this GPU's own schedule: the cost
+    # model below picks between gate-by-gate passes, fusion to width 4 / 5 (a k = 5 pass costs ~15 % more than a
+    # k <= 4 pass) and cache-blocked passes (many gates per HBM pass), and `info['schedule']` records the choice.
+    # Explicit `compress=` / `blocked=` override it; 'evolution-hybridq' keeps the reference core's own schedule
+    # (fusion to 4 qubits, one pass per fused gate).
+    auto_schedule = optimize in ('evolution', 'evolution-hip') and 'blocked' not in kwargs and 'compress' not in kwargs
     kwargs.setdefault('compress', 4)  # simulation.py:314
     kwargs.setdefault('device', None)
     if final_state is not None:  # simulation.py:415-418

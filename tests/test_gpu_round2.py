@@ -316,3 +316,9 @@ def test_evolution_hip_chooses_a_schedule(torch_cuda):
     # an explicit setting overrides the model
     _, info = simulate(rqc_1q2q(16, depth=6, seed=4), initial_state='0' * 16, optimize='evolution-hip', compress=3, return_info=True)
     assert 'schedule' not in info
+    # 'evolution' (the reference's "best engine" alias) chooses too; 'evolution-hybridq' keeps the reference schedule
+    g20 = rqc_1q2q(20, depth=12, seed=2)
+    psi_a, info_a = simulate(g20, initial_state='0' * 20, optimize='evolution', return_info=True, qubits=list(range(20)))
+    psi_h, info_h = simulate(g20, initial_state='0' * 20, optimize='evolution-hybridq', return_info=True, qubits=list(range(20)))
+    assert info_a['schedule']['chosen'] == 'blocked' and 'schedule' not in info_h
+    assert np.abs(psi_a - psi_h).max() / np.abs(psi_h).max() < 2 * circuit_tol(g20)
