@@ -322,3 +322,36 @@ def test_evolution_hip_chooses_a_schedule(torch_cuda):
     psi_h, info_h = simulate(g20, initial_state='0' * 20, optimize='evolution-hybridq', return_info=True, qubits=list(range(20)))
     assert info_a['schedule']['chosen'] == 'blocked' and 'schedule' not in info_h
     assert np.abs(psi_a - psi_h).max() / np.abs(psi_h).max() < 2 * circuit_tol(g20)
+
+
+@pytest.mark.parametrize('ct,n,tb', [('complex64', 25, 13), ('complex128', 24, 12), ('complex64', 23, 13)])
+def test_apply_blocked_many_tiles_per_workgroup(torch_cuda, ct, n, tb):
+    """The cache-blocked kernel with several tiles per (persistent) workgroup -- register prefetch of the next tile,
+    incremental tile base, table-driven gates -- and with more gates than the LDS tables hold (the variant that
+    computes its addresses and reads A operands from global memory): same state as the gates applied one by one
+    on the device (the per-gate kernels are pinned to the oracle elsewhere)."""
+    from hybridq_amd import core
+    from hybridq_amd.circuits import haar_unitary
+    torch = torch_cuda
+    core.use_torch_stream()
+    rng = np.random.default_rng(n)
+    ft = torch.float32 if ct == 'complex64' else torch.float64
+    low = 5 if ct == 'complex64' else 4
+    for n_gates in (3, 7, 24):
+        high = np.sort(rng.permutation(np.arange(low, n))[:tb - low])
+        tile = np.concatenate([np.arange(low), high]).astype(np.uint32)
+        gates = []
+        for _ in range(n_gates):
+            k = int(rng.integers(1, 5))
+            gates.append((haar_unitary(1 << k, rng).astype(ct), [int(p) for p in rng.permutation(tile)[:k]]))
+        a = torch.from_numpy(rng.standard_normal((2, 1 << n))).to(ft).cuda()
+        a /= torch.linalg.norm(a)
+        b = a.clone()
+        core.apply_blocked(a[0], a[1], tile, gates, n_qubits=n)
+        assert core.last_kernel() == 'blocked'
+        for U, pos in gates:
+            core.apply_U(b[0], b[1], U, pos, n)
+        core.sync()
+        err = float((a - b).abs().max() / b.abs().max())
+        as_circuit = [(U, tuple(pos)) for U, pos in gates]
+        assert err <= circuit_tol(as_circuit, as_circuit, complex_type=ct), (ct, n, n_gates, err)
