@@ -678,12 +678,30 @@ static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned*
   const size_t lds = (size_t)2 * sizeof(T) << a.tb;
   static bool attr_done = false;  // under the context mutex
   if (!attr_done) {
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW>,
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW, 0>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_done = true;
   }
   const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 2048);
-  HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+  // register prefetch of the next tile where the tile has the usual size of this wave shape and the registers allow
+  // (not the 8 x 1 shape of k = 10: 224 + 64 registers); HQ_GEMM_PREF=0 switches it off
+  constexpr int CBv = sizeof(T) == 4 ? 2 : 1;
+  constexpr int NPVx = sizeof(T) == 4 ? (CBW == 2 ? (RBW == 1 ? 2 : (RBW == 2 ? 4 : 0)) : 0)  // f32 4 x 2 (k = 9) would spill
+                                     : (CBW == 1 ? (RBW == 1 ? 2 : (RBW == 2 ? 4 : (RBW == 4 ? 8 : 0))) : 0);
+  static const int use_pref = getenv("HQ_GEMM_PREF") ? atoi(getenv("HQ_GEMM_PREF")) : 1;
+  if constexpr (NPVx > 0) {
+    if (use_pref && ((1u << (a.tb - CBv)) == (unsigned)NPVx * kGemmBlock)) {
+      static bool attr2 = false;
+      if (!attr2) {
+        HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW, NPVx>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr2 = true;
+      }
+      HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, NPVx>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+      return 0;
+    }
+  }
+  HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, 0>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
   return 0;
 }
 

@@ -1152,7 +1152,11 @@ struct GemmArg {
   unsigned nsg;                      // A-load groups = 2^k / (4 G), G = 16 / sizeof(T)
 };
 
-template <typename T, int RBW, int CBW>
+// NPV > 0 (tiles of exactly NPV * 512 vectors per plane): the next tile is requested into registers before the
+// MFMA phase of the current one and dropped into LDS after its results were stored (the same recipe, for the same
+// reason, as apply_blocked_kernel's PREF: copy-in, MFMA and copy-out phases run in step on the whole chip, so HBM
+// idled while the matrix cores worked and vice versa -- k = 7 measured 10.5 ms = 7.0 ms of MFMA + 2.9 ms of HBM).
+template <typename T, int RBW, int CBW, int NPV>
 __global__ void __launch_bounds__(kGemmBlock)
 apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ Atab,
                   const unsigned* __restrict__ offs, const GemmArg a, const uint64_t ntiles) {
@@ -1194,18 +1198,72 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
   const unsigned nvec = 1u << (a.tb - CB);
   const V* __restrict__ Av = reinterpret_cast<const V*>(Atab) + lane;
 
-  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    uint64_t base = tile;  // vec index with zeros at the tile's (non-component) positions
-    for (unsigned m = CB; m < a.tb; ++m) {
-      const uint64_t lo = (1ull << (a.apos[m] - CB)) - 1;
+  constexpr bool PREF = NPV > 0;
+  constexpr int NP = PREF ? NPV : 1;
+  auto tile_base = [&](uint64_t tile) {  // vec index with zeros at the tile's (non-component) positions
+    uint64_t base = tile;
+#pragma unroll
+    for (unsigned m = CB; m < (unsigned)kGemmMaxTileBits; ++m) {  // constant trip count: positions read from the arguments once
+      const uint64_t lo = m < a.tb ? (1ull << (a.apos[m] - CB)) - 1 : ~0ull;
       base = ((base & ~lo) << 1) | (base & lo);
     }
-    for (unsigned v = tid; v < nvec; v += kGemmBlock) {
-      uint64_t g = base;
-      for (unsigned m = CB; m < a.tb; ++m) g |= (uint64_t)((v >> (m - CB)) & 1u) << (a.apos[m] - CB);
-      const unsigned slot = swz(v << CB) >> CB;
-      reinterpret_cast<V*>(xr)[slot] = __builtin_nontemporal_load(pre + g);
-      reinterpret_cast<V*>(xi)[slot] = __builtin_nontemporal_load(pim + g);
+    return base;
+  };
+  auto vec_off = [&](unsigned v) {  // OR-linear in v
+    uint64_t g = 0;
+    for (unsigned m = CB; m < a.tb; ++m) g |= (uint64_t)((v >> (m - CB)) & 1u) << (a.apos[m] - CB);
+    return g;
+  };
+  const uint64_t stride = gridDim.x;
+  // deposited-coordinate increment: next = ((cur | ~M) + D) & M, M = the index bits outside the tile
+  const uint64_t dep_mask = tile_base(~0ull), dep_stride = tile_base(stride);
+  auto next_base = [&](uint64_t b) { return ((b | ~dep_mask) + dep_stride) & dep_mask; };
+  V pr[NP], pi[NP];
+  unsigned slot[NP];
+  uint64_t off_blk[NP];
+  const uint64_t off_tid = PREF ? vec_off(tid) : 0;
+  if constexpr (PREF) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      slot[i] = swz((tid + i * kGemmBlock) << CB) >> CB;
+      off_blk[i] = vec_off(i * kGemmBlock);  // wave-uniform
+    }
+  }
+  auto prefetch = [&](const uint64_t b) {  // unconditional, uniform address part pinned to SGPRs (see apply_blocked_kernel)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      uint64_t sb = b | off_blk[i];
+      asm volatile("" : "+s"(sb));
+      pr[i] = __builtin_nontemporal_load(pre + (sb | off_tid));
+      pi[i] = __builtin_nontemporal_load(pim + (sb | off_tid));
+    }
+  };
+  uint64_t base_cur = 0;
+  if constexpr (PREF) {
+    if (blockIdx.x >= ntiles) return;
+    base_cur = tile_base(blockIdx.x);
+    {
+      const uint64_t b = base_cur | off_tid;  // first tile: straight into LDS
+#pragma unroll 1
+      for (int i = 0; i < NP; ++i) {
+        const uint64_t g = b | vec_off(i * kGemmBlock);
+        const unsigned sl = swz((tid + i * kGemmBlock) << CB) >> CB;
+        reinterpret_cast<V*>(xr)[sl] = __builtin_nontemporal_load(pre + g);
+        reinterpret_cast<V*>(xi)[sl] = __builtin_nontemporal_load(pim + g);
+      }
+    }
+    prefetch(blockIdx.x + stride < ntiles ? next_base(base_cur) : base_cur);
+  }
+
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += stride) {
+    const uint64_t base = PREF ? base_cur : tile_base(tile);
+    if constexpr (!PREF) {
+      for (unsigned v = tid; v < nvec; v += kGemmBlock) {
+        const uint64_t g = base | vec_off(v);
+        const unsigned sl = swz(v << CB) >> CB;
+        reinterpret_cast<V*>(xr)[sl] = __builtin_nontemporal_load(pre + g);
+        reinterpret_cast<V*>(xi)[sl] = __builtin_nontemporal_load(pim + g);
+      }
     }
     __syncthreads();
     Acc accr[RBW][CBW], acci[RBW][CBW];
@@ -1254,14 +1312,40 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
       }
     }
     __syncthreads();
-    for (unsigned v = tid; v < nvec; v += kGemmBlock) {
-      uint64_t g = base;
-      for (unsigned m = CB; m < a.tb; ++m) g |= (uint64_t)((v >> (m - CB)) & 1u) << (a.apos[m] - CB);
-      const unsigned slot = swz(v << CB) >> CB;
-      __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[slot], pre + g);
-      __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[slot], pim + g);
+    if constexpr (PREF) {
+      V sr[NP], si[NP];  // all LDS reads in flight before the first store
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        sr[i] = reinterpret_cast<V*>(xr)[slot[i]];
+        si[i] = reinterpret_cast<V*>(xi)[slot[i]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        uint64_t sb = base | off_blk[i];
+        asm volatile("" : "+s"(sb));
+        __builtin_nontemporal_store(sr[i], pre + (sb | off_tid));
+        __builtin_nontemporal_store(si[i], pim + (sb | off_tid));
+      }
+      __syncthreads();
+      // the fill follows the stores on every path: the in-order vmcnt wait for the prefetched vectors sees
+      // "2 NPV loads, then 2 NPV stores" and never drains the stores
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        reinterpret_cast<V*>(xr)[slot[i]] = pr[i];
+        reinterpret_cast<V*>(xi)[slot[i]] = pi[i];
+      }
+      base_cur = next_base(base);
+      prefetch(tile + 2 * stride < ntiles ? next_base(base_cur) : base);
+    } else {
+      for (unsigned v = tid; v < nvec; v += kGemmBlock) {
+        const uint64_t g = base | vec_off(v);
+        const unsigned sl = swz(v << CB) >> CB;
+        __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[sl], pre + g);
+        __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[sl], pim + g);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
