@@ -1090,18 +1090,25 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
     const bool vec = tile_bits >= 10 && reinterpret_cast<uintptr_t>(a) % 16 == 0;
     static bool attr_done = false;
     if (!attr_done) {
-      HQ_HIP_CHECK(hipFuncSetAttribute((const void*)swap_lds_kernel<uint32_t, 4, false>,
+      HQ_HIP_CHECK(hipFuncSetAttribute((const void*)swap_lds_kernel<uint32_t, 4, false, 0>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HQ_HIP_CHECK(hipFuncSetAttribute((const void*)swap_lds_kernel<uint64_t, 2, false>,
+      HQ_HIP_CHECK(hipFuncSetAttribute((const void*)swap_lds_kernel<uint64_t, 2, false, 0>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_done = true;
     }
+    // register prefetch of the next tile: pays for the 32 KiB tiles of 4-byte elements only (s = 13 and the first
+    // pass of the two-pass path: 4.39 -> 5.09 TB/s); smaller tiles already overlap through their many resident
+    // workgroups and lose 5-9 % with it (tools/swap_rate.py).  HQ_SWAP_PREF=0 switches it off
+    static const int use_pref = getenv("HQ_SWAP_PREF") ? atoi(getenv("HQ_SWAP_PREF")) : 1;
+    const unsigned npv = vec ? (1u << tile_bits) / (kBlock * VEC) : 0;
     if (!table)
-      HQ_LAUNCH(c, (swap_lds_kernel<E, VEC, false>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
+      HQ_LAUNCH(c, (swap_lds_kernel<E, VEC, false, 0>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
+    else if (vec && use_pref && npv == 8 && sizeof(E) == 4)
+      HQ_LAUNCH(c, (swap_lds_kernel<E, VEC, true, 8>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
     else if (vec)
-      HQ_LAUNCH(c, (swap_lds_kernel<E, VEC, true>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
+      HQ_LAUNCH(c, (swap_lds_kernel<E, VEC, true, 0>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
     else
-      HQ_LAUNCH(c, (swap_lds_kernel<E, 1, true>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
+      HQ_LAUNCH(c, (swap_lds_kernel<E, 1, true, 0>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
     HQ_HIP_CHECK(hipGetLastError());
     return 0;
   }

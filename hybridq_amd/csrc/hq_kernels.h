@@ -1606,11 +1606,15 @@ struct SwapArg {
 // 16-byte loads into LDS, permuted LDS reads, 16-byte stores (VEC elements per access).
 // TABLE = false (large s: the whole LDS budget goes to the tile) computes the permuted index
 // inline instead of reading it from a 2^s-entry table.
-template <typename E, int VEC, bool TABLE>
+// NPV > 0 (tiles of exactly NPV * kBlock vectors): the next tile is requested into registers while this one is
+// permuted and stored, and dropped into LDS after the stores were issued (the recipe of apply_blocked_kernel's PREF:
+// load / permute-store phases of a tile no longer alternate in step on the whole chip).
+template <typename E, int VEC, bool TABLE, int NPV>
 __global__ void __launch_bounds__(kBlock)
 swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
                 const uint64_t ntiles) {
   struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
+  typedef E PackV __attribute__((ext_vector_type(VEC)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned S = 1u << sa.s, TILE = 1u << tile_bits;
   uint16_t* src = reinterpret_cast<uint16_t*>(smem);          // S entries (TABLE only)
@@ -1622,13 +1626,7 @@ swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
       for (unsigned i = 0; i < sa.s; ++i) y |= ((x >> i) & 1u) << sa.pos[i];
       src[x] = (uint16_t)y;
     }
-  for (uint64_t tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
-    E* g = a + tb * TILE;
-    __syncthreads();
-    for (unsigned x = tid * VEC; x < TILE; x += kBlock * VEC) {
-      *reinterpret_cast<Pack*>(buf + x) = *reinterpret_cast<const Pack*>(g + x);
-    }
-    __syncthreads();
+  auto permute_store = [&](E* g) {
     for (unsigned x = tid * VEC; x < TILE; x += kBlock * VEC) {
       Pack p;
 #pragma unroll
@@ -1644,6 +1642,40 @@ swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
         p.e[c] = buf[(xx & ~(S - 1)) | y];
       }
       *reinterpret_cast<Pack*>(g + x) = p;
+    }
+  };
+  if constexpr (NPV > 0 && VEC > 1) {
+    if (blockIdx.x >= ntiles) return;
+    const uint64_t stride = gridDim.x;
+    PackV pr[NPV];
+    auto prefetch = [&](uint64_t tb) {  // unconditional (callers clamp): see apply_blocked_kernel
+      const PackV* g = reinterpret_cast<const PackV*>(a + tb * TILE) + tid;
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) pr[i] = __builtin_nontemporal_load(g + i * kBlock);
+    };
+    {
+      const PackV* g = reinterpret_cast<const PackV*>(a + (uint64_t)blockIdx.x * TILE) + tid;
+#pragma unroll 1
+      for (int i = 0; i < NPV; ++i) reinterpret_cast<PackV*>(buf)[tid + i * kBlock] = __builtin_nontemporal_load(g + i * kBlock);
+    }
+    prefetch(blockIdx.x + stride < ntiles ? blockIdx.x + stride : blockIdx.x);
+    for (uint64_t tb = blockIdx.x; tb < ntiles; tb += stride) {
+      __syncthreads();
+      permute_store(a + tb * TILE);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) reinterpret_cast<PackV*>(buf)[tid + i * kBlock] = pr[i];
+      prefetch(tb + 2 * stride < ntiles ? tb + 2 * stride : tb);
+    }
+  } else {
+    for (uint64_t tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
+      E* g = a + tb * TILE;
+      __syncthreads();
+      for (unsigned x = tid * VEC; x < TILE; x += kBlock * VEC) {
+        *reinterpret_cast<Pack*>(buf + x) = *reinterpret_cast<const Pack*>(g + x);
+      }
+      __syncthreads();
+      permute_store(g);
     }
   }
 }
