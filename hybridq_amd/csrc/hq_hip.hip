@@ -686,7 +686,7 @@ static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned*
   // register prefetch of the next tile where the tile has the usual size of this wave shape and the registers allow
   // (not the 8 x 1 shape of k = 10: 224 + 64 registers); HQ_GEMM_PREF=0 switches it off
   constexpr int CBv = sizeof(T) == 4 ? 2 : 1;
-  constexpr int NPVx = sizeof(T) == 4 ? (CBW == 2 ? (RBW == 1 ? 2 : (RBW == 2 ? 4 : 0)) : 0)  // f32 4 x 2 (k = 9) would spill
+  constexpr int NPVx = sizeof(T) == 4 ? (CBW == 2 && RBW == 1 ? 2 : 0)  // f32: k = 7 only (2 x 2, k = 8: no gain, -3 % for some positions; 4 x 2 would spill)
                                      : (CBW == 1 ? (RBW == 1 ? 2 : (RBW == 2 ? 4 : (RBW == 4 ? 8 : 0))) : 0);
   static const int use_pref = getenv("HQ_GEMM_PREF") ? atoi(getenv("HQ_GEMM_PREF")) : 1;
   if constexpr (NPVx > 0) {

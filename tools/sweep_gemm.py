@@ -14,10 +14,14 @@ n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 core.use_torch_stream()
 rng = np.random.default_rng(0)
 for dt, n, ks in (('float32', n0, (7, 8, 9, 10)), ('float64', n0 - 1, (7, 8, 9))):
-    planes = torch.empty((2, 1 << n), dtype=getattr(torch, dt), device='cuda')
+    if os.environ.get('SWEEP_ALLOC', 'torch') == 'tuned':
+        from hybridq_amd.simulation import alloc_planes
+        planes = alloc_planes(n, getattr(torch, dt), 'cuda')
+    else:
+        planes = torch.empty((2, 1 << n), dtype=getattr(torch, dt), device='cuda')
     core.init_state(planes[0], planes[1], 'plus')
     for k in ks:
-        for pos in (sorted(int(p) for p in rng.permutation(n)[:k]), list(range(3, 3 + k))):
+        for pos in (sorted(int(p) for p in rng.permutation(n)[:k]), list(range(3, 3 + k)), [6, 15, 16, 19, 20, 21, 23, 27, 28, 29][:k]):
             U = haar_unitary(1 << k, rng).astype('complex64' if dt == 'float32' else 'complex128')
             core.apply_U(planes[0], planes[1], U, pos, n)
             torch.cuda.synchronize()
