@@ -1103,7 +1103,9 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
       }
     }
     HQ_TSTAMP(4);
-    __syncthreads();
+    // no barrier between the store phase and the fill with PREF: a thread refills exactly the LDS slots it has just
+    // read for its stores (fs + i * BLOCK both times), in its own program order
+    if constexpr (!PREF) __syncthreads();
     HQ_TSTAMP(5);
     if constexpr (PREF) {
       fill();  // tile + stride (a repeat of a finished tile past the end: never used)
@@ -1327,7 +1329,7 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
         __builtin_nontemporal_store(sr[i], pre + (sb | off_tid));
         __builtin_nontemporal_store(si[i], pim + (sb | off_tid));
       }
-      __syncthreads();
+      // (no barrier: a thread refills exactly the slots it has just read for its stores)
       // the fill follows the stores on every path: the in-order vmcnt wait for the prefetched vectors sees
       // "2 NPV loads, then 2 NPV stores" and never drains the stores
 #pragma unroll
