@@ -163,3 +163,25 @@ def test_qasm_extension_blocks_from_reference_writer():
         from_qasm('matrix 0')  # MATRIX without its U block
     with pytest.raises(ValueError):
         from_qasm('#@ qubits =\n#@ {\nh 0')  # unterminated JSON
+
+
+def test_blocked_planner_keeps_passes_inside_the_lds_tables():
+    """plan_blocked(inner_max='auto'): the fusion choice per pass prefers gate lists whose A-operand and address
+    tables fit the LDS beside the tile (the table-driven kernel variant); on the benchmark circuit every pass fits,
+    every gate is scheduled once, and the plan is deterministic."""
+    from hybridq_amd.blocking import LDS_TABLE_BUDGET, blocked_stats, lds_bytes, plan_blocked
+    from hybridq_amd.circuits import rqc_1q2q
+    n = 30
+    gates = rqc_1q2q(n, depth=40, seed=n)
+    pos = {q: n - 1 - q for q in range(n)}
+    ops = plan_blocked(gates, pos, n)
+    again = plan_blocked(gates, pos, n)
+    assert [(o[0], len(o[2])) for o in ops] == [(o[0], len(o[2])) for o in again]
+    st = blocked_stats(ops)
+    assert st['blocked_passes'] <= 30 and st['plain_gates'] == 0 and st['inner_gates'] <= 160
+    inv = {p: q for q, p in pos.items()}
+    for op in ops:
+        assert op[0] == 'B'
+        assert lds_bytes([(U, [inv[p] for p in ps]) for U, ps in op[2]]) <= LDS_TABLE_BUDGET
+    unfused = plan_blocked(gates, pos, n, inner_max=0)
+    assert sum(len(o[2]) for o in unfused if o[0] == 'B') + sum(1 for o in unfused if o[0] == 'G') == len(gates)
