@@ -21,8 +21,12 @@
  * HQ_PROGRAM_MB (table buffer of a recorded program, default 64),
  * HQ_PROGRAM_GRAPH (0: replay programs as a launch loop instead of a hipGraph);
  * measurement switches: HQ_GEMM_TB (tile bits of the k >= 7 kernel),
- * HQ_BLOCKED_THREADS (256|512), HQ_BLOCKED_ALDS (0: operand tables of blocked
- * passes stay in global memory).
+ * HQ_BLOCKED_THREADS (256|512), HQ_BLOCKED_ALDS (0: operand and address tables of
+ * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_PREF,
+ * HQ_GEMM_PREF, HQ_SWAP_PREF (0: no register prefetch of the next tile in the
+ * cache-blocked / k >= 7 / low-bit-swap kernels), HQ_BIG_PHASED, HQ_BIG_GRID (k = 5, 6
+ * kernel), HQ_SWAP_TWO_PASS (0: one 128 KiB-tile pass or gather + copy for s > 13),
+ * HQ_VMM_FREE_VA (1: hq_free also releases the virtual range).
  */
 #ifndef HQ_HIP_H
 #define HQ_HIP_H
