@@ -355,3 +355,27 @@ def test_apply_blocked_many_tiles_per_workgroup(torch_cuda, ct, n, tb):
         err = float((a - b).abs().max() / b.abs().max())
         as_circuit = [(U, tuple(pos)) for U, pos in gates]
         assert err <= circuit_tol(as_circuit, as_circuit, complex_type=ct), (ct, n, n_gates, err)
+
+
+@pytest.mark.parametrize('dt,n', [('float32', 26), ('float64', 25)])
+def test_swap_many_tiles_per_workgroup(torch_cuda, dt, n):
+    """swap_* with far more LDS tiles than workgroups (the persistent loop with the register prefetch of the next
+    tile for 32 KiB float32 tiles): s = 8, 12, 13, 15 on 2^n elements, exact against a gather computed with torch
+    index arithmetic on the device."""
+    from hybridq_amd import core
+    torch = torch_cuda
+    rng = np.random.default_rng(n)
+    tdt = getattr(torch, dt)
+    a = torch.arange(1 << n, device='cuda', dtype=torch.int64)
+    for s in (8, 12, 13, 15):
+        pos = rng.permutation(s)
+        x = a & ((1 << s) - 1)
+        y = torch.zeros_like(x)
+        for i in range(s):  # new[x] = old[(x & ~(2^s - 1)) | sum_i x_i << pos[i]]   (python_swap.cpp:68-99)
+            y |= ((x >> i) & 1) << int(pos[i])
+        src = (a & ~((1 << s) - 1)) | y
+        data = (a % 1000003).to(tdt)  # exactly representable, all chunks different
+        exp = data[src]
+        core.swap(data, pos, n)
+        core.sync()
+        assert torch.equal(data, exp), (dt, n, s, list(pos))
