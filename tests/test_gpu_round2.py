@@ -379,3 +379,37 @@ def test_swap_many_tiles_per_workgroup(torch_cuda, dt, n):
         core.swap(data, pos, n)
         core.sync()
         assert torch.equal(data, exp), (dt, n, s, list(pos))
+
+
+@pytest.mark.parametrize('ct,n,ks', [('complex64', 25, (7, 8)), ('complex128', 24, (7, 8, 9))])
+def test_gemm_kernel_many_tiles_per_workgroup(torch_cuda, ct, n, ks):
+    """k >= 7 on more tiles than workgroups (the persistent loop of apply_gemm_kernel with the register prefetch
+    of the next tile, incremental tile base): same result as the VALU kernel (`generic` mode: an independent
+    implementation pinned to the oracle at small n), and U^dagger undoes U."""
+    from hybridq_amd import core
+    from hybridq_amd.circuits import haar_unitary
+    torch = torch_cuda
+    core.use_torch_stream()
+    rng = np.random.default_rng(5 * n)
+    ft = torch.float32 if ct == 'complex64' else torch.float64
+    tol = 4 * BAR[np.dtype(ct)]
+    for k in ks:
+        pos = sorted(int(p) for p in rng.permutation(n)[:k])
+        U = haar_unitary(1 << k, rng).astype(ct)
+        a = torch.from_numpy(rng.standard_normal((2, 1 << n))).to(ft).cuda()
+        a /= torch.linalg.norm(a)
+        b, orig = a.clone(), a.clone()
+        core.apply_U(a[0], a[1], U, pos, n)
+        assert core.last_kernel() == 'gemm', core.last_kernel_desc()
+        core.set_apply_mode('generic')
+        try:
+            core.apply_U(b[0], b[1], U, pos, n)
+            assert core.last_kernel() != 'gemm'
+        finally:
+            core.set_apply_mode('auto')
+        core.sync()
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) / scale < tol, (ct, n, k, pos)
+        core.apply_U(a[0], a[1], np.ascontiguousarray(U.conj().T), pos, n)
+        core.sync()
+        assert float((a - orig).abs().max()) / float(orig.abs().max()) < 2 * tol, (ct, n, k, pos)
