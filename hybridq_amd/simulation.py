@@ -428,6 +428,7 @@ BLOCKED_OVERLAP_MS = 1.3  # ... what of the stream does NOT hide behind the gate
 #                            next tile is prefetched into registers; 0.95 ms for a tile on the 8 lowest bits, 1.3 ms
 #                            fitted on the benchmark circuit's tiles; complex128 at n - 1 measures 15 % above the model)
 BLOCKED_INNER_MS = {1: 0.38, 2: 0.63, 3: 0.63, 4: 1.20}
+TUNED_PLACEMENT_SEARCH_MS = 2500.0  # what alloc_planes' draw-and-probe search costs (n = 30; measured 2.5 s)
 LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)
 
 
@@ -567,9 +568,13 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     torch = _torch()
     if _wants_shards(kwargs):
         return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule)
+    # Placement of the state: the tuned (VMM draw-and-probe) placement speeds the streaming kernels up by ~10 % but
+    # the search itself costs ~2.5 s at n = 30 (8 draws): only worth it when the modelled loop is long enough to
+    # win that back; the cache-blocked passes prefer the plain allocator anyway (prepare_state_planes).
     n_blocked = sum(1 for g in gates if not _is_functional(g) and isinstance(g[0], str) and g[0] == 'B')
+    tuned = 2 * n_blocked <= len(gates) and 0.1 * estimate_ms(gates, n, ctype) > TUNED_PLACEMENT_SEARCH_MS
     state = EvolutionState(qubits, complex_type=complex_type, initial_state=initial_state,
-                           device=kwargs['device'], placement='plain' if 2 * n_blocked > len(gates) else 'tuned')
+                           device=kwargs['device'], placement='tuned' if tuned else 'plain')
     info = {}
     core.sync()
     t0 = time.perf_counter()  # simulation.py:519
