@@ -220,7 +220,7 @@ class HipBackend:
 
     _ipc_mappings = {}  # (peer rank, exported handle) -> base address of the mapping in this process
 
-    def __init__(self, float_type, device=None, transport=None):
+    def __init__(self, float_type, device=None, transport=None, placement='tuned'):
         import os
         import torch
         import torch.distributed as dist
@@ -233,6 +233,7 @@ class HipBackend:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.transport = transport or os.environ.get('HQ_SHARD_TRANSPORT', 'auto')
         self.transport_note = ''
+        self.placement = placement  # 'tuned': draw-and-probe VMM placement of the shard buffers (seconds); 'plain': torch's allocator
         core.use_torch_stream()
 
     def _wanted_transport(self):
@@ -245,7 +246,7 @@ class HipBackend:
         from .simulation import alloc_planes
         # re/im rows offset by PLANE_PAD_BYTES.  Planes that other ranks map through HIP IPC (p2p transport)
         # must come from hipMalloc: hipIpcGetMemHandle does not export the library's VMM mappings.
-        return alloc_planes(m, self.tdt, self.device, vmm=self._wanted_transport() != 'p2p')
+        return alloc_planes(m, self.tdt, self.device, vmm=self.placement == 'tuned' and self._wanted_transport() != 'p2p')
 
     # -- exchange transport ---------------------------------------------------------------
     def setup_exchange(self, group, buffers):

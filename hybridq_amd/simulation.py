@@ -632,7 +632,10 @@ def _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_sch
     gates = [(U, qs) for qs, U in (_gate_qubits_matrix(g) for g in circuit)]
     compress = kwargs['compress']
     comp_n = compress.get('max_n_qubits', 4) if isinstance(compress, dict) else compress
-    sh = ShardedEvolution(n, complex_type=ctype, initial_state=initial_state, qubits=qubits)
+    # one-shot call: the placement search of the shard buffers (seconds per buffer) is not won back by one circuit
+    from .dist import HipBackend
+    sh = ShardedEvolution(n, complex_type=ctype, initial_state=initial_state, qubits=qubits,
+                          backend=HipBackend(_FLOAT_OF[np.dtype(ctype)], placement='plain'))
     # auto schedule: cache-blocked local passes between the exchanges (2.7x the fused stream on one GPU)
     blocked = kwargs.get('blocked', bool(auto_schedule) and sh.m >= 14)
     sched = sh.plan(gates, compress=comp_n or 0, blocked=blocked)
