@@ -20,15 +20,38 @@ win; the matrix-core kernel absorbs the 16x larger matrices for free.
 import numpy as np
 
 
+_EMBED_INDEX = {}  # (k, gate axes) -> (rows, cols) of the embedded matrix, cached
+
+
 def _embed(U, qs, Q):
-    """Matrix of gate (U, qs) on the ordered qubit list Q (Q[0] = most significant bit)."""
+    """Matrix of gate (U, qs) on the ordered qubit list Q (Q[0] = most significant bit).  One fancy assignment
+    through cached index arrays: the planners call this tens of thousands of times on tiny matrices, where
+    numpy's tensordot / moveaxis bookkeeping cost more than the arithmetic."""
     k = len(Q)
     kg = len(qs)
-    M = np.eye(1 << k, dtype=np.complex128).reshape((2,) * k + (1 << k,))
-    axes = [Q.index(q) for q in qs]
-    Ut = np.asarray(U, dtype=np.complex128).reshape((2,) * (2 * kg))
-    M = np.moveaxis(np.tensordot(Ut, M, axes=(list(range(kg, 2 * kg)), axes)), list(range(kg)), axes)
-    return M.reshape(1 << k, 1 << k)
+    U = np.asarray(U, dtype=np.complex128).reshape(1 << kg, 1 << kg)
+    if kg == k and list(qs) == list(Q):
+        return U.copy()
+    axes = tuple(Q.index(q) for q in qs)
+    key = (k, axes)
+    idx = _EMBED_INDEX.get(key)
+    if idx is None:
+        gate_bits = [k - 1 - a for a in axes]  # index bit of the embedded matrix carrying gate bit kg-1-j
+        rest_bits = [b for b in range(k) if b not in gate_bits]
+        g = np.arange(1 << kg)
+        gpart = np.zeros(1 << kg, dtype=np.int64)
+        for j, b in enumerate(gate_bits):  # gate index bit kg-1-j (qs[0] most significant) -> matrix bit b
+            gpart |= ((g >> (kg - 1 - j)) & 1) << b
+        r = np.arange(1 << (k - kg))
+        rpart = np.zeros(1 << (k - kg), dtype=np.int64)
+        for j, b in enumerate(rest_bits):
+            rpart |= ((r >> j) & 1) << b
+        rows = rpart[:, None, None] | gpart[None, :, None]
+        cols = rpart[:, None, None] | gpart[None, None, :]
+        idx = _EMBED_INDEX[key] = (rows, cols)
+    M = np.zeros((1 << k, 1 << k), dtype=np.complex128)
+    M[idx[0], idx[1]] = U[None, :, :]
+    return M
 
 
 def _sorted_union(a, b):
@@ -46,7 +69,8 @@ def commute(U1, q1, U2, q2, atol=1e-7):
         return True
     Q = _sorted_union(q1, q2)
     A, B = _embed(U1, q1, Q), _embed(U2, q2, Q)
-    return bool(np.allclose(A @ B, B @ A, atol=atol))
+    AB, BA = A @ B, B @ A
+    return bool((np.abs(AB - BA) <= atol + 1e-5 * np.abs(BA)).all())  # np.allclose's test without its bookkeeping
 
 
 class _Layer:
