@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // mode bit 0: MFMA waves work, bit 1: LDS waves work, bit 2: every wave does both (read, MFMA, write per iteration)
 __global__ void __launch_bounds__(512) k(float* out, int iters, int mode, float a, int flags, unsigned m0, unsigned m1, const unsigned* __restrict__ desc) {
@@ -16,7 +17,25 @@ __global__ void __launch_bounds__(512) k(float* out, int iters, int mode, float 
   f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   f32x4 x[4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1, 1, 1, 1}, {1, 1, 1, 1}};
   const unsigned slot = (wave & 3) * 1024 + lane;  // 4 x 64 vectors per wave, conflict-free
-  if (mode & 4) {
+  if ((mode & 4) && (flags & 16)) {
+    // the same LDS traffic and pipe time per iteration with v_mfma_f32_32x32x2_f32: 8 instructions of 64 cycles
+    f32x16 big[2];
+    for (int i = 0; i < 16; ++i) { big[0][i] = 0; big[1][i] = 0; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = tile[slot + ((r * 64 + it * 256) & 1023 & ~63u)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        big[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[s][0], big[0], 0, 0, 0);
+        big[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[s][2], big[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[slot + ((r * 64 + it * 256) & 1023 & ~63u)] = f32x4{big[r & 1][r], big[r & 1][r + 4], big[r & 1][r + 8], big[r & 1][r + 12]};
+      if ((flags & 1) && (it & 1)) __syncthreads();
+    }
+    acc[0][0] += big[0][0] + big[1][0];
+  } else if (mode & 4) {
     // flags bit 0: workgroup barrier every 2 iterations ("per gate"); bit 1: ~25 dependent VALU ops of address
     // arithmetic per iteration; bit 2: a "gate prologue" every 2 iterations (8 ds_read_b32 + ~50 dependent VALU ops)
     unsigned salt = 0;
@@ -94,7 +113,8 @@ int main() {
                         {4, 0, "every wave: read, MFMA, write"}, {4, 1, " + barrier / 2 it"}, {4, 2, " + 25 VALU / it"},
                         {4, 4, " + prologue / 2 it"}, {4, 3, " + barrier + VALU"}, {4, 5, " + barrier + prologue"},
                         {4, 7, " + barrier + VALU + prologue"}, {4, 8, " + 2 dependent s_loads / 2 it"},
-                        {4, 9, " + barrier + s_loads"}, {4, 15, " + barrier + VALU + prologue + s_loads"}};
+                        {4, 9, " + barrier + s_loads"}, {4, 15, " + barrier + VALU + prologue + s_loads"},
+                        {4, 16, "32x32x2: read, MFMA, write"}, {4, 17, "32x32x2 + barrier / 2 it"}};
   unsigned* desc;
   hipMalloc(&desc, 64 * 4);
   hipMemset(desc, 0, 64 * 4);
