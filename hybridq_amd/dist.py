@@ -83,10 +83,17 @@ def plan_schedule(gate_qubits, qubits, g):
             raise RuntimeError('planner stalled without global qubits')
         # blocked frontier: ready gates that touch a global position
         heads = sorted({queues[q][0] for q in qubits if queues[q]})
+        # qubits the exchange must not evict: those of the ready gates, in program order, as long as g evictable
+        # local qubits remain (small shards with wide fused gates: protecting EVERY ready gate can leave none)
         needed = set()
         for gi in heads:
             if ready(gi):
-                needed.update(gate_qubits[gi])
+                more = needed | set(gate_qubits[gi])
+                if sum(1 for q in qubits if pos[q] < m and q not in more) < g:
+                    if not needed:
+                        needed = more  # even the first gate alone leaves too few: reported below
+                    break
+                needed = more
         local = [q for q in qubits if pos[q] < m and q not in needed]
         if len(local) < g:
             raise RuntimeError('not enough evictable local qubits for an exchange')

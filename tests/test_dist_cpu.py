@@ -142,7 +142,7 @@ def _worker(rank, world, port, n, seed, ct, out_dir):
 
 
 @pytest.mark.parametrize('world,n,ct', [(2, 10, 'complex128'), (4, 11, 'complex128'), (2, 12, 'complex64'),
-                                        (2, 15, 'complex64')])
+                                        (2, 15, 'complex64'), (8, 12, 'complex128')])  # 8 ranks = BASELINE configs 3 and 5
 def test_sharded_matches_single_process(tmp_path, world, n, ct):
     import torch.multiprocessing as mp
     import oracle
