@@ -212,6 +212,31 @@ def fuse_evictions(schedule):
 # ------------------------------------------------------------------------------------
 # backends
 # ------------------------------------------------------------------------------------
+def exchange_selftest(torch, tdt, device, world, rank, exchange):
+    """Run ``exchange(src, dst, perm, m) -> result_in_src`` (collective) once without and once with a local
+    permutation on rank-tagged data and check every received chunk: chunk j of the result must be chunk `rank` of
+    rank j's (permuted) source.  Raises RuntimeError on a mismatch.  Transport-agnostic: the CPU test-suite runs it
+    over gloo with the host backend, HipBackend runs it on a fresh RCCL communicator."""
+    g = int(np.log2(world))
+    m = max(2 * g + 2, 12)
+    chunk = (1 << m) >> g
+    src = torch.empty((2, 1 << m), dtype=tdt, device=device)
+    dst = torch.zeros_like(src)
+    idx = torch.arange(1 << m, device=device)
+    for perm in (None, np.concatenate([[1, 0], np.arange(2, m)]).astype(np.uint32)):
+        src[0] = (idx % 4096).to(tdt) + 4096.0 * rank  # exactly representable, rank-tagged
+        src[1] = -src[0]
+        got = src if exchange(src, dst, perm, m) else dst
+        x = idx[rank * chunk:(rank + 1) * chunk]
+        if perm is not None:  # bits 0 and 1 swapped (its own inverse: independent of the direction convention)
+            x = (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1)
+        for j in range(world):
+            want = (x % 4096).to(tdt) + 4096.0 * j
+            if not torch.equal(got[0, j * chunk:(j + 1) * chunk], want) or \
+                    not torch.equal(got[1, j * chunk:(j + 1) * chunk], -want):
+                raise RuntimeError(f'exchange self-test: wrong data in chunk {j}' + (' (with permutation)' if perm is not None else ''))
+
+
 class HipBackend:
     """Shard planes in HBM (torch tensors), kernels and the qubit exchange from libhq_hip.so.
 
@@ -273,6 +298,7 @@ class HipBackend:
                 uid = [self.core.shard_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                 self.core.shard_init_rccl(world, rank, uid[0])
+                self._rccl_selftest(world, rank)
             elif want == 'p2p':
                 self._setup_p2p(group, buffers)
             elif want != 'torch':
@@ -289,6 +315,16 @@ class HipBackend:
                 self.transport_note = f'{want} transport unavailable on a peer ({[o for o in ok if o][0]}); using torch.distributed collectives'
                 want = 'torch'
         self.transport = want
+
+    def _rccl_selftest(self, world, rank):
+        """One small real exchange through hq_exchange_* right after the communicator exists (exchange_selftest): a
+        transport that errors or delivers the wrong chunks is detected HERE, where every rank can still agree on
+        the torch fallback."""
+        def ex(src, dst, perm, m):
+            in_src = self.core.exchange(src[0], src[1], dst[0], dst[1], perm, m)
+            self.core.sync()
+            return in_src
+        exchange_selftest(self.torch, self.tdt, self.device, world, rank, ex)
 
     def _setup_p2p(self, group, buffers):
         core, dist = self.core, self.dist

@@ -92,11 +92,24 @@ def _free_port():
 
 
 def _worker(rank, world, port, n, seed, ct, out_dir):
+    import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
+        # the exchange self-test of the product (run on a fresh RCCL communicator there): its expectation must hold
+        # for the reference two-step exchange (permute, then all_to_all_single) on every rank count
+        from hybridq_amd.dist import exchange_selftest
+        _be = CpuBackend(np.float64)
+
+        def _ex(src, dst, perm, m):
+            if perm is not None:
+                _be.permute(src, dst, perm, m)
+                src, dst = dst, src
+            _be.all_to_all(dst, src, None)
+            return perm is not None
+        exchange_selftest(torch, torch.float64, 'cpu', world, rank, _ex)
         from hybridq_amd.circuits import random_dense, rqc_1q2q
         from hybridq_amd.dist import ShardedEvolution
         ft = np.float32 if ct == 'complex64' else np.float64

@@ -140,6 +140,11 @@ def test_rccl_transport_plumbing(torch_cuda):
         core.sync()
         exp = torch.arange(1 << 22, dtype=torch.float32, device='cuda') * 2.0 + 1.0
         assert torch.equal(b, exp)
+        # the self-test HipBackend runs after creating its communicator on a real multi-GPU job (world = 1 here:
+        # checks its expectation for the permuted case and that it runs through hq_exchange_*)
+        from hybridq_amd.dist import HipBackend
+        HipBackend(np.float32)._rccl_selftest(1, 0)
+        HipBackend(np.float64)._rccl_selftest(1, 0)
     finally:
         core.shard_free()
 
