@@ -994,12 +994,19 @@ static int launch_tile_permute(Context& c, E* a, unsigned n, const std::vector<u
                      ((size_t)sizeof(E) << ta.tb);
   static bool attr_done = false;
   if (!attr_done) {
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)tile_permute_kernel<uint32_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)tile_permute_kernel<uint64_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)tile_permute_kernel<uint32_t, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)tile_permute_kernel<uint64_t, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)tile_permute_kernel<uint32_t, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_done = true;
   }
   const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
-  HQ_LAUNCH(c, (tile_permute_kernel<E, VEC>), dim3(grid), dim3(kBlock), lds, a, ta, ntiles);
+  // register prefetch of the next tile for the 32 KiB tiles of 4-byte elements (as in swap_lds_kernel; HQ_SWAP_PREF=0: off)
+  static const int use_pref = getenv("HQ_SWAP_PREF") ? atoi(getenv("HQ_SWAP_PREF")) : 1;
+  if (use_pref && sizeof(E) == 4 && ((1u << ta.tb) / VEC) == 8u * kBlock) {
+    if constexpr (sizeof(E) == 4) HQ_LAUNCH(c, (tile_permute_kernel<E, VEC, 8>), dim3(grid), dim3(kBlock), lds, a, ta, ntiles);
+  } else {
+    HQ_LAUNCH(c, (tile_permute_kernel<E, VEC, 0>), dim3(grid), dim3(kBlock), lds, a, ta, ntiles);
+  }
   HQ_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -1697,7 +1697,8 @@ struct TilePermArg {
 template <typename E, int VEC> struct PackOf { typedef E type __attribute__((ext_vector_type(VEC))); };
 template <typename E> struct PackOf<E, 1> { typedef E type; };
 
-template <typename E, int VEC>
+// NPV > 0 (tiles of exactly NPV * kBlock vectors): register prefetch of the next tile (see swap_lds_kernel).
+template <typename E, int VEC, int NPV>
 __global__ void __launch_bounds__(kBlock)
 tile_permute_kernel(E* __restrict__ a, const TilePermArg ta, const uint64_t ntiles) {
   using Pack = typename PackOf<E, VEC>::type;
@@ -1718,17 +1719,15 @@ tile_permute_kernel(E* __restrict__ a, const TilePermArg ta, const uint64_t ntil
     for (unsigned m = VBITS; m < ta.tb; ++m) g |= ((v >> (m - VBITS)) & 1u) << ta.apos[m];
     goff[v] = g;
   }
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  auto tile_ptr = [&](uint64_t t) {
     uint64_t base = t;  // element index with zeros at the tile's positions
     for (unsigned m = 0; m < ta.tb; ++m) {
       const uint64_t lo = (1ull << ta.apos[m]) - 1;
       base = ((base & ~lo) << 1) | (base & lo);
     }
-    E* __restrict__ at = a + base;
-    __syncthreads();
-    for (unsigned v = tid; v < NV; v += kBlock)
-      *reinterpret_cast<Pack*>(buf + v * VEC) = __builtin_nontemporal_load(reinterpret_cast<const Pack*>(at + goff[v]));
-    __syncthreads();
+    return a + base;
+  };
+  auto permute_store = [&](E* __restrict__ at) {
     for (unsigned v = tid; v < NV; v += kBlock) {
       Pack p;
       if constexpr (VEC == 1) {
@@ -1738,6 +1737,44 @@ tile_permute_kernel(E* __restrict__ a, const TilePermArg ta, const uint64_t ntil
         for (int c = 0; c < VEC; ++c) p[c] = buf[src[v * VEC + c]];
       }
       __builtin_nontemporal_store(p, reinterpret_cast<Pack*>(at + goff[v]));
+    }
+  };
+  if constexpr (NPV > 0 && VEC > 1) {
+    if (blockIdx.x >= ntiles) return;
+    __syncthreads();  // goff is read below by other threads than its writers
+    const uint64_t stride = gridDim.x;
+    Pack pr[NPV];
+    uint32_t go[NPV];
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) go[i] = goff[tid + i * kBlock];
+    auto prefetch = [&](uint64_t t) {  // unconditional (callers clamp)
+      const E* __restrict__ at = tile_ptr(t);
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) pr[i] = __builtin_nontemporal_load(reinterpret_cast<const Pack*>(at + go[i]));
+    };
+    {
+      const E* __restrict__ at = tile_ptr(blockIdx.x);
+#pragma unroll 1
+      for (int i = 0; i < NPV; ++i)
+        *reinterpret_cast<Pack*>(buf + (tid + i * kBlock) * VEC) = __builtin_nontemporal_load(reinterpret_cast<const Pack*>(at + goff[tid + i * kBlock]));
+    }
+    prefetch(blockIdx.x + stride < ntiles ? blockIdx.x + stride : blockIdx.x);
+    for (uint64_t t = blockIdx.x; t < ntiles; t += stride) {
+      __syncthreads();
+      permute_store(tile_ptr(t));
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) *reinterpret_cast<Pack*>(buf + (tid + i * kBlock) * VEC) = pr[i];
+      prefetch(t + 2 * stride < ntiles ? t + 2 * stride : t);
+    }
+  } else {
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      E* __restrict__ at = tile_ptr(t);
+      __syncthreads();
+      for (unsigned v = tid; v < NV; v += kBlock)
+        *reinterpret_cast<Pack*>(buf + v * VEC) = __builtin_nontemporal_load(reinterpret_cast<const Pack*>(at + goff[v]));
+      __syncthreads();
+      permute_store(at);
     }
   }
 }
