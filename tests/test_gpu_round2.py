@@ -413,3 +413,21 @@ def test_gemm_kernel_many_tiles_per_workgroup(torch_cuda, ct, n, ks):
         core.apply_U(a[0], a[1], np.ascontiguousarray(U.conj().T), pos, n)
         core.sync()
         assert float((a - orig).abs().max()) / float(orig.abs().max()) < 2 * tol, (ct, n, k, pos)
+
+
+def test_large_state_comes_back_through_the_chunked_copy(torch_cuda):
+    """simulate(return_numpy_array=True) on a state above CHUNKED_RETURN_MIN_BYTES: the chunked, threaded device -> host
+    copy returns exactly what the plain tensor.cpu() gives."""
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import CHUNKED_RETURN_MIN_BYTES, _to_host, simulate
+    torch = torch_cuda
+    n = 26
+    assert (8 << n) >= CHUNKED_RETURN_MIN_BYTES
+    g = rqc_1q2q(n, depth=4, seed=3)
+    psi = simulate(g, initial_state='+' * n, qubits=list(range(n)))
+    st = simulate(g, initial_state='+' * n, qubits=list(range(n)), return_numpy_array=False)
+    ref = st.to_complex().cpu().numpy()
+    assert psi.shape == (2,) * n and psi.dtype == np.complex64
+    assert np.array_equal(psi.reshape(-1), ref)
+    x = torch.randn(1 << 25, dtype=torch.complex128, device='cuda')
+    assert np.array_equal(_to_host(x), x.cpu().numpy())
