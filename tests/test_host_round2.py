@@ -18,7 +18,7 @@ def test_choose_schedule_cost_model():
     gates = rqc_1q2q(n, depth=40, seed=n)
     ops, info = choose_schedule(gates, list(range(n)), n, np.dtype('complex64'))
     est = info['modelled_ms']
-    # measured on MI355X (profiles/r02_v6_bench.json): 2415-2509 / 399-408 / 307-311 / 135-148 ms
+    # measured on MI355X (profiles/r02_v7_bench.json): 2415-2509 / 399-408 / 307-311 / 135-148 ms
     assert abs(est['per_gate'] - 2431) < 50 and abs(est['fused_4'] - 400) < 25 and abs(est['fused_5'] - 307) < 15
     assert abs(est['blocked'] - 137) < 10 and info['chosen'] == 'blocked'
     assert est['per_gate'] == pytest.approx(900 * PASS_MS[1], rel=1e-6)
