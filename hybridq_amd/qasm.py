@@ -152,3 +152,26 @@ def from_qasm(text):
             U = U.T
         gates.append((np.ascontiguousarray(U), qs))
     return gates
+
+
+def to_qasm(gates, qubits_map=None):
+    """Write ``[(U, qubits), ...]`` in the reference's extended QASM (hybridq/extras/io/qasm.py:160-233): the number
+    of qubits, a ``#@ qubits =`` map from QASM index to label, and every gate as a ``matrix`` line preceded by its
+    ``#@ U =`` block (a plain (U, qubits) pair carries no gate name).  ``from_qasm(to_qasm(c))`` returns the same
+    matrices and labels; the reference's ``from_qasm`` reads the text as MATRIX gates."""
+    import json
+    gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
+    labels = sorted({q for _, qs in gates for q in qs}, key=lambda q: (type(q).__name__, q))
+    if qubits_map is None:
+        qubits_map = {q: i for i, q in enumerate(labels)}
+    lines = [str(len(labels)), '#@ qubits = ']
+    lines += ['#@ ' + x for x in json.dumps({str(i): str(q) for q, i in sorted(qubits_map.items(), key=lambda kv: kv[1])},
+                                             indent=2).split('\n')]
+    for U, qs in gates:
+        if U.shape != (1 << len(qs),) * 2:
+            raise ValueError(f'matrix shape {U.shape} does not fit {len(qs)} qubit(s)')
+        rows = [[str(complex(x)) for x in row] for row in U]
+        lines.append('#@ U = ')
+        lines += ['#@ ' + x for x in json.dumps(rows, indent=2).split('\n')]
+        lines.append('matrix ' + ' '.join(str(qubits_map[q]) for q in qs))
+    return '\n'.join(lines) + '\n'

@@ -185,3 +185,18 @@ def test_blocked_planner_keeps_passes_inside_the_lds_tables():
         assert lds_bytes([(U, [inv[p] for p in ps]) for U, ps in op[2]]) <= LDS_TABLE_BUDGET
     unfused = plan_blocked(gates, pos, n, inner_max=0)
     assert sum(len(o[2]) for o in unfused if o[0] == 'B') + sum(1 for o in unfused if o[0] == 'G') == len(gates)
+
+
+def test_to_qasm_round_trip():
+    """to_qasm writes (U, qubits) pairs as MATRIX gates with `#@ U` blocks and a qubits map (the reference's reader
+    accepts the text: checked once against hybridq.extras.io.qasm.from_qasm in the build container); from_qasm gives
+    the matrices and labels back exactly."""
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.qasm import from_qasm, to_qasm
+    g = [(U, tuple(10 * q + 3 for q in qs)) for U, qs in random_dense(6, 12, kmax=3, seed=1)]
+    back = from_qasm(to_qasm(g))
+    assert len(back) == len(g)
+    for (U, qs), (V, ps) in zip(g, back):
+        assert tuple(qs) == tuple(ps) and np.array_equal(np.asarray(U, dtype=np.complex128), V)
+    with pytest.raises(ValueError):
+        to_qasm([(np.eye(2), (0, 1))])
