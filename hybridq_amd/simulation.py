@@ -221,27 +221,34 @@ def alloc_planes(n, torch_dtype, device, vmm=True):
 CHUNKED_RETURN_MIN_BYTES = 256 << 20
 
 
-def _to_host(dev_tensor):
-    """Device tensor -> numpy array (a fresh, ordinary host array)."""
+def _to_host(dev_tensor, out=None):
+    """Device tensor -> numpy array (a fresh, ordinary host array, or `out`: a contiguous array of the same size)."""
     torch = _torch()
     flat = dev_tensor.reshape(-1)
     nbytes = flat.numel() * flat.element_size()
     chunk = (128 << 20) // flat.element_size()
-    if nbytes < CHUNKED_RETURN_MIN_BYTES or flat.numel() % chunk:
-        return dev_tensor.cpu().numpy()
+    plain = nbytes < CHUNKED_RETURN_MIN_BYTES or flat.numel() % chunk
+    stage = None
+    if not plain:
+        try:
+            stage = [torch.empty(chunk, dtype=flat.dtype, pin_memory=True) for _ in range(8)]
+        except RuntimeError:  # no page-locked memory to be had: the ordinary copy
+            plain = True
+    if plain:
+        host = dev_tensor.cpu().numpy()
+        if out is None:
+            return host
+        out.reshape(-1)[:] = host.reshape(-1)
+        return out
     from concurrent.futures import ThreadPoolExecutor
-    depth = 8
-    try:
-        stage = [torch.empty(chunk, dtype=flat.dtype, pin_memory=True) for _ in range(depth)]
-    except RuntimeError:  # no page-locked memory to be had: the ordinary copy
-        return dev_tensor.cpu().numpy()
-    out = np.empty(flat.numel(), dtype=stage[0].numpy().dtype)
+    depth = len(stage)
+    res = np.empty(flat.numel(), dtype=stage[0].numpy().dtype) if out is None else out.reshape(-1)
     done = [torch.cuda.Event() for _ in range(depth)]
     futures = [None] * depth
 
     def drain(c, s):
         done[s].synchronize()
-        out[c * chunk:(c + 1) * chunk] = stage[s].numpy()
+        res[c * chunk:(c + 1) * chunk] = stage[s].numpy()
 
     with ThreadPoolExecutor(4) as pool:
         for c in range(flat.numel() // chunk):
@@ -254,7 +261,49 @@ def _to_host(dev_tensor):
         for f in futures:
             if f is not None:
                 f.result()
-    return out.reshape(tuple(dev_tensor.shape))
+    return res.reshape(tuple(dev_tensor.shape)) if out is None else out
+
+
+def _from_host(host, dev_tensor):
+    """Contiguous numpy array -> (contiguous, 1-D) device tensor of the same size and dtype: the mirror of _to_host
+    (threads fill pinned staging buffers, the copies to the device run asynchronously behind them)."""
+    torch = _torch()
+    flat = dev_tensor.reshape(-1)
+    src = np.ascontiguousarray(host).reshape(-1)
+    chunk = (128 << 20) // flat.element_size()
+    stage = None
+    if flat.numel() * flat.element_size() >= CHUNKED_RETURN_MIN_BYTES and flat.numel() % chunk == 0 and flat.is_contiguous():
+        try:
+            stage = [torch.empty(chunk, dtype=flat.dtype, pin_memory=True) for _ in range(8)]
+        except RuntimeError:
+            stage = None
+    if stage is None:
+        dev_tensor.copy_(torch.from_numpy(src).reshape(dev_tensor.shape))
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    depth = len(stage)
+    sent = [torch.cuda.Event() for _ in range(depth)]
+    used = [False] * depth
+    nch = flat.numel() // chunk
+
+    def fill(c, s):
+        stage[s].numpy()[:] = src[c * chunk:(c + 1) * chunk]
+
+    with ThreadPoolExecutor(4) as pool:
+        pending = {}
+        for c in range(min(depth, nch)):
+            pending[c] = pool.submit(fill, c, c % depth)
+        for c in range(nch):
+            s = c % depth
+            pending.pop(c).result()
+            flat[c * chunk:(c + 1) * chunk].copy_(stage[s], non_blocking=True)
+            sent[s].record()
+            used[s] = True
+            nxt = c + depth
+            if nxt < nch:
+                sent[s].synchronize()  # the staging buffer has left for the device
+                pending[nxt] = pool.submit(fill, nxt, s)
+    torch.cuda.current_stream().synchronize()
 
 
 def prepare_state_planes(initial_state, n, float_type, device, placement='tuned'):
@@ -352,12 +401,15 @@ class EvolutionState:
                 self.planes.copy_(new_psi.reshape(2, -1))
             return
         core.sync()
-        host = self.planes.cpu().numpy().reshape((2,) + (2,) * self.n)
-        new_psi, new_order = gate.apply(psi=host, order=order)
+        host = np.empty((2, 1 << self.n), dtype=self.float_type)
+        for p in (0, 1):  # chunked, threaded copies for large states (see _to_host)
+            _to_host(self.planes[p], out=host[p])
+        new_psi, new_order = gate.apply(psi=host.reshape((2,) + (2,) * self.n), order=order)
         if any(x != y for x, y in zip(order, new_order)):  # :552-554
             raise RuntimeError("'order' has changed.")
         new_psi = np.ascontiguousarray(new_psi, dtype=self.float_type).reshape(2, -1)
-        self.planes.copy_(torch.from_numpy(new_psi))
+        for p in (0, 1):
+            _from_host(new_psi[p], self.planes[p])
 
     def compile(self, circuit, compress=4, blocked=False):
         """Record `circuit` (matrix gates only) against THIS state's planes into a

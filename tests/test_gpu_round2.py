@@ -431,3 +431,29 @@ def test_large_state_comes_back_through_the_chunked_copy(torch_cuda):
     assert np.array_equal(psi.reshape(-1), ref)
     x = torch.randn(1 << 25, dtype=torch.complex128, device='cuda')
     assert np.array_equal(_to_host(x), x.cpu().numpy())
+
+
+def test_host_functional_gate_on_a_large_state(torch_cuda):
+    """A reference-style (host numpy) FunctionalGate on a state large enough for the chunked, threaded D2H / H2D
+    copies: same result as the equivalent matrix gate."""
+    from hybridq_amd.circuits import haar_unitary, rqc_1q2q
+    from hybridq_amd.simulation import FunctionalGate, simulate
+    n = 26
+    rng = np.random.default_rng(9)
+    U = haar_unitary(2, rng).astype(np.complex64)
+    q = 7
+
+    def apply(psi, order):  # psi: (2,) + (2,)*n real array (re, im); gate on qubit q, in place
+        ax = order.index(q) + 1
+        re, im = np.moveaxis(psi[0], ax - 1, 0), np.moveaxis(psi[1], ax - 1, 0)
+        r0, r1, i0, i1 = re[0].copy(), re[1].copy(), im[0].copy(), im[1].copy()
+        for row, (a, b) in enumerate(U):
+            re[row] = a.real * r0 - a.imag * i0 + b.real * r1 - b.imag * i1
+            im[row] = a.real * i0 + a.imag * r0 + b.real * i1 + b.imag * r1
+        return psi, order
+    pre = rqc_1q2q(n, depth=3, seed=4)
+    circ_f = pre + [FunctionalGate([q], apply)] + pre[:20]
+    circ_m = pre + [(U, (q,))] + pre[:20]
+    a = simulate(circ_f, initial_state='0' * n, qubits=list(range(n)), compress=0)
+    b = simulate(circ_m, initial_state='0' * n, qubits=list(range(n)), compress=0)
+    assert np.abs(a - b).max() / np.abs(b).max() < 2 * BAR[np.dtype('complex64')]
