@@ -341,6 +341,17 @@ def prepare_state_planes(initial_state, n, float_type, device, placement='tuned'
     psi = np.asarray(initial_state).reshape(-1)
     if psi.size != 1 << n:
         raise ValueError("'initial_state' has the wrong size.")
+    ctype = np.dtype('complex64') if np.dtype(float_type) == np.dtype('float32') else np.dtype('complex128')
+    if psi.size * ctype.itemsize >= CHUNKED_RETURN_MIN_BYTES:
+        # large arrays: one chunked upload of the complex amplitudes, split into the planes on the device (the host
+        # would spend longer extracting .real / .imag than the whole transfer takes)
+        dev = torch.empty(psi.size, dtype=torch.complex64 if ctype == np.dtype('complex64') else torch.complex128,
+                          device=planes.device)
+        _from_host(np.ascontiguousarray(psi, dtype=ctype), dev)
+        planes[0].copy_(dev.real)
+        planes[1].copy_(dev.imag)
+        del dev
+        return planes
     planes[0].copy_(torch.from_numpy(np.array(psi.real, dtype=float_type, order='C')))
     planes[1].copy_(torch.from_numpy(np.array(psi.imag, dtype=float_type, order='C')))
     return planes

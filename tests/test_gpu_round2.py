@@ -457,3 +457,23 @@ def test_host_functional_gate_on_a_large_state(torch_cuda):
     a = simulate(circ_f, initial_state='0' * n, qubits=list(range(n)), compress=0)
     b = simulate(circ_m, initial_state='0' * n, qubits=list(range(n)), compress=0)
     assert np.abs(a - b).max() / np.abs(b).max() < 2 * BAR[np.dtype('complex64')]
+
+
+def test_large_array_initial_state(torch_cuda):
+    """initial_state given as a 2^n array above the chunked-copy threshold (uploaded as complex, split on the device):
+    the state comes back unchanged through an empty circuit's worth of identity, and a circuit on it equals the same
+    circuit started from the equivalent string."""
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    n = 25
+    rng = np.random.default_rng(6)
+    psi0 = (rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)).astype(np.complex64)
+    psi0 /= np.linalg.norm(psi0)
+    ident = [(np.eye(2, dtype=np.complex64), (q,)) for q in range(n)]
+    out = simulate(ident, initial_state=psi0, qubits=list(range(n)), compress=0, simplify=False, remove_id_gates=False)
+    assert np.array_equal(out.reshape(-1), psi0)
+    g = rqc_1q2q(n, depth=3, seed=8)
+    plus = np.full(1 << n, 2.0 ** (-n / 2), dtype=np.complex64)
+    a = simulate(g, initial_state=plus, qubits=list(range(n)))
+    b = simulate(g, initial_state='+' * n, qubits=list(range(n)))
+    assert np.abs(a - b).max() / np.abs(b).max() < 2 * BAR[np.dtype('complex64')]
