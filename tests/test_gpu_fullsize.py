@@ -219,3 +219,38 @@ def test_n34_on_one_gpu_tuned_placement(torch_cuda, n):
     assert abs(core.norm2(planes[0], planes[1]) - 1.0) < 1e-5
     pr = core.probabilities(planes[0], planes[1], [3, 17, n - 2, n - 1], n)
     assert np.abs(pr - 1 / 16).max() < 1e-6
+
+
+def test_blocked_kernel_beyond_32_bit_indices(torch_cuda):
+    """The cache-blocked kernel (register prefetch, incremental 64-bit tile base, table-driven gates) on a 2^33
+    state with tile bits up to position 32: the same planes as the gates applied one by one."""
+    torch = torch_cuda
+    from hybridq_amd import core
+    from hybridq_amd.circuits import haar_unitary
+    free, _ = torch.cuda.mem_get_info()
+    n = 33
+    if free < 2.2 * 8 * (1 << n):
+        pytest.skip('needs two 64 GiB states')
+    core.use_torch_stream()
+    rng = np.random.default_rng(33)
+    a = torch.empty((2, 1 << n), dtype=torch.float32, device='cuda')
+    core.init_state(a[0], a[1], 'plus')
+    for pos in ([0], [n - 1], [5, n - 2], [1, 17]):
+        core.apply_U(a[0], a[1], haar_unitary(1 << len(pos), rng).astype('complex64'), pos, n)
+    b = a.clone()
+    tile = np.array([0, 1, 2, 3, 4, 9, 14, 20, 25, 29, 30, 31, 32], dtype=np.uint32)
+    gates = []
+    for _ in range(7):
+        k = int(rng.integers(1, 5))
+        gates.append((haar_unitary(1 << k, rng).astype('complex64'), [int(p) for p in rng.permutation(tile)[:k]]))
+    core.apply_blocked(a[0], a[1], tile, gates, n_qubits=n)
+    assert core.last_kernel() == 'blocked'
+    for U, pos in gates:
+        core.apply_U(b[0], b[1], U, pos, n)
+    core.sync()
+    worst, chunk = 0.0, 1 << 28
+    for p in (0, 1):
+        for c in range(0, 1 << n, chunk):
+            worst = max(worst, float((a[p, c:c + chunk] - b[p, c:c + chunk]).abs().max()))
+    scale = float(b[:, :1 << 26].abs().max())
+    assert worst / scale < 2e-6, worst / scale
