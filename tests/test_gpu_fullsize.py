@@ -254,3 +254,41 @@ def test_blocked_kernel_beyond_32_bit_indices(torch_cuda):
             worst = max(worst, float((a[p, c:c + chunk] - b[p, c:c + chunk]).abs().max()))
     scale = float(b[:, :1 << 26].abs().max())
     assert worst / scale < 2e-6, worst / scale
+
+
+def test_gemm_and_swap_prefetch_loops_beyond_32_bit_indices(torch_cuda):
+    """k = 7 (apply_gemm_kernel with the register prefetch and the incremental 64-bit tile base) and the s = 13 / 15
+    swaps (prefetching LDS-tile loops) on 2^33 elements: U^dagger undoes U, a swap followed by its inverse restores
+    the plane -- checked on samples that include the top of the address range."""
+    torch = torch_cuda
+    from hybridq_amd import core
+    from hybridq_amd.circuits import haar_unitary
+    free, _ = torch.cuda.mem_get_info()
+    n = 33
+    if free < 1.2 * 8 * (1 << n):
+        pytest.skip('needs a 64 GiB state')
+    core.use_torch_stream()
+    rng = np.random.default_rng(34)
+    a = torch.empty((2, 1 << n), dtype=torch.float32, device='cuda')
+    core.init_state(a[0], a[1], 'plus')
+    for pos in ([0], [n - 1], [6, n - 2], [2, 19], [11]):
+        core.apply_U(a[0], a[1], haar_unitary(1 << len(pos), rng).astype('complex64'), pos, n)
+    idx = torch.cat([torch.from_numpy(rng.integers(0, 1 << n, 1 << 16)), torch.arange((1 << n) - 4096, 1 << n)]).cuda()
+    before = a[:, idx].clone()
+    pos = [1, 6, 12, 18, 24, 30, 32]
+    U = haar_unitary(128, rng).astype('complex64')
+    core.apply_U(a[0], a[1], U, pos, n)
+    assert core.last_kernel() == 'gemm'
+    mid = a[:, idx].clone()
+    core.apply_U(a[0], a[1], np.ascontiguousarray(U.conj().T), pos, n)
+    core.sync()
+    scale = float(before.abs().max())
+    assert float((mid - before).abs().max()) / scale > 1e-3  # the gate did something
+    assert float((a[:, idx] - before).abs().max()) / scale < 4e-6
+    for s in (13, 15):
+        perm = rng.permutation(s)
+        inv = np.argsort(perm)
+        core.swap(a[0], perm, n)
+        core.swap(a[0], inv, n)
+        core.sync()
+        assert float((a[0, idx] - before[0]).abs().max()) / scale < 4e-6, s
