@@ -101,9 +101,9 @@ PLANE_PAD_BYTES = 12288
 #: winner of 4-6 draws: 2.68-2.76 ms per gate against 3.04 ms (6.2-6.4 vs 5.6 TB/s).
 #: HQ_STATE_ALLOC=torch switches the mechanism off, HQ_STATE_TRIES sets the number of draws.
 VMM_MIN_BYTES = 1 << 28
-#: a draw that streams at least this fast (TB/s in the probe) ends the search early; slower ones are
-#: what torch / hipMalloc memory gives anyway, so the search goes on to its draw limit
-GOOD_DRAW_TBPS = 5.9
+#: a draw that streams at least this fast (TB/s in the probe) ends the search early (the fast family measures
+#: 6.3-6.4; a 6.1 draw used to end it and cost the 20-step bench run 4 %); slower ones keep the search going to its limit
+GOOD_DRAW_TBPS = 6.25
 #: what the last tuned allocation found (bench.py reports it)
 last_placement = {}
 
