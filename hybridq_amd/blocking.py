@@ -29,7 +29,7 @@ from .fusion import fuse
 INNER_COST = {1: 1.0, 2: 1.0, 3: 1.0, 4: 1.9}
 
 
-#: LDS next to a 64 KiB tile with two workgroups per CU (hq_hip.hip: a_budget), and what a gate needs of it:
+#: LDS next to a 64 KiB tile with two workgroups per CU (hq_apply.hip: a_budget), and what a gate needs of it:
 #: its MFMA A-operand table (k = 2, 3: 256 elements, k = 4: 1024; k = 1 runs on the VALU from scalar registers)
 #: plus 136 32-bit words of slot-address tables
 LDS_TABLE_BUDGET = 15 * 1024

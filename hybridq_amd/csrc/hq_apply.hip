@@ -1,0 +1,942 @@
+// hq_apply.hip -- apply_U_float32/64 (the reference boundary of /root/reference/include/python_U.cpp:33-112, 131-143:
+// k dispatch and kernel selection) and hq_apply_blocked_* (many gates per HBM pass).
+#include "hq_common.h"
+#include "hq_kernels_apply.h"
+
+namespace hq {
+
+// ---------------------------------------------------------------------------------
+// apply_U dispatch (device pointers)
+// ---------------------------------------------------------------------------------
+template <typename T, int K, int VMASK>
+static int launch_direct_kv(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n) {
+  constexpr int VB = Vec<T>::VB;
+  constexpr int KV = popc_c(VMASK), KR = K - KV, R = 1 << KR, D = 1 << K;
+  constexpr int ILP = R >= 4 ? 1 : (R == 2 ? 2 : 4);
+  // sort positions ascending, remember which original matrix bit each one is
+  unsigned order[K];
+  for (int j = 0; j < K; ++j) order[j] = j;
+  std::sort(order, order + K, [&](unsigned a, unsigned b) { return pos[a] < pos[b]; });
+  GateArg<T, K> g;
+  for (int t = 0; t < D; ++t) {
+    int to = 0;
+    for (int j = 0; j < K; ++j) to |= ((t >> j) & 1) << order[j];
+    for (int s = 0; s < D; ++s) {
+      int so = 0;
+      for (int j = 0; j < K; ++j) so |= ((s >> j) & 1) << order[j];
+      g.re[t * D + s] = U[2 * (to * D + so)];
+      g.im[t * D + s] = U[2 * (to * D + so) + 1];
+    }
+  }
+  RegPos rp = {{0, 0, 0, 0}};
+  for (int j = 0; j < KR; ++j) rp.p[j] = pos[order[KV + j]] - VB;
+  const uint64_t nslots = 1ull << (n - VB - KR);
+  const uint64_t nblocks = nslots / (ILP * kBlock);
+  if (nblocks == 0 || nblocks > 0x7fffffffull) return fail("direct: grid out of range");
+  // Non-temporal loads/stores: +7..10 % when every wave-level access is a contiguous run of
+  // >= 512 B (all register targets at positions >= 7: measured 5.9 vs 5.5 TB/s at n=30),
+  // but they bypass the cache-line merging that low targets rely on (pos 2: 2.7 vs 5.3
+  // TB/s), so they are used only for high targets unless forced.
+  bool nt = c.nontemporal > 0;
+  if (c.nontemporal < 0) {
+    nt = true;
+    for (int j = 0; j < KR; ++j) nt = nt && (rp.p[j] + VB >= 7);
+  }
+  if (nt)
+    HQ_LAUNCH(c, (apply_direct_kernel<T, K, VMASK, ILP, true>), dim3((unsigned)nblocks), dim3(kBlock), 0, re, im, g, rp);
+  else
+    HQ_LAUNCH(c, (apply_direct_kernel<T, K, VMASK, ILP, false>), dim3((unsigned)nblocks), dim3(kBlock), 0, re, im, g, rp);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "direct";
+  c.last_desc = std::string("apply_direct_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(K) + ", " + std::to_string(VMASK) + ", " + std::to_string(ILP) + ", " +
+                (nt ? "true" : "false") + ">";
+  return 0;
+}
+
+template <typename T, int K>
+static int launch_direct_k(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                           int vmask) {
+  constexpr int VB = Vec<T>::VB;
+  switch (vmask) {
+    case 0: return launch_direct_kv<T, K, 0>(c, re, im, U, pos, n);
+    case 1: return launch_direct_kv<T, K, 1>(c, re, im, U, pos, n);
+    case 2:
+      if constexpr (VB >= 2) return launch_direct_kv<T, K, 2>(c, re, im, U, pos, n);
+      break;
+    case 3:
+      if constexpr (VB >= 2 && K >= 2) return launch_direct_kv<T, K, 3>(c, re, im, U, pos, n);
+      break;
+  }
+  return fail("direct: bad vmask");
+}
+
+// can the direct kernel run this call?
+template <typename T>
+static bool direct_ok(unsigned n, unsigned k, const unsigned* pos) {
+  constexpr int VB = Vec<T>::VB;
+  if (k < 1 || k > 3) return false;
+  unsigned kv = 0;
+  for (unsigned j = 0; j < k; ++j) kv += pos[j] < (unsigned)VB;
+  const unsigned kr = k - kv;
+  const unsigned R = 1u << kr;
+  const unsigned ilp = R >= 4 ? 1 : (R == 2 ? 2 : 4);
+  if (n < VB + kr) return false;
+  const uint64_t nslots = 1ull << (n - VB - kr);
+  return nslots >= (uint64_t)ilp * kBlock;
+}
+
+template <typename T>
+static int launch_direct(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                         unsigned k) {
+  constexpr int VB = Vec<T>::VB;
+  int vmask = 0;
+  for (unsigned j = 0; j < k; ++j)
+    if (pos[j] < (unsigned)VB) vmask |= 1 << pos[j];
+  switch (k) {
+    case 1: return launch_direct_k<T, 1>(c, re, im, U, pos, n, vmask);
+    case 2: return launch_direct_k<T, 2>(c, re, im, U, pos, n, vmask);
+    case 3: return launch_direct_k<T, 3>(c, re, im, U, pos, n, vmask);
+  }
+  return fail("direct: k out of range");
+}
+
+// U (interleaved, original bit order) -> planar re[D*D], im[D*D] with the matrix index
+// bits re-ordered to ASCENDING target position; `sorted` receives the positions.
+template <typename T>
+static void sort_gate(const T* U, const unsigned* pos, unsigned k, std::vector<T>& out,
+                      unsigned* sorted) {
+  const unsigned D = 1u << k;
+  unsigned order[kMaxK];
+  for (unsigned j = 0; j < k; ++j) order[j] = j;
+  std::sort(order, order + k, [&](unsigned a, unsigned b) { return pos[a] < pos[b]; });
+  for (unsigned j = 0; j < k; ++j) sorted[j] = pos[order[j]];
+  out.resize((size_t)2 * D * D);
+  for (unsigned t = 0; t < D; ++t) {
+    unsigned to = 0;
+    for (unsigned j = 0; j < k; ++j) to |= ((t >> j) & 1u) << order[j];
+    for (unsigned s = 0; s < D; ++s) {
+      unsigned so = 0;
+      for (unsigned j = 0; j < k; ++j) so |= ((s >> j) & 1u) << order[j];
+      out[(size_t)t * D + s] = U[2 * ((size_t)to * D + so)];
+      out[(size_t)D * D + (size_t)t * D + s] = U[2 * ((size_t)to * D + so) + 1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// matrix-core path (f32, k <= 4): role assignment + A-operand table (see hq_kernels.h)
+// ---------------------------------------------------------------------------------
+template <typename T>
+struct MfmaPlan {
+  int kbits = 0, vmask = 0, ilp = 1;
+  bool nt = false;
+  unsigned n_addr = 0;
+  MfmaRoles ro;
+  std::vector<T> A;
+};
+
+template <typename T>
+static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigned n, unsigned k,
+                      MfmaPlan<T>& P, bool for_tile = false) {
+  constexpr unsigned CB = Vec<T>::VB;  // vector-component index bits: 2 (f32) / 1 (f64)
+  if (k < 1 || k > (for_tile ? 4u : 6u)) return false;
+  std::vector<T> Us;
+  unsigned sp[kMaxK];
+  sort_gate<T>(U, pos, k, Us, sp);
+  const unsigned D = 1u << k;
+  const T* Ur = Us.data();
+  const T* Ui = Us.data() + (size_t)D * D;
+  const unsigned k_eff = k <= 3 ? 3 : k;
+  P.kbits = (int)k_eff + 1;
+  // effective digits: real targets (tbit = sorted target index) + identity dummies (tbit = -1)
+  struct Digit { unsigned pos; int tbit; };
+  std::vector<Digit> E;
+  uint64_t used = 0;
+  for (unsigned j = 0; j < k; ++j) { E.push_back({sp[j], (int)j}); used |= 1ull << sp[j]; }
+  // Where the identity dummies of a k < 3 gate go (measured at n = 30, tools/sweep_dummy.py):
+  // in free index bits >= 6.  They become register digits whose 16-byte accesses are >= 256 B
+  // apart (non-temporal policy applies) while the real low targets keep the q-digit role (a
+  // permutation of one contiguous run).  Never slower than the two earlier placements
+  // ("comp": free vector components, "low": lowest free bits >= 2) and 8 % faster for single
+  // targets on bits 2-5.  Small states fall through to "low", then to the components.
+  int dummy_low = c.dummy_policy;
+  if (dummy_low < 0) dummy_low = for_tile ? ((sp[0] < CB || (k == 1 && sp[0] >= 5)) ? 1 : 0) : 2;  // LDS tiles: earlier rule (sweep_blocked)
+  if (dummy_low == 2)
+    for (unsigned p = 6; p < n && E.size() < k_eff; ++p)
+      if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
+  for (unsigned p = dummy_low >= 1 ? CB : 0; p < n && E.size() < k_eff; ++p)
+    if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
+  for (unsigned p = 0; p < CB && E.size() < k_eff; ++p)  // tiny n: fall back to the components
+    if (!((used >> p) & 1)) { E.push_back({p, -1}); used |= 1ull << p; }
+  if (E.size() < k_eff) return false;
+  std::sort(E.begin(), E.end(), [](const Digit& a, const Digit& b) { return a.pos < b.pos; });
+  int vmask = 0;
+  std::vector<int> comp_digit, addr_digit;  // indices into E
+  for (unsigned e = 0; e < k_eff; ++e) {
+    if (E[e].pos < CB) { vmask |= 1 << E[e].pos; comp_digit.push_back((int)e); }
+    else addr_digit.push_back((int)e);
+  }
+  P.vmask = vmask;
+  const int KV = (int)comp_digit.size(), NS = P.kbits - 2, NR = NS - KV, NL = 1 << NR;
+  const unsigned na = (unsigned)addr_digit.size();
+  if (na < 1 || na > 6) return false;
+  P.n_addr = na;
+  P.ilp = std::max(1, 8 / NL);
+  if (NR < 0 || n < CB + na) return false;
+  const uint64_t nslots = 1ull << (n - CB - na);
+  // tile mode and the k >= 5 kernel (grid-stride over wave iterations): one wave iteration
+  if (nslots < ((for_tile || k_eff >= 5) ? 16u : (uint64_t)P.ilp * 64)) return false;
+  // roles: -1 = plane, otherwise index into E.  q gets the low address digits first
+  // (positions 2..5: a permutation of a contiguous run), then the plane, then the rest.
+  constexpr int PLANE = -1;
+  std::vector<int> order;
+  for (int e : addr_digit) if (E[e].pos - CB <= 3) order.push_back(e);
+  order.push_back(PLANE);
+  for (int e : addr_digit) if (E[e].pos - CB > 3) order.push_back(e);
+  const int qd[2] = {order[0], order[1]};
+  std::vector<int> rd(order.begin() + 2, order.end());  // NR reg digits
+  if ((int)rd.size() != NR) return false;
+  MfmaRoles& ro = P.ro;
+  for (int m = 0; m < 6; ++m) ro.pos[m] = 63;
+  for (unsigned m = 0; m < na; ++m) ro.pos[m] = E[addr_digit[m]].pos - CB;
+  ro.q_plane = -1;
+  ro.r_plane = -1;
+  for (int b = 0; b < 2; ++b) {
+    ro.q_off[b] = qd[b] == PLANE ? 0u : (1u << (E[qd[b]].pos - CB));
+    if (qd[b] == PLANE) ro.q_plane = b;
+  }
+  for (int b = 0; b < 5; ++b) ro.r_off[b] = 0;
+  bool nt = true;
+  for (int b = 0; b < NR; ++b) {
+    if (rd[b] == PLANE) { ro.r_plane = b; continue; }
+    if (E[rd[b]].pos - CB > 31) return false;  // offsets are 32-bit vec indices
+    ro.r_off[b] = 1u << (E[rd[b]].pos - CB);
+    nt = nt && E[rd[b]].pos >= 6;
+  }
+  for (int b = 0; b < 2; ++b)
+    if (qd[b] != PLANE && E[qd[b]].pos - CB > 31) return false;
+  P.nt = c.nontemporal < 0 ? nt : c.nontemporal > 0;
+  // decode a K index (q, step) into (plane, effective amplitude index over E)
+  auto decode = [&](unsigned q, unsigned st, unsigned& plane, unsigned& teff) {
+    plane = 0;
+    teff = 0;
+    for (int b = 0; b < 2; ++b) {
+      const unsigned bit = (q >> b) & 1u;
+      if (qd[b] == PLANE) plane = bit; else teff |= bit << qd[b];
+    }
+    for (int cix = 0; cix < KV; ++cix) teff |= ((st >> cix) & 1u) << comp_digit[cix];
+    for (int b = 0; b < NR; ++b) {
+      const unsigned bit = (st >> (KV + b)) & 1u;
+      if (rd[b] == PLANE) plane = bit; else teff |= bit << rd[b];
+    }
+  };
+  auto split = [&](unsigned teff, unsigned& treal, unsigned& tdummy) {
+    treal = 0;
+    tdummy = 0;
+    for (unsigned e = 0; e < k_eff; ++e) {
+      const unsigned bit = (teff >> e) & 1u;
+      if (E[e].tbit >= 0) treal |= bit << E[e].tbit; else tdummy |= bit << e;
+    }
+  };
+  const int NSTEP = 1 << NS, NRB = 1 << (NS - 2);
+  P.A.assign((size_t)NRB * NSTEP * 64, (T)0);
+  for (int rb = 0; rb < NRB; ++rb)
+    for (int st = 0; st < NSTEP; ++st)
+      for (unsigned lane = 0; lane < 64; ++lane) {
+        const unsigned i = lane & 15, q_in = lane >> 4;
+        unsigned po, to, pi, ti, tor, tod, tir, tid;
+        // D row of lane (q', j) register r: 4q'+r for the f32 MFMA, q'+4r for the f64 one
+        const unsigned q_out = sizeof(T) == 4 ? (i >> 2) : (i & 3), r_out = sizeof(T) == 4 ? (i & 3) : (i >> 2);
+        decode(q_out, r_out | ((unsigned)rb << 2), po, to);
+        decode(q_in, (unsigned)st, pi, ti);
+        split(to, tor, tod);
+        split(ti, tir, tid);
+        T val = 0;
+        if (tod == tid) {
+          const T ur = Ur[tor * D + tir], ui = Ui[tor * D + tir];
+          val = po == pi ? ur : (po == 0 ? -ui : ui);
+        }
+        if (k_eff >= 5) {  // apply_mfma_big_kernel: G consecutive steps per 16-byte LDS read
+          constexpr int G = 16 / (int)sizeof(T);
+          P.A[((((size_t)rb * (NSTEP / G) + st / G) * 64 + lane) * G) + st % G] = val;
+        } else {
+          P.A[((size_t)rb * NSTEP + st) * 64 + lane] = val;
+        }
+      }
+  return true;
+}
+
+template <typename T, int KBITS, int VMASK>
+static void launch_mfma_kv(Context& c, T* re, T* im, const T* dA, const MfmaPlan<T>& P, unsigned nblocks) {
+  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NL = 1 << (NS - KV);
+  constexpr int ILP = NL >= 8 ? 1 : 8 / NL;
+  const MfmaRoles ro = P.ro;  // captured by value when the launch is recorded
+  if (P.nt)
+    HQ_LAUNCH(c, (apply_mfma_kernel<T, KBITS, VMASK, ILP, true>), dim3(nblocks), dim3(kBlock), 0, re, im, dA, ro);
+  else
+    HQ_LAUNCH(c, (apply_mfma_kernel<T, KBITS, VMASK, ILP, false>), dim3(nblocks), dim3(kBlock), 0, re, im, dA, ro);
+}
+
+// k = 5, 6 role kernel, 512-thread workgroups; PHASED = the two halves of a workgroup alternate between their
+// MFMA phase and their memory phase (see the kernel).  HQ_BIG_PHASED=0/1 forces one variant (experiments).
+template <typename T, int KBITS, int VMASK, bool PHASED>
+static int launch_mfma_big_var(Context& c, T* re, T* im, const T* dA, const MfmaPlan<T>& P, unsigned n,
+                               const BigOffsets& tab) {
+  constexpr unsigned CB = Vec<T>::VB;
+  constexpr int BLOCK = 512;
+  constexpr int NS = KBITS - 2, NRB = 1 << (NS - 2), NSTEP = 1 << NS;
+  constexpr size_t lds = (size_t)NRB * NSTEP * 64 * sizeof(T);
+  static bool attr_done = false;  // under the context mutex
+  if (!attr_done) {
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_mfma_big_kernel<T, KBITS, VMASK, true, BLOCK, PHASED>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_mfma_big_kernel<T, KBITS, VMASK, false, BLOCK, PHASED>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const uint64_t niter = (1ull << (n - CB - P.n_addr)) >> 4;  // 16 slots per wave iteration
+  const uint64_t wgs = (niter + BLOCK / 64 - 1) / (BLOCK / 64);
+  static const int grid_cap = getenv("HQ_BIG_GRID") ? atoi(getenv("HQ_BIG_GRID")) : 2048;
+  const unsigned grid = (unsigned)std::min<uint64_t>(wgs, (uint64_t)grid_cap);
+  const MfmaRoles ro = P.ro;
+  if (P.nt)
+    HQ_LAUNCH(c, (apply_mfma_big_kernel<T, KBITS, VMASK, true, BLOCK, PHASED>), dim3(grid), dim3(BLOCK), lds, re, im, dA, ro, tab, niter);
+  else
+    HQ_LAUNCH(c, (apply_mfma_big_kernel<T, KBITS, VMASK, false, BLOCK, PHASED>), dim3(grid), dim3(BLOCK), lds, re, im, dA, ro, tab, niter);
+  return 0;
+}
+
+// measured at n = 30 / 29 (gpurun_out/r2e, r2f: means over 6 position patterns, phased vs free-running):
+//   k = 5 f32 3.42 vs 3.61 ms, f64 3.40 vs 3.51;  k = 6 f32 4.65 vs 4.72;  k = 6 f64 5.35 vs 4.81 (the f64
+//   k = 6 instantiation needs 218 of 256 registers and spills ~100 B/lane inside the MFMA phase: with the
+//   partner wave parked at the barrier nothing covers the reloads)
+static bool big_phased(int kbits, bool is_double) {
+  static const int forced = getenv("HQ_BIG_PHASED") ? atoi(getenv("HQ_BIG_PHASED")) : -1;
+  return forced >= 0 ? forced != 0 : !(kbits >= 7 && is_double);
+}
+
+template <typename T, int KBITS, int VMASK>
+static int launch_mfma_big_kv(Context& c, T* re, T* im, const T* dA, const MfmaPlan<T>& P, unsigned n) {
+  // byte offset of every register-digit load from the lane's base address (BigOffsets)
+  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
+  BigOffsets tab;
+  memset(&tab, 0, sizeof(tab));
+  const int64_t plane_step = reinterpret_cast<const unsigned char*>(im) - reinterpret_cast<const unsigned char*>(re);
+  for (int ld = 0; ld < NL; ++ld) {
+    uint64_t o = 0;
+    bool pl = false;
+    for (int b = 0; b < NR; ++b)
+      if ((ld >> b) & 1) { o |= P.ro.r_off[b]; pl = pl || P.ro.r_plane == b; }
+    tab.off[ld] = (int64_t)(16 * o) + (pl ? plane_step : 0);
+  }
+  if (big_phased(KBITS, sizeof(T) == 8)) return launch_mfma_big_var<T, KBITS, VMASK, true>(c, re, im, dA, P, n, tab);
+  return launch_mfma_big_var<T, KBITS, VMASK, false>(c, re, im, dA, P, n, tab);
+}
+
+template <typename T>
+static int launch_mfma_big(Context& c, T* re, T* im, const T* A, const MfmaPlan<T>& P, unsigned n) {
+  constexpr unsigned CB = Vec<T>::VB;
+  int rc = -1;
+  switch (P.kbits * 4 + P.vmask) {
+    case 24: rc = launch_mfma_big_kv<T, 6, 0>(c, re, im, A, P, n); break;
+    case 25: rc = launch_mfma_big_kv<T, 6, 1>(c, re, im, A, P, n); break;
+    case 28: rc = launch_mfma_big_kv<T, 7, 0>(c, re, im, A, P, n); break;
+    case 29: rc = launch_mfma_big_kv<T, 7, 1>(c, re, im, A, P, n); break;
+    default:
+      if constexpr (CB == 2) {
+        switch (P.kbits * 4 + P.vmask) {
+          case 26: rc = launch_mfma_big_kv<T, 6, 2>(c, re, im, A, P, n); break;
+          case 27: rc = launch_mfma_big_kv<T, 6, 3>(c, re, im, A, P, n); break;
+          case 30: rc = launch_mfma_big_kv<T, 7, 2>(c, re, im, A, P, n); break;
+          case 31: rc = launch_mfma_big_kv<T, 7, 3>(c, re, im, A, P, n); break;
+          default: break;
+        }
+      }
+  }
+  if (rc < 0) return fail("mfma: bad plan");
+  if (rc) return rc;
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "mfma";
+  const bool phased = big_phased(P.kbits, sizeof(T) == 8);
+  c.last_desc = std::string("apply_mfma_big_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(P.kbits) + ", " + std::to_string(P.vmask) + ", " + (P.nt ? "true" : "false") + ", " +
+                (phased ? "512, true>" : "512, false>");
+  return 0;
+}
+
+template <typename T>
+static int launch_mfma(Context& c, T* re, T* im, const MfmaPlan<T>& P, unsigned n) {
+  constexpr unsigned CB = Vec<T>::VB;
+  void* dA = nullptr;
+  if (arena_upload(c, P.A.data(), P.A.size() * sizeof(T), &dA)) return 1;
+  if (P.kbits >= 6) return launch_mfma_big<T>(c, re, im, (const T*)dA, P, n);
+  const uint64_t nslots = 1ull << (n - CB - P.n_addr);
+  const uint64_t nblocks64 = nslots / ((uint64_t)P.ilp * 64);
+  if (nblocks64 == 0 || nblocks64 > 0x7fffffffull) return fail("mfma: grid out of range");
+  const unsigned nb = (unsigned)nblocks64;
+  const T* A = (const T*)dA;
+  bool ok = true;
+  switch (P.kbits * 4 + P.vmask) {
+    case 16: launch_mfma_kv<T, 4, 0>(c, re, im, A, P, nb); break;
+    case 17: launch_mfma_kv<T, 4, 1>(c, re, im, A, P, nb); break;
+    case 20: launch_mfma_kv<T, 5, 0>(c, re, im, A, P, nb); break;
+    case 21: launch_mfma_kv<T, 5, 1>(c, re, im, A, P, nb); break;
+    default:
+      if constexpr (CB == 2) {
+        switch (P.kbits * 4 + P.vmask) {
+          case 18: launch_mfma_kv<T, 4, 2>(c, re, im, A, P, nb); break;
+          case 19: launch_mfma_kv<T, 4, 3>(c, re, im, A, P, nb); break;
+          case 22: launch_mfma_kv<T, 5, 2>(c, re, im, A, P, nb); break;
+          case 23: launch_mfma_kv<T, 5, 3>(c, re, im, A, P, nb); break;
+          default: ok = false;
+        }
+      } else {
+        ok = false;
+      }
+  }
+  if (!ok) return fail("mfma: bad plan");
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "mfma";
+  c.last_desc = std::string("apply_mfma_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(P.kbits) + ", " + std::to_string(P.vmask) + ", " + std::to_string(P.ilp) + ", " +
+                (P.nt ? "true" : "false") + ">";
+  return 0;
+}
+
+template <typename T>
+static int launch_generic(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                          unsigned k) {
+  GenArg a;
+  memset(&a, 0, sizeof(a));
+  a.k = k;
+  a.c = std::min<unsigned>(n - k, kTileBits - k);
+  uint64_t tmask = 0;
+  for (unsigned j = 0; j < k; ++j) {
+    a.tpos[j] = pos[j];
+    tmask |= 1ull << pos[j];
+  }
+  unsigned nc = 0;
+  for (unsigned p = 0; p < n && nc < a.c; ++p)
+    if (!((tmask >> p) & 1)) a.cpos[nc++] = p;
+  std::vector<unsigned> all(a.tpos, a.tpos + k);
+  all.insert(all.end(), a.cpos, a.cpos + a.c);
+  std::sort(all.begin(), all.end());
+  for (unsigned j = 0; j < k + a.c; ++j) a.apos[j] = all[j];
+  a.vec_ok = (a.cpos[0] == 0 && a.cpos[1] == 1) ? 1u : 0u;
+  const size_t D = (size_t)1 << k, C = (size_t)1 << a.c;
+  void* dU = nullptr;
+  if (arena_upload(c, U, 2 * D * D * sizeof(T), &dU)) return 1;
+  const size_t lds = D * 8 + C * 4 + 2 * D * C * sizeof(T);
+  if (!c.attr_set) {
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_generic_kernel<float>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_generic_kernel<double>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    c.attr_set = true;
+  }
+  const uint64_t nblocks = 1ull << (n - k - a.c);
+  const unsigned grid = (unsigned)std::min<uint64_t>(nblocks, 256 * 16);
+  HQ_LAUNCH(c, (apply_generic_kernel<T>), dim3(grid), dim3(kBlock), lds, re, im, (const T*)dU, a, nblocks);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "generic";
+  c.last_desc = std::string("apply_generic_kernel<") + (sizeof(T) == 4 ? "float" : "double") + "> k=" + std::to_string(k);
+  return 0;
+}
+
+// k = 7..10: tile GEMM on the matrix cores (apply_gemm_kernel)
+// Tile bits of the GEMM kernel: 128 KiB of LDS (one workgroup per CU) for the largest k, where
+// the U traffic per tile matters; 32-64 KiB for k = 7, 8 (two to four workgroups per CU, whose
+// copy and MFMA phases overlap each other).  HQ_GEMM_TB overrides (experiments).
+template <typename T>
+static unsigned gemm_tile_bits(unsigned k) {
+  static const int forced = getenv("HQ_GEMM_TB") ? atoi(getenv("HQ_GEMM_TB")) : 0;
+  const unsigned big = sizeof(T) == 4 ? 14 : 13;
+  if (forced) return std::min<unsigned>(big, std::max<unsigned>((unsigned)forced, k + 4));
+  // measured at n = 30 / 29 (gpurun_out/sweep_gemm_tb.txt): 32 columns (f32) / 16 columns (f64)
+  return std::min<unsigned>(big, k + (sizeof(T) == 4 ? 5 : 4));
+}
+
+template <typename T>
+static bool gemm_ok(unsigned n, unsigned k, bool forced = false) {
+  const unsigned big = sizeof(T) == 4 ? 14 : 13;
+  const unsigned tb = gemm_tile_bits<T>(k);
+  if (k < (forced ? 6u : 7u) || k + 4 > big || n < tb) return false;  // k = 6 only on request ("gemm" mode)
+  return ((1u << k) >> 4) * ((1u << (tb - k)) >> 4) >= 8;              // one output block per wave at least
+}
+
+template <typename T, int RBW, int CBW>
+static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned* dOff, const GemmArg& a,
+                          uint64_t ntiles) {
+  const size_t lds = (size_t)2 * sizeof(T) << a.tb;
+  static bool attr_done = false;  // under the context mutex
+  if (!attr_done) {
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW, 0>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 2048);
+  // register prefetch of the next tile where the tile has the usual size of this wave shape and the registers allow
+  // (not the 8 x 1 shape of k = 10: 224 + 64 registers); HQ_GEMM_PREF=0 switches it off
+  constexpr int CBv = sizeof(T) == 4 ? 2 : 1;
+  constexpr int NPVx = sizeof(T) == 4 ? (CBW == 2 && RBW == 1 ? 2 : 0)  // f32: k = 7 only (2 x 2, k = 8: no gain, -3 % for some positions; 4 x 2 would spill)
+                                     : (CBW == 1 ? (RBW == 1 ? 2 : (RBW == 2 ? 4 : (RBW == 4 ? 8 : 0))) : 0);
+  static const int use_pref = getenv("HQ_GEMM_PREF") ? atoi(getenv("HQ_GEMM_PREF")) : 1;
+  if constexpr (NPVx > 0) {
+    if (use_pref && ((1u << (a.tb - CBv)) == (unsigned)NPVx * kGemmBlock)) {
+      static bool attr2 = false;
+      if (!attr2) {
+        HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW, NPVx>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr2 = true;
+      }
+      HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, NPVx>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+      return 0;
+    }
+  }
+  HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, 0>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+  return 0;
+}
+
+template <typename T>
+static int launch_gemm(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n, unsigned k) {
+  constexpr unsigned G = 16 / sizeof(T);
+  const unsigned tb = gemm_tile_bits<T>(k);
+  const unsigned D = 1u << k, cbits = tb - k;
+  std::vector<T> Us;
+  unsigned sp[kMaxK];
+  sort_gate<T>(U, pos, k, Us, sp);  // matrix index bit j <-> sp[j], ascending
+  const T* Ur = Us.data();
+  const T* Ui = Us.data() + (size_t)D * D;
+  GemmArg a;
+  memset(&a, 0, sizeof(a));
+  a.tb = tb;
+  a.k = k;
+  uint64_t tmask = 0;
+  for (unsigned j = 0; j < k; ++j) tmask |= 1ull << sp[j];
+  std::vector<unsigned> cpos;
+  for (unsigned p = 0; p < n && cpos.size() < cbits; ++p)
+    if (!((tmask >> p) & 1)) cpos.push_back(p);
+  std::vector<unsigned> all(sp, sp + k);
+  all.insert(all.end(), cpos.begin(), cpos.end());
+  std::sort(all.begin(), all.end());
+  for (unsigned m = 0; m < tb; ++m) a.apos[m] = all[m];
+  auto local = [&](unsigned gpos) { return (unsigned)(std::find(all.begin(), all.end(), gpos) - all.begin()); };
+  std::vector<unsigned> tl(k), cl(cbits);
+  for (unsigned j = 0; j < k; ++j) tl[j] = local(sp[j]);
+  for (unsigned j = 0; j < cbits; ++j) cl[j] = local(cpos[j]);
+  for (int i = 0; i < 4; ++i) { a.tl[i] = tl[i]; a.cl[i] = cl[i]; }
+  // swizzle: a half-wave's B read varies the element bits {tl[0], cl[0..3]}; ds_read_b32/b64
+  // bank = element index mod 32.  Fold those of them that are >= 5 into free bits of [2,5)
+  // (bits 0,1 stay: 16-byte vectors must remain contiguous for the copy phases).
+  {
+    const unsigned lb5[5] = {tl[0], cl[0], cl[1], cl[2], cl[3]};
+    std::vector<unsigned> high, freeb;
+    for (unsigned b : lb5) if (b >= 5) high.push_back(b);
+    for (unsigned b = 2; b < 5; ++b)
+      if (std::find(lb5, lb5 + 5, b) == lb5 + 5) freeb.push_back(b);
+    std::sort(high.begin(), high.end());
+    a.n_sw = (unsigned)std::min(high.size(), freeb.size());
+    for (unsigned i = 0; i < a.n_sw; ++i) { a.sw_src[i] = high[i]; a.sw_dst[i] = freeb[i]; }
+  }
+  auto swz = [&](unsigned e) {
+    for (unsigned i = 0; i < a.n_sw; ++i) e ^= ((e >> a.sw_src[i]) & 1u) << a.sw_dst[i];
+    return e;
+  };
+  auto dep = [](unsigned v, const std::vector<unsigned>& p) {
+    unsigned e = 0;
+    for (size_t i = 0; i < p.size(); ++i) e |= ((v >> i) & 1u) << p[i];
+    return e;
+  };
+  const unsigned D4 = D / 4, NRBT = D / 16, NCB = (1u << cbits) / 16;
+  std::vector<unsigned> offs(D4 + NRBT + NCB);
+  for (unsigned st = 0; st < D4; ++st) offs[st] = swz(dep(st << 2, tl));
+  for (unsigned rb = 0; rb < NRBT; ++rb) offs[D4 + rb] = swz(dep(rb << 4, tl));
+  for (unsigned cb = 0; cb < NCB; ++cb) offs[D4 + NRBT + cb] = swz(dep(cb << 4, cl));
+  // A-operand table: [row block][step group][Ur | Ui][lane][G]: lane (i = lane & 15, q = lane >> 4)
+  // holds M[16 rb + i][4 (G sg + s) + q]
+  a.nsg = D4 / G;
+  std::vector<T> A((size_t)2 * D * D);
+  for (unsigned rb = 0; rb < NRBT; ++rb)
+    for (unsigned sg = 0; sg < a.nsg; ++sg)
+      for (unsigned lane = 0; lane < 64; ++lane) {
+        const unsigned row = rb * 16 + (lane & 15);
+        for (unsigned s2 = 0; s2 < G; ++s2) {
+          const unsigned t = 4 * (sg * G + s2) + (lane >> 4);
+          const size_t o = ((((size_t)rb * a.nsg + sg) * 2) * 64 + lane) * G + s2;
+          A[o] = Ur[(size_t)row * D + t];
+          A[o + (size_t)64 * G] = Ui[(size_t)row * D + t];
+        }
+      }
+  void* dA = nullptr;
+  void* dO = nullptr;
+  if (arena_upload(c, A.data(), A.size() * sizeof(T), &dA)) return 1;
+  if (arena_upload(c, offs.data(), offs.size() * sizeof(unsigned), &dO)) return 1;
+  const uint64_t ntiles = 1ull << (n - tb);
+  // 64 (f32) / 32 (f64) output blocks per tile over 8 waves: wave = RBW x CBW blocks
+  const unsigned per_wave = (NRBT * NCB) / 8;
+  const unsigned cbw = std::min(std::min(NCB, 4u), std::max(per_wave, 1u)), rbw = per_wave / cbw;
+  int rc = -1;
+  const T* Ap = (const T*)dA;
+  const unsigned* Op = (const unsigned*)dO;
+  switch (rbw * 16 + cbw) {
+    case 1 * 16 + 1: rc = launch_gemm_rc<T, 1, 1>(c, re, im, Ap, Op, a, ntiles); break;
+    case 1 * 16 + 2: rc = launch_gemm_rc<T, 1, 2>(c, re, im, Ap, Op, a, ntiles); break;
+    case 2 * 16 + 1: rc = launch_gemm_rc<T, 2, 1>(c, re, im, Ap, Op, a, ntiles); break;
+    case 1 * 16 + 4: rc = launch_gemm_rc<T, 1, 4>(c, re, im, Ap, Op, a, ntiles); break;
+    case 2 * 16 + 4: rc = launch_gemm_rc<T, 2, 4>(c, re, im, Ap, Op, a, ntiles); break;
+    case 2 * 16 + 2: rc = launch_gemm_rc<T, 2, 2>(c, re, im, Ap, Op, a, ntiles); break;
+    case 4 * 16 + 2: rc = launch_gemm_rc<T, 4, 2>(c, re, im, Ap, Op, a, ntiles); break;
+    case 4 * 16 + 1: rc = launch_gemm_rc<T, 4, 1>(c, re, im, Ap, Op, a, ntiles); break;
+    case 8 * 16 + 1:  // k = 10 with 16 columns: float32 only (gemm_ok stops complex128 at k = 9; the f64 form would spill)
+      if constexpr (sizeof(T) == 4) rc = launch_gemm_rc<T, 8, 1>(c, re, im, Ap, Op, a, ntiles);
+      break;
+    default: break;
+  }
+  if (rc < 0) return fail("gemm: unsupported shape");
+  if (rc) return rc;
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "gemm";
+  c.last_desc = std::string("apply_gemm_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(rbw) + ", " + std::to_string(cbw) + "> k=" + std::to_string(k);
+  return 0;
+}
+
+// k = 5, 6: LDS-staged tile GEMM on the matrix cores (apply_mfma_tile_kernel)
+template <typename T>
+static bool mfma_tile_ok(unsigned n, unsigned k) {
+  const unsigned tile_bits = sizeof(T) == 4 ? 12 : 11;
+  return (k == 5 || k == 6) && n >= tile_bits;
+}
+
+template <typename T>
+static int launch_mfma_tile(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                            unsigned k) {
+  const unsigned tile_bits = sizeof(T) == 4 ? 12 : 11;
+  GenArg a;
+  memset(&a, 0, sizeof(a));
+  a.k = k;
+  a.c = tile_bits - k;
+  uint64_t tmask = 0;
+  for (unsigned j = 0; j < k; ++j) {
+    a.tpos[j] = pos[j];
+    tmask |= 1ull << pos[j];
+  }
+  unsigned nc = 0;
+  for (unsigned p = 0; p < n && nc < a.c; ++p)
+    if (!((tmask >> p) & 1)) a.cpos[nc++] = p;
+  std::vector<unsigned> all(a.tpos, a.tpos + k);
+  all.insert(all.end(), a.cpos, a.cpos + a.c);
+  std::sort(all.begin(), all.end());
+  for (unsigned j = 0; j < k + a.c; ++j) a.apos[j] = all[j];
+  constexpr unsigned VB = Vec<T>::VB;
+  a.vec_ok = 1;
+  for (unsigned b = 0; b < VB; ++b) a.vec_ok &= (a.cpos[b] == b) ? 1u : 0u;
+  // A-operand table: A[row block][step][lane] = M[16 rb + (lane & 15)][4 step + (lane >> 4)],
+  // M = [[Ur,-Ui],[Ui,Ur]] with row/column index = plane * 2^k + t (t in the caller's bit order)
+  const unsigned D = 1u << k, E = 2 * D, NSTEP = E / 4, NRBT = E / 16;
+  std::vector<T> A((size_t)NRBT * NSTEP * 64);
+  for (unsigned rb = 0; rb < NRBT; ++rb)
+    for (unsigned st = 0; st < NSTEP; ++st)
+      for (unsigned lane = 0; lane < 64; ++lane) {
+        const unsigned row = 16 * rb + (lane & 15), col = 4 * st + (lane >> 4);
+        const unsigned po = row / D, to = row % D, pi = col / D, ti = col % D;
+        const T ur = U[2 * ((size_t)to * D + ti)], ui = U[2 * ((size_t)to * D + ti) + 1];
+        A[((size_t)rb * NSTEP + st) * 64 + lane] = po == pi ? ur : (po == 0 ? -ui : ui);
+      }
+  void* dA = nullptr;
+  if (arena_upload(c, A.data(), A.size() * sizeof(T), &dA)) return 1;
+  const size_t C = (size_t)1 << a.c;
+  const size_t lds = D * 8 + C * 4 + 2 * (size_t)D * C * sizeof(T);
+  const uint64_t nblocks = 1ull << (n - tile_bits);
+  const unsigned grid = (unsigned)std::min<uint64_t>(nblocks, 256 * 4);
+  if (k == 5)
+    HQ_LAUNCH(c, (apply_mfma_tile_kernel<T, 5>), dim3(grid), dim3(kBlock), lds, re, im, (const T*)dA, a, nblocks);
+  else
+    HQ_LAUNCH(c, (apply_mfma_tile_kernel<T, 6>), dim3(grid), dim3(kBlock), lds, re, im, (const T*)dA, a, nblocks);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "mfma_tile";
+  c.last_desc = std::string("apply_mfma_tile_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(k) + ">";
+  return 0;
+}
+
+template <typename T>
+static int launch_naive(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                        unsigned k) {
+  HQ_NOT_RECORDABLE(c, "the tiny-state fallback kernel");
+  NaiveArg a;
+  memset(&a, 0, sizeof(a));
+  a.k = k;
+  for (unsigned j = 0; j < k; ++j) a.tpos[j] = pos[j];
+  const uint64_t size = 1ull << n;
+  const size_t D = (size_t)1 << k;
+  void* dU = nullptr;
+  if (arena_upload(c, U, 2 * D * D * sizeof(T), &dU)) return 1;
+  void* tmp = nullptr;
+  if (get_scratch(c, 2, 2 * size * sizeof(T), &tmp)) return 1;
+  T* tre = (T*)tmp;
+  T* tim = tre + size;
+  HQ_HIP_CHECK(hipMemcpyAsync(tre, re, size * sizeof(T), hipMemcpyDeviceToDevice, c.stream));
+  HQ_HIP_CHECK(hipMemcpyAsync(tim, im, size * sizeof(T), hipMemcpyDeviceToDevice, c.stream));
+  const uint64_t nblocks = (size + kBlock - 1) / kBlock;
+  if (nblocks > 0x7fffffffull) return fail("naive: state too large");
+  hipLaunchKernelGGL((apply_naive_kernel<T>), dim3((unsigned)nblocks), dim3(kBlock), 0, c.stream,
+                     (const T*)tre, (const T*)tim, re, im, (const T*)dU, a, size);
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "naive";
+  c.last_desc = "apply_naive_kernel";
+  return 0;
+}
+
+template <typename T>
+static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* pos, unsigned n,
+                        unsigned k) {
+  const bool can_direct = direct_ok<T>(n, k, pos);
+  const bool can_generic = (n - k) >= 2 && k <= kMaxK;
+  MfmaPlan<T> plan;
+  bool can_mfma = false;
+  if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && k <= 6) can_mfma = plan_mfma<T>(c, U, pos, n, k, plan);
+  auto run_mfma = [&]() -> int { return launch_mfma<T>(c, re, im, plan, n); };
+  switch (c.mode) {
+    case Mode::Direct:
+      if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
+      break;
+    case Mode::Mfma:
+      if (can_mfma) return run_mfma();
+      break;
+    case Mode::Generic:
+      if (can_generic) return launch_generic<T>(c, re, im, U, pos, n, k);
+      break;
+    case Mode::Naive:
+      return launch_naive<T>(c, re, im, U, pos, n, k);
+    case Mode::Tile:
+      if (mfma_tile_ok<T>(n, k)) return launch_mfma_tile<T>(c, re, im, U, pos, n, k);
+      break;
+    case Mode::Gemm:
+      if (gemm_ok<T>(n, k, true)) return launch_gemm<T>(c, re, im, U, pos, n, k);
+      break;
+    case Mode::Auto:
+      break;
+  }
+  if (can_mfma) return run_mfma();
+  if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
+  if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && mfma_tile_ok<T>(n, k))
+    return launch_mfma_tile<T>(c, re, im, U, pos, n, k);
+  if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && gemm_ok<T>(n, k))
+    return launch_gemm<T>(c, re, im, U, pos, n, k);
+  if (can_generic) return launch_generic<T>(c, re, im, U, pos, n, k);
+  return launch_naive<T>(c, re, im, U, pos, n, k);
+}
+
+template <typename T>
+static int apply_U_entry(T* re, T* im, const T* U, const unsigned* pos, unsigned n, unsigned k) {
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (k == 0) return 0;  // python_U.cpp:38-39
+  if (!re || !im || !U || !pos) return fail("apply_U: null pointer");
+  if (k > kMaxK) return fail("apply_U: n_pos > 10 is not supported");
+  if (check_positions(pos, n, k)) return fail("apply_U: invalid positions");
+  if ((reinterpret_cast<uintptr_t>(re) % 32) || (reinterpret_cast<uintptr_t>(im) % 32))
+    return fail("apply_U: planes must be 32-byte aligned");  // U.h:34-36
+  const bool dre = is_device_pointer(re), dim_ = is_device_pointer(im);
+  if (dre != dim_) return fail("apply_U: psi_re/psi_im must both be device or both host");
+  if (dre) return apply_device<T>(c, re, im, U, pos, n, k);
+  // host compatibility path: stage -> kernel -> copy back -> sync
+  HQ_NOT_RECORDABLE(c, "a host-pointer call");
+  const size_t bytes = ((size_t)1 << n) * sizeof(T);
+  void* s0 = nullptr;
+  if (get_scratch(c, 0, 2 * bytes, &s0)) return 1;
+  T* dr = (T*)s0;
+  T* di = (T*)((unsigned char*)s0 + bytes);
+  HQ_HIP_CHECK(hipMemcpyAsync(dr, re, bytes, hipMemcpyHostToDevice, c.stream));
+  HQ_HIP_CHECK(hipMemcpyAsync(di, im, bytes, hipMemcpyHostToDevice, c.stream));
+  if (apply_device<T>(c, dr, di, U, pos, n, k)) return 1;
+  HQ_HIP_CHECK(hipMemcpyAsync(re, dr, bytes, hipMemcpyDeviceToHost, c.stream));
+  HQ_HIP_CHECK(hipMemcpyAsync(im, di, bytes, hipMemcpyDeviceToHost, c.stream));
+  HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// apply_blocked: a list of gates inside one LDS tile, one HBM pass (device pointers, f32)
+// ---------------------------------------------------------------------------------
+template <typename T>
+static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_pos, unsigned tb,
+                               unsigned n_gates, const T* U_all, const unsigned* pos_all,
+                               const unsigned* k_all) {
+  constexpr unsigned CB = Vec<T>::VB;
+  const unsigned max_tb = sizeof(T) == 4 ? kBlockedMaxTileBits : kBlockedMaxTileBits - 1;  // 128 KiB of LDS
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!re || !im || !tile_pos || (n_gates && (!U_all || !pos_all || !k_all))) return fail("apply_blocked: null pointer");
+  if (n_gates == 0) return 0;
+  if (n > 62 || tb > max_tb || tb < 10 || tb > n) return fail("apply_blocked: tile size out of range");
+  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("apply_blocked: device pointers only");
+  if ((reinterpret_cast<uintptr_t>(re) % 32) || (reinterpret_cast<uintptr_t>(im) % 32))
+    return fail("apply_blocked: planes must be 32-byte aligned");
+  BlockedArg ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.tb = tb;
+  int local_of[64];
+  for (int i = 0; i < 64; ++i) local_of[i] = -1;
+  for (unsigned i = 0; i < tb; ++i) {
+    if (tile_pos[i] >= n || (i && tile_pos[i] <= tile_pos[i - 1])) return fail("apply_blocked: tile positions must be ascending and < n");
+    ba.apos[i] = tile_pos[i];
+    local_of[tile_pos[i]] = (int)i;
+  }
+  for (unsigned b = 0; b < CB; ++b)
+    if (tile_pos[b] != b) return fail("apply_blocked: the tile must contain the vector-component index bits (0,1 for f32; 0 for f64)");
+  std::vector<BlockedGate> gates(n_gates);
+  std::vector<T> Atab;
+  const T* Up = U_all;
+  const unsigned* pp = pos_all;
+  for (unsigned g = 0; g < n_gates; ++g) {
+    const unsigned k = k_all[g];
+    if (k < 1 || k > 4) return fail("apply_blocked: gates must have 1..4 targets");
+    unsigned lp[4];
+    for (unsigned j = 0; j < k; ++j) {
+      if (pp[j] >= 64 || local_of[pp[j]] < 0) return fail("apply_blocked: gate target outside the tile");
+      lp[j] = (unsigned)local_of[pp[j]];
+    }
+    if (check_positions(lp, tb, k)) return fail("apply_blocked: duplicate targets");
+    // largest k that takes the register butterfly on the LDS tile (blocked_inner_gate_valu) instead
+    // of the matrix-core form with identity dummies: measured, k = 1 wins (4x fewer flops), k = 2 does not
+    static int valu_kmax = getenv("HQ_BLOCKED_VALU") ? atoi(getenv("HQ_BLOCKED_VALU")) : 1;
+    if (k <= 2 && (int)k <= valu_kmax) {
+      std::vector<T> Us;
+      unsigned sp[kMaxK];
+      sort_gate<T>(Up, lp, k, Us, sp);  // planar, matrix index bits in ascending local position
+      BlockedGate& G = gates[g];
+      memset(&G, 0, sizeof(G));
+      unsigned vmask = 0, kr = 0;
+      for (int m = 0; m < 6; ++m) G.ro.pos[m] = 31;
+      for (unsigned j = 0; j < k; ++j) {
+        if (sp[j] < CB) vmask |= 1u << sp[j];
+        else G.ro.pos[kr++] = sp[j] - CB;
+      }
+      if (tb - CB < kr) return fail("apply_blocked: tile too small");
+      G.a_off = (unsigned)Atab.size();
+      G.kv = 64 + k * 4 + vmask;
+      G.n_addr = kr;
+      Atab.insert(Atab.end(), Us.begin(), Us.end());
+      while (Atab.size() % 4) Atab.push_back((T)0);  // keep the next table 16-byte aligned
+      Up += (size_t)2 << (2 * k);
+      pp += k;
+      continue;
+    }
+    MfmaPlan<T> P;
+    if (!plan_mfma<T>(c, Up, lp, tb, k, P, true)) return fail("apply_blocked: cannot plan an inner gate");
+    BlockedGate& G = gates[g];
+    memset(&G, 0, sizeof(G));
+    G.ro = P.ro;
+    for (int m = 0; m < 4; ++m)
+      if (G.ro.pos[m] >= 31) G.ro.pos[m] = 31;
+    G.a_off = (unsigned)Atab.size();
+    G.kv = (unsigned)(P.kbits * 4 + P.vmask);
+    G.n_addr = P.n_addr;
+    Atab.insert(Atab.end(), P.A.begin(), P.A.end());
+    Up += (size_t)2 << (2 * k);
+    pp += k;
+  }
+  const uint64_t ntiles = 1ull << (n - tb);
+  const size_t tile_bytes = ((size_t)2 << tb) * sizeof(T);
+  const size_t per_cu = std::min<size_t>(std::max<size_t>(1, (160 * 1024) / tile_bytes), 4);
+  static bool attr_done = false;
+  if (!attr_done) {
+    const void* fns[] = {(const void*)apply_blocked_kernel<float, 256, false, false>, (const void*)apply_blocked_kernel<float, 512, false, false>,
+                         (const void*)apply_blocked_kernel<double, 256, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false>,
+                         (const void*)apply_blocked_kernel<float, 512, true, false>, (const void*)apply_blocked_kernel<double, 512, true, false>,
+                         (const void*)apply_blocked_kernel<float, 512, true, true>, (const void*)apply_blocked_kernel<float, 512, false, true>,
+                         (const void*)apply_blocked_kernel<double, 512, true, true>};
+    for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
+  static int block_threads = getenv("HQ_BLOCKED_THREADS") ? atoi(getenv("HQ_BLOCKED_THREADS")) : 512;
+  static int a_in_lds = getenv("HQ_BLOCKED_ALDS") ? atoi(getenv("HQ_BLOCKED_ALDS")) : 1;
+  // LDS left per workgroup behind the tile when `per_cu` workgroups share a CU
+  const size_t a_budget = (160 * 1024) / per_cu - tile_bytes > 2048 ? (160 * 1024) / per_cu - tile_bytes - 1024 : 0;
+  // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
+  // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
+  const size_t tab_bytes = (((size_t)n_gates * kBlockedTabWords * sizeof(BlockedTabT)) + 15) & ~(size_t)15;  // per-gate address tables (built in-kernel)
+  const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
+  // register prefetch of the next tile (512 threads, 4 vectors per thread and plane = 13 (f32) / 12 (f64) tile bits;
+  // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
+  static int use_pref = getenv("HQ_BLOCKED_PREF") ? atoi(getenv("HQ_BLOCKED_PREF")) : 1;
+  const bool pref = use_pref && block_threads != 256 && tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits);
+  if (fits) {
+    void *dG = nullptr, *dA = nullptr;
+    if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
+    if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
+    const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes;
+    if (pref) {
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
+                n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+    } else {
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
+                n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+    }
+  } else {
+    void *dG = nullptr, *dA = nullptr;
+    if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
+    if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
+    const size_t lds = tile_bytes;
+    if (block_threads == 256)
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 256, false, false>), dim3(grid), dim3(256), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+    else if (pref) {
+      if constexpr (sizeof(T) == 4)
+        HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, false, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+    } else
+      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, false, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+  }
+  HQ_HIP_CHECK(hipGetLastError());
+  c.last_kernel = "blocked";
+  c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                std::to_string(block_threads == 256 ? 256 : 512) + "> tb=" + std::to_string(tb) + " gates=" +
+                std::to_string(n_gates);
+  return 0;
+}
+
+int apply_device_f32(Context& c, float* re, float* im, const float* U, const unsigned* pos, unsigned n, unsigned k) {
+  return apply_device<float>(c, re, im, U, pos, n, k);
+}
+int apply_device_f64(Context& c, double* re, double* im, const double* U, const unsigned* pos, unsigned n, unsigned k) {
+  return apply_device<double>(c, re, im, U, pos, n, k);
+}
+
+}  // namespace hq
+
+extern "C" {
+
+int apply_U_float32(float* psi_re, float* psi_im, const float* U, const unsigned int* pos,
+                    unsigned int n_qubits, unsigned int n_pos) {
+  return hq::apply_U_entry<float>(psi_re, psi_im, U, pos, n_qubits, n_pos);
+}
+
+int apply_U_float64(double* psi_re, double* psi_im, const double* U, const unsigned int* pos,
+                    unsigned int n_qubits, unsigned int n_pos) {
+  return hq::apply_U_entry<double>(psi_re, psi_im, U, pos, n_qubits, n_pos);
+}
+
+int hq_apply_blocked_float32(float* re, float* im, unsigned int n, const unsigned int* tile_pos,
+                             unsigned int tile_bits, unsigned int n_gates, const float* U_all,
+                             const unsigned int* pos_all, const unsigned int* k_all) {
+  return hq::apply_blocked_entry<float>(re, im, n, tile_pos, tile_bits, n_gates, U_all, pos_all, k_all);
+}
+
+int hq_apply_blocked_float64(double* re, double* im, unsigned int n, const unsigned int* tile_pos,
+                             unsigned int tile_bits, unsigned int n_gates, const double* U_all,
+                             const unsigned int* pos_all, const unsigned int* k_all) {
+  return hq::apply_blocked_entry<double>(re, im, n, tile_pos, tile_bits, n_gates, U_all, pos_all, k_all);
+}
+
+}  // extern "C"
+
+#ifdef HQ_EXP_TIMELINE
+extern "C" int hq_debug_timeline(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hq::hq_timeline), sizeof(unsigned long long) * 512);
+}
+#endif

@@ -1,69 +1,10 @@
-// hq_kernels.h -- device kernels of the MI355X (gfx950) state-vector evolution core.
-//
-// Semantics implemented (reference: /root/reference/include/U.h:28-102,123-202,
-// include/swap.h:28-95, include/python_U.cpp:114-123), written from the index
-// formula, CDNA4-first:
-//
-//   * apply_direct   k <= 3: pure HBM streaming.  Each lane owns 16-byte vectors
-//                    (index bits 0..1 for f32, bit 0 for f64) and ALL 2^k partner
-//                    vectors of its tile, so the butterfly is register-local: no
-//                    LDS, no cross-lane traffic.  The lane -> address map skips the
-//                    target bits, i.e. a wave's loads are contiguous 1 KiB runs
-//                    whenever the targets sit at positions >= 8, and degrade to
-//                    interleaved 16/32/64-byte pieces of the same cache lines (both
-//                    halves issued back to back by the same wave) for lower targets.
-//                    U lives in SGPRs / the scalar cache (kernel argument).
-//   * apply_mfma     f32, k <= 4: the gate as a real-embedded GEMM on the matrix cores with
-//                    role-assigned index digits (see the kernel's header comment).
-//   * apply_generic  any k <= 10: workgroup tile of 2^(k+c) amplitudes staged
-//                    through LDS (c lowest non-target bits = contiguous columns),
-//                    dense complex mat-mat on the tile, results streamed back.
-//   * apply_naive    out-of-place one-thread-per-amplitude fallback for tiny states.
-//   * swap_lds / swap_gather, interleave (to_complex), init_state, norm2.
+// hq_kernels_apply.h -- apply_U kernels (reference: /root/reference/include/U.h:28-102, 123-202): VALU butterflies,
+// matrix-core role kernels (k <= 4, k = 5/6), the cache-blocked many-gates-per-pass kernel, the k >= 7 tile GEMM,
+// the generic LDS-tile kernel and the tiny-state fallback.  Overview in hq_kernels_common.h.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "hq_kernels_common.h"
 
 namespace hq {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct Vec;
-template <> struct Vec<float> {
-  using type = f32x4;   // 16-byte lane vector
-  using quad = f32x4;   // 4 consecutive elements
-  static constexpr int VB = 2;
-};
-template <> struct Vec<double> {
-  using type = f64x2;
-  using quad = f64x4;
-  static constexpr int VB = 1;
-};
-
-__host__ __device__ constexpr int popc_c(int x) { return x == 0 ? 0 : (x & 1) + popc_c(x >> 1); }
-// gather the bits of v selected by mask into a compact integer
-__host__ __device__ constexpr int pext_c(int v, int mask) {
-  int out = 0, o = 0;
-  for (int b = 0; b < 8; ++b)
-    if ((mask >> b) & 1) { out |= ((v >> b) & 1) << o; ++o; }
-  return out;
-}
-// scatter the low bits of v to the positions selected by mask
-__host__ __device__ constexpr int pdep_c(int v, int mask) {
-  int out = 0, o = 0;
-  for (int b = 0; b < 8; ++b)
-    if ((mask >> b) & 1) { out |= ((v >> o) & 1) << b; ++o; }
-  return out;
-}
-
-constexpr int kBlock = 256;
-
-// fma in the TYPE of its operands: `__builtin_fma` is the double builtin, so a float call site
-// silently converts to f64 and back (found in round 1: the float butterfly kernels ran v_fma_f64)
-__device__ __forceinline__ float hq_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double hq_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // ---------------------------------------------------------------------------------
 // apply_direct
@@ -1118,17 +1059,6 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 }
 
 // ---------------------------------------------------------------------------------
-// apply_generic (LDS tile)
-// ---------------------------------------------------------------------------------
-constexpr int kMaxK = 10;
-constexpr int kTileBits = 12;
-// Copy a host-pinned (device-mapped) buffer into device memory in-stream (operand tables).
-__global__ void __launch_bounds__(kBlock)
-upload_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, const size_t n16) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
-}
-
-// ---------------------------------------------------------------------------------
 // k = 7..10 on the matrix cores: apply_gemm_kernel (reference: the runtime-k loop U.h:123-202).
 //
 // A workgroup (8 waves) owns a tile of 2^TB amplitudes (TB = 14 f32 / 13 f64: both planes =
@@ -1594,544 +1524,6 @@ apply_naive_kernel(const T* __restrict__ in_re, const T* __restrict__ in_im,
   }
   out_re[x] = ar;
   out_im[x] = ai;
-}
-
-// ---------------------------------------------------------------------------------
-// swap (low-bit permutation)
-// ---------------------------------------------------------------------------------
-struct SwapArg {
-  unsigned s;
-  unsigned pos[32];
-};
-
-// One workgroup permutes 2^tile_bits contiguous elements (>= one 2^s chunk) through LDS:
-// 16-byte loads into LDS, permuted LDS reads, 16-byte stores (VEC elements per access).
-// TABLE = false (large s: the whole LDS budget goes to the tile) computes the permuted index
-// inline instead of reading it from a 2^s-entry table.
-// NPV > 0 (tiles of exactly NPV * kBlock vectors): the next tile is requested into registers while this one is
-// permuted and stored, and dropped into LDS after the stores were issued (the recipe of apply_blocked_kernel's PREF:
-// load / permute-store phases of a tile no longer alternate in step on the whole chip).
-template <typename E, int VEC, bool TABLE, int NPV>
-__global__ void __launch_bounds__(kBlock)
-swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
-                const uint64_t ntiles) {
-  struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
-  typedef E PackV __attribute__((ext_vector_type(VEC)));
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const unsigned S = 1u << sa.s, TILE = 1u << tile_bits;
-  uint16_t* src = reinterpret_cast<uint16_t*>(smem);          // S entries (TABLE only)
-  E* buf = reinterpret_cast<E*>(smem + (TABLE ? (((size_t)S * 2 + 15) & ~(size_t)15) : 0));
-  const unsigned tid = threadIdx.x;
-  if (TABLE)
-    for (unsigned x = tid; x < S; x += kBlock) {
-      unsigned y = 0;
-      for (unsigned i = 0; i < sa.s; ++i) y |= ((x >> i) & 1u) << sa.pos[i];
-      src[x] = (uint16_t)y;
-    }
-  auto permute_store = [&](E* g) {
-    for (unsigned x = tid * VEC; x < TILE; x += kBlock * VEC) {
-      Pack p;
-#pragma unroll
-      for (int c = 0; c < VEC; ++c) {
-        const unsigned xx = x + c;
-        unsigned y;
-        if (TABLE) {
-          y = src[xx & (S - 1)];
-        } else {
-          y = 0;
-          for (unsigned i = 0; i < sa.s; ++i) y |= ((xx >> i) & 1u) << sa.pos[i];
-        }
-        p.e[c] = buf[(xx & ~(S - 1)) | y];
-      }
-      *reinterpret_cast<Pack*>(g + x) = p;
-    }
-  };
-  if constexpr (NPV > 0 && VEC > 1) {
-    if (blockIdx.x >= ntiles) return;
-    const uint64_t stride = gridDim.x;
-    PackV pr[NPV];
-    auto prefetch = [&](uint64_t tb) {  // unconditional (callers clamp): see apply_blocked_kernel
-      const PackV* g = reinterpret_cast<const PackV*>(a + tb * TILE) + tid;
-#pragma unroll
-      for (int i = 0; i < NPV; ++i) pr[i] = __builtin_nontemporal_load(g + i * kBlock);
-    };
-    {
-      const PackV* g = reinterpret_cast<const PackV*>(a + (uint64_t)blockIdx.x * TILE) + tid;
-#pragma unroll 1
-      for (int i = 0; i < NPV; ++i) reinterpret_cast<PackV*>(buf)[tid + i * kBlock] = __builtin_nontemporal_load(g + i * kBlock);
-    }
-    prefetch(blockIdx.x + stride < ntiles ? blockIdx.x + stride : blockIdx.x);
-    for (uint64_t tb = blockIdx.x; tb < ntiles; tb += stride) {
-      __syncthreads();
-      permute_store(a + tb * TILE);
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NPV; ++i) reinterpret_cast<PackV*>(buf)[tid + i * kBlock] = pr[i];
-      prefetch(tb + 2 * stride < ntiles ? tb + 2 * stride : tb);
-    }
-  } else {
-    for (uint64_t tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
-      E* g = a + tb * TILE;
-      __syncthreads();
-      for (unsigned x = tid * VEC; x < TILE; x += kBlock * VEC) {
-        *reinterpret_cast<Pack*>(buf + x) = *reinterpret_cast<const Pack*>(g + x);
-      }
-      __syncthreads();
-      permute_store(g);
-    }
-  }
-}
-
-// In-place permutation of the TB index bits `apos` (ascending; the lowest ones are the index bits
-// 0..log2(VEC)-1, so every global access is a 16-byte vector of a contiguous run) inside tiles staged
-// through LDS: new tile element x = old tile element whose tile-local index has bit i of x at bit
-// lp[i].  A low-bit permutation of up to 16 bits (swap_*, transpose()) that does not fit one LDS
-// tile is the product of TWO such passes over different bit sets (host: plan_two_pass_swap).
-constexpr int kTilePermBits = 13;
-struct TilePermArg {
-  unsigned tb;
-  unsigned apos[kTilePermBits];  // global positions of the tile-local bits
-  unsigned lp[kTilePermBits];    // tile-local bit i of the destination index -> tile-local bit of the source index
-};
-
-template <typename E, int VEC> struct PackOf { typedef E type __attribute__((ext_vector_type(VEC))); };
-template <typename E> struct PackOf<E, 1> { typedef E type; };
-
-// NPV > 0 (tiles of exactly NPV * kBlock vectors): register prefetch of the next tile (see swap_lds_kernel).
-template <typename E, int VEC, int NPV>
-__global__ void __launch_bounds__(kBlock)
-tile_permute_kernel(E* __restrict__ a, const TilePermArg ta, const uint64_t ntiles) {
-  using Pack = typename PackOf<E, VEC>::type;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr unsigned VBITS = VEC == 4 ? 2 : (VEC == 2 ? 1 : 0);
-  const unsigned TILE = 1u << ta.tb, NV = TILE >> VBITS;
-  uint16_t* src = reinterpret_cast<uint16_t*>(smem);                                        // TILE entries: permuted tile-local index
-  uint32_t* goff = reinterpret_cast<uint32_t*>(smem + (((size_t)TILE * 2 + 15) & ~(size_t)15));  // NV entries: element offset of vector v
-  E* buf = reinterpret_cast<E*>(reinterpret_cast<unsigned char*>(goff) + (((size_t)NV * 4 + 15) & ~(size_t)15));
-  const unsigned tid = threadIdx.x;
-  for (unsigned x = tid; x < TILE; x += kBlock) {
-    unsigned y = 0;
-    for (unsigned i = 0; i < ta.tb; ++i) y |= ((x >> i) & 1u) << ta.lp[i];
-    src[x] = (uint16_t)y;
-  }
-  for (unsigned v = tid; v < NV; v += kBlock) {  // the tile's bits all sit below bit 32 (swap: s <= 18)
-    uint32_t g = 0;
-    for (unsigned m = VBITS; m < ta.tb; ++m) g |= ((v >> (m - VBITS)) & 1u) << ta.apos[m];
-    goff[v] = g;
-  }
-  auto tile_ptr = [&](uint64_t t) {
-    uint64_t base = t;  // element index with zeros at the tile's positions
-    for (unsigned m = 0; m < ta.tb; ++m) {
-      const uint64_t lo = (1ull << ta.apos[m]) - 1;
-      base = ((base & ~lo) << 1) | (base & lo);
-    }
-    return a + base;
-  };
-  auto permute_store = [&](E* __restrict__ at) {
-    for (unsigned v = tid; v < NV; v += kBlock) {
-      Pack p;
-      if constexpr (VEC == 1) {
-        p = buf[src[v]];
-      } else {
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) p[c] = buf[src[v * VEC + c]];
-      }
-      __builtin_nontemporal_store(p, reinterpret_cast<Pack*>(at + goff[v]));
-    }
-  };
-  if constexpr (NPV > 0 && VEC > 1) {
-    if (blockIdx.x >= ntiles) return;
-    __syncthreads();  // goff is read below by other threads than its writers
-    const uint64_t stride = gridDim.x;
-    Pack pr[NPV];
-    uint32_t go[NPV];
-#pragma unroll
-    for (int i = 0; i < NPV; ++i) go[i] = goff[tid + i * kBlock];
-    auto prefetch = [&](uint64_t t) {  // unconditional (callers clamp)
-      const E* __restrict__ at = tile_ptr(t);
-#pragma unroll
-      for (int i = 0; i < NPV; ++i) pr[i] = __builtin_nontemporal_load(reinterpret_cast<const Pack*>(at + go[i]));
-    };
-    {
-      const E* __restrict__ at = tile_ptr(blockIdx.x);
-#pragma unroll 1
-      for (int i = 0; i < NPV; ++i)
-        *reinterpret_cast<Pack*>(buf + (tid + i * kBlock) * VEC) = __builtin_nontemporal_load(reinterpret_cast<const Pack*>(at + goff[tid + i * kBlock]));
-    }
-    prefetch(blockIdx.x + stride < ntiles ? blockIdx.x + stride : blockIdx.x);
-    for (uint64_t t = blockIdx.x; t < ntiles; t += stride) {
-      __syncthreads();
-      permute_store(tile_ptr(t));
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NPV; ++i) *reinterpret_cast<Pack*>(buf + (tid + i * kBlock) * VEC) = pr[i];
-      prefetch(t + 2 * stride < ntiles ? t + 2 * stride : t);
-    }
-  } else {
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-      E* __restrict__ at = tile_ptr(t);
-      __syncthreads();
-      for (unsigned v = tid; v < NV; v += kBlock)
-        *reinterpret_cast<Pack*>(buf + v * VEC) = __builtin_nontemporal_load(reinterpret_cast<const Pack*>(at + goff[v]));
-      __syncthreads();
-      permute_store(at);
-    }
-  }
-}
-
-// Out-of-place gather for large s: out[x] = in[(x & ~(S-1)) | perm(x & (S-1))].
-template <typename E>
-__global__ void __launch_bounds__(kBlock)
-swap_gather_kernel(const E* __restrict__ in, E* __restrict__ out, const SwapArg sa,
-                   const uint64_t size) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  const uint64_t S = 1ull << sa.s;
-  for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < size; x += stride) {
-    uint64_t y = x & ~(S - 1);
-    for (unsigned i = 0; i < sa.s; ++i) y |= ((x >> i) & 1ull) << sa.pos[i];
-    out[x] = in[y];
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// permute_bits: out-of-place permutation of ARBITRARY index bits, dst[x] = src[pi(x)],
-// where bit i of x moves to bit perm[i] of pi(x).  Generalises swap (which only moves the
-// low s bits) to the whole index; used to bring qubits into the exchange slots of the
-// multi-GPU shard exchange and to restore the canonical order.  Only the moved bits cost
-// index arithmetic; if bits 0..1 are fixed the copy runs on 16-byte vectors.
-// ---------------------------------------------------------------------------------
-// Moved bits are grouped into FIELDS: runs of consecutive destination bits whose sources are
-// consecutive too (a rotation of a block of qubits is one field, whatever its width), so the
-// index arithmetic is one shift + mask per run and any permutation of up to 62 bits fits.
-constexpr int kPermMaxFields = 62;
-struct PermArg {
-  unsigned nfields;
-  unsigned char from[kPermMaxFields];   // lowest destination-index bit of the field ...
-  unsigned char to[kPermMaxFields];     // ... lands at this source-index bit
-  unsigned char len[kPermMaxFields];    // field width in bits
-  uint64_t fixed_mask; // bits that stay where they are
-};
-
-template <typename E, int VEC>
-__global__ void __launch_bounds__(kBlock)
-permute_bits_kernel(const E* __restrict__ src, E* __restrict__ dst, const PermArg pa,
-                    const uint64_t nunits /* 2^n / VEC */) {
-  struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t u = (uint64_t)blockIdx.x * kBlock + threadIdx.x; u < nunits; u += stride) {
-    const uint64_t x = u * VEC;
-    uint64_t y = x & pa.fixed_mask;
-#pragma unroll 4
-    for (unsigned i = 0; i < pa.nfields; ++i) y |= ((x >> pa.from[i]) & ((1ull << pa.len[i]) - 1)) << pa.to[i];
-    *reinterpret_cast<Pack*>(dst + x) = *reinterpret_cast<const Pack*>(src + y);
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// exchange_pack: the local half of the multi-GPU qubit exchange.  The shard (2^m elements per
-// plane) is cut into G = 2^g chunks by its top g LOCAL index bits; chunk j belongs to rank j after
-// the exchange.  One pass reads the plane(s) through an optional local bit permutation (the
-// eviction that brings the outgoing qubits to the top g bits -- folded in here instead of a pass
-// of its own) and writes every chunk to its own destination base:
-//   * RCCL transport: dst[j] = slot j of the local send buffer (then ncclSend / ncclRecv);
-//   * peer-to-peer transport: dst[j] = slot `rank` of rank j's receive buffer, mapped through HIP
-//     IPC -- the stores travel over xGMI and no second pass exists at all.
-// Both planes in one launch (planes = 2) or one plane per launch (so that the transfer of the first
-// plane overlaps the packing of the second).
-// ---------------------------------------------------------------------------------
-constexpr int kMaxShardRanks = 16;
-struct ExchArg {
-  unsigned g, m, planes;
-  PermArg perm;                       // identity: nfields = 0
-  void* dst[kMaxShardRanks][2];       // [chunk][plane]
-};
-
-template <typename E, int VEC>
-__global__ void __launch_bounds__(kBlock)
-exchange_pack_kernel(const E* __restrict__ src0, const E* __restrict__ src1, const ExchArg a,
-                     const uint64_t nunits /* 2^m / VEC */) {
-  struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  const unsigned cbits = a.m - a.g;
-  const uint64_t wmask = (1ull << cbits) - 1;
-  for (uint64_t u = (uint64_t)blockIdx.x * kBlock + threadIdx.x; u < nunits; u += stride) {
-    const uint64_t x = u * VEC;
-    uint64_t y = x & a.perm.fixed_mask;
-#pragma unroll 4
-    for (unsigned i = 0; i < a.perm.nfields; ++i)
-      y |= ((x >> a.perm.from[i]) & ((1ull << a.perm.len[i]) - 1)) << a.perm.to[i];
-    const unsigned j = (unsigned)(x >> cbits);
-    const uint64_t w = x & wmask;
-    *reinterpret_cast<Pack*>(reinterpret_cast<E*>(a.dst[j][0]) + w) = *reinterpret_cast<const Pack*>(src0 + y);
-    if (a.planes == 2)
-      *reinterpret_cast<Pack*>(reinterpret_cast<E*>(a.dst[j][1]) + w) = *reinterpret_cast<const Pack*>(src1 + y);
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// to_complex, init_state, norm2
-// ---------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-interleave_kernel(const T* __restrict__ re, const T* __restrict__ im, T* __restrict__ out,
-                  const uint64_t size) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
-    out[2 * i] = re[i];
-    out[2 * i + 1] = im[i];
-  }
-}
-
-// 4 elements per thread, 16-byte accesses; size must be a multiple of 4 and pointers
-// 16/32-byte aligned (checked by the host).
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-interleave4_kernel(const T* __restrict__ re, const T* __restrict__ im, T* __restrict__ out,
-                   const uint64_t nquads) {
-  using Q = typename Vec<T>::quad;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nquads; i += stride) {
-    const Q r = reinterpret_cast<const Q*>(re)[i];
-    const Q m = reinterpret_cast<const Q*>(im)[i];
-    Q o0 = {r[0], m[0], r[1], m[1]};
-    Q o1 = {r[2], m[2], r[3], m[3]};
-    reinterpret_cast<Q*>(out)[2 * i] = o0;
-    reinterpret_cast<Q*>(out)[2 * i + 1] = o1;
-  }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-init_state_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t size, const int kind,
-                  const uint64_t basis, const T amp) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
-    re[i] = kind == 1 ? amp : (i == basis ? (T)1 : (T)0);
-    im[i] = 0;
-  }
-}
-
-// Product state of '0' / '1' / '+' / '-' factors (hybridq/circuit/simulation/utils.py:99-153 builds it
-// on the host with kron + parity + transpose): amplitude of index X is 0 unless the '0'/'1' bits of
-// X match, else (-1)^popcount(X & minus_mask) * 2^(-#pm/2).  X = hi_bits | local index, so a shard
-// of a multi-GPU state (hi_bits = rank << n_local) is written by the same kernel.
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-init_product_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t nquads, const uint64_t hi_bits,
-                    const uint64_t mask01, const uint64_t val01, const uint64_t mask_minus, const T amp) {
-  using Q = typename Vec<T>::quad;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nquads; i += stride) {
-    Q r, z = {0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint64_t x = hi_bits | (4 * i + c);
-      const T v = (__popcll(x & mask_minus) & 1) ? -amp : amp;
-      r[c] = ((x & mask01) == val01) ? v : (T)0;
-    }
-    __builtin_nontemporal_store(r, reinterpret_cast<Q*>(re) + i);
-    __builtin_nontemporal_store(z, reinterpret_cast<Q*>(im) + i);
-  }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-norm2_kernel(const T* __restrict__ re, const T* __restrict__ im, const uint64_t size,
-             double* __restrict__ out) {
-  __shared__ double part[kBlock / 64];
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  double acc = 0;
-  using V = typename Vec<T>::type;
-  constexpr int VE = 1 << Vec<T>::VB;
-  if (size % (2 * VE) == 0 && reinterpret_cast<uintptr_t>(re) % 16 == 0 && reinterpret_cast<uintptr_t>(im) % 16 == 0) {
-    // 16-byte non-temporal loads, two vector pairs in flight per thread, two accumulators (5.4 -> 6 TB/s)
-    const V* __restrict__ vr = reinterpret_cast<const V*>(re);
-    const V* __restrict__ vi = reinterpret_cast<const V*>(im);
-    const uint64_t nvec = size / VE;
-    double acc2 = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += 2 * stride) {
-      const uint64_t i2 = i + stride < nvec ? i + stride : i;  // (nvec is a multiple of 2: clamped repeats are skipped below)
-      const V r0 = __builtin_nontemporal_load(vr + i), m0 = __builtin_nontemporal_load(vi + i);
-      const V r1 = __builtin_nontemporal_load(vr + i2), m1 = __builtin_nontemporal_load(vi + i2);
-#pragma unroll
-      for (int c = 0; c < VE; ++c) acc += (double)r0[c] * (double)r0[c] + (double)m0[c] * (double)m0[c];
-      if (i2 != i) {
-#pragma unroll
-        for (int c = 0; c < VE; ++c) acc2 += (double)r1[c] * (double)r1[c] + (double)m1[c] * (double)m1[c];
-      }
-    }
-    acc += acc2;
-  } else {
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
-      const double r = re[i], m = im[i];
-      acc += r * r + m * m;
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0;
-    for (int w = 0; w < kBlock / 64; ++w) s += part[w];
-    atomicAdd(out, s);
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// probabilities / project: device side of the Measure and Projection functional gates
-// (hybridq/gate/measure.py:25-125, gate/projection.py:25-119), so that circuits containing
-// them need no D2H round trip of the state.
-// ---------------------------------------------------------------------------------
-struct BitsArg {
-  unsigned k;
-  unsigned pos[kMaxK];  // bit j of the outcome index <-> index bit pos[j]
-};
-
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-probabilities_kernel(const T* __restrict__ re, const T* __restrict__ im, const uint64_t size,
-                     const BitsArg ba, double* __restrict__ out /* 2^k, pre-zeroed */) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* bins = reinterpret_cast<double*>(smem);
-  const unsigned nb = 1u << ba.k;
-  for (unsigned i = threadIdx.x; i < nb; i += kBlock) bins[i] = 0.0;
-  __syncthreads();
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < size; x += stride) {
-    unsigned t = 0;
-    for (unsigned j = 0; j < ba.k; ++j) t |= (unsigned)((x >> ba.pos[j]) & 1ull) << j;
-    const double r = re[x], m = im[x];
-    atomicAdd(&bins[t], r * r + m * m);
-  }
-  __syncthreads();
-  for (unsigned i = threadIdx.x; i < nb; i += kBlock)
-    if (bins[i] != 0.0) atomicAdd(&out[i], bins[i]);
-}
-
-// Streaming variant for n >= 16: a workgroup walks chunks of 2^16 amplitudes as 16-byte vectors
-// (index = chunk : it[6 bits] : thread[8 bits] : component[CB bits]).  Measured bits in the
-// component / thread / chunk fields are constant per register, thread or chunk; only measured
-// bits in the 6 `it` bits change inside a chunk, and the loop is ordered so that they form the
-// OUTER loop: a thread sums a whole inner loop in registers and issues one LDS atomic per
-// (outer value, component class) instead of one per amplitude.
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-probabilities_stream_kernel(const T* __restrict__ re, const T* __restrict__ im, const unsigned n,
-                            const BitsArg ba, double* __restrict__ out /* 2^k, pre-zeroed */) {
-  using V = typename Vec<T>::type;
-  constexpr unsigned CB = Vec<T>::VB, NC = 1u << CB;
-  constexpr unsigned TB = 8, IB = 6, CHUNK = CB + TB + IB;  // bits of the thread / it fields; 2^CHUNK amplitudes per chunk
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* bins = reinterpret_cast<double*>(smem);
-  const unsigned nb = 1u << ba.k;
-  for (unsigned i = threadIdx.x; i < nb; i += kBlock) bins[i] = 0.0;
-  __syncthreads();
-  // outcome contributions of the fields
-  unsigned comp_t[NC];
-#pragma unroll
-  for (unsigned c = 0; c < NC; ++c) comp_t[c] = 0;
-  unsigned thr_t = 0, it_meas[IB], n_it_meas = 0, it_free[IB], n_it_free = 0, it_out[IB];
-  for (unsigned b = 0; b < IB; ++b) {
-    bool measured = false;
-    for (unsigned j = 0; j < ba.k; ++j)
-      if (ba.pos[j] == CB + TB + b) { it_meas[n_it_meas] = b; it_out[n_it_meas] = j; ++n_it_meas; measured = true; }
-    if (!measured) it_free[n_it_free++] = b;
-  }
-  for (unsigned j = 0; j < ba.k; ++j) {
-    const unsigned p = ba.pos[j];
-    if (p < CB) {
-#pragma unroll
-      for (unsigned c = 0; c < NC; ++c) comp_t[c] |= ((c >> p) & 1u) << j;
-    } else if (p < CB + TB) {
-      thr_t |= ((threadIdx.x >> (p - CB)) & 1u) << j;
-    }
-  }
-  const V* __restrict__ vre = reinterpret_cast<const V*>(re);
-  const V* __restrict__ vim = reinterpret_cast<const V*>(im);
-  const uint64_t nchunks = 1ull << (n - CHUNK);
-  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    unsigned hi_t = 0;
-    for (unsigned j = 0; j < ba.k; ++j)
-      if (ba.pos[j] >= CHUNK) hi_t |= (unsigned)((chunk >> (ba.pos[j] - CHUNK)) & 1ull) << j;
-    const uint64_t vbase = (chunk << (TB + IB)) + threadIdx.x;
-    for (unsigned om = 0; om < (1u << n_it_meas); ++om) {
-      unsigned it0 = 0, it_t = 0;
-      for (unsigned b = 0; b < n_it_meas; ++b) {
-        it0 |= ((om >> b) & 1u) << it_meas[b];
-        it_t |= ((om >> b) & 1u) << it_out[b];
-      }
-      double acc[NC];
-#pragma unroll
-      for (unsigned c = 0; c < NC; ++c) acc[c] = 0.0;
-      for (unsigned f = 0; f < (1u << n_it_free); ++f) {
-        unsigned it = it0;
-        for (unsigned b = 0; b < n_it_free; ++b) it |= ((f >> b) & 1u) << it_free[b];
-        const V r = __builtin_nontemporal_load(vre + vbase + ((uint64_t)it << TB));
-        const V m = __builtin_nontemporal_load(vim + vbase + ((uint64_t)it << TB));
-#pragma unroll
-        for (unsigned c = 0; c < NC; ++c) acc[c] += (double)r[c] * (double)r[c] + (double)m[c] * (double)m[c];
-      }
-      const unsigned t0 = hi_t | thr_t | it_t;
-      // components that fall into the same outcome are summed first
-#pragma unroll
-      for (unsigned c = 0; c < NC; ++c) {
-        bool first = true;
-        double sum = acc[c];
-#pragma unroll
-        for (unsigned d = 0; d < NC; ++d)
-          if (d != c && comp_t[d] == comp_t[c]) {
-            if (d < c) first = false; else sum += acc[d];
-          }
-        if (first) atomicAdd(&bins[t0 | comp_t[c]], sum);
-      }
-    }
-  }
-  __syncthreads();
-  for (unsigned i = threadIdx.x; i < nb; i += kBlock)
-    if (bins[i] != 0.0) atomicAdd(&out[i], bins[i]);
-}
-
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-project_kernel(T* __restrict__ re, T* __restrict__ im, const uint64_t size, const uint64_t mask,
-               const uint64_t want, const T scale) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < size; x += stride) {
-    const bool keep = (x & mask) == want;
-    re[x] = keep ? re[x] * scale : (T)0;
-    im[x] = keep ? im[x] * scale : (T)0;
-  }
-}
-
-// <a|b> = sum conj(a) b on split planes, accumulated in double: out[0] += sum(ar*br + ai*bi),
-// out[1] += sum(ar*bi - ai*br)   (expectation values, simulation.py:1125-1216)
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-vdot_kernel(const T* __restrict__ are, const T* __restrict__ aim, const T* __restrict__ bre,
-            const T* __restrict__ bim, const uint64_t size, double* __restrict__ out) {
-  __shared__ double part[2][kBlock / 64];
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  double sr = 0, si = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
-    const double ar = are[i], ai = aim[i], br = bre[i], bi = bim[i];
-    sr += ar * br + ai * bi;
-    si += ar * bi - ai * br;
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    sr += __shfl_down(sr, o, 64);
-    si += __shfl_down(si, o, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    part[0][threadIdx.x >> 6] = sr;
-    part[1][threadIdx.x >> 6] = si;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0, b = 0;
-    for (int w = 0; w < kBlock / 64; ++w) { a += part[0][w]; b += part[1][w]; }
-    atomicAdd(&out[0], a);
-    atomicAdd(&out[1], b);
-  }
 }
 
 }  // namespace hq

@@ -22,14 +22,14 @@ ALLOWED_SCRATCH = {
 
 @pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
 def test_no_kernel_spills(tmp_path):
-    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    src = os.path.join(ROOT, 'hybridq_amd', 'csrc', 'hq_hip.hip')
-    res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-                          '-Rpass-analysis=kernel-resource-usage', src, '-o', str(tmp_path / 'x.so')],
-                         capture_output=True, text=True)
-    assert res.returncode == 0, res.stderr[-2000:]
+    import sys
+    sys.path.insert(0, ROOT)
+    from hybridq_amd import build as hq_build
+    log = []  # every translation unit of the library, with the product's own flags
+    hq_build.build(force=True, extra_flags=['-Rpass-analysis=kernel-resource-usage'], lib=str(tmp_path / 'x.so'),
+                   objdir=str(tmp_path / 'obj'), log=log)
     names, scratch = [], []
-    for line in res.stderr.splitlines():
+    for line in '\n'.join(log).splitlines():
         m = re.search(r'remark:\s+Function Name: (\S+)', line)
         if m:
             names.append(m.group(1))

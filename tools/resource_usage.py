@@ -1,7 +1,7 @@
 """Summarise `hipcc -Rpass-analysis=kernel-resource-usage` output: one row per kernel
 (VGPRs, AGPRs, scratch bytes/lane, occupancy, LDS).  Usage:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Rpass-analysis=kernel-resource-usage \
-        hybridq_amd/csrc/hq_hip.hip -o /tmp/x.so 2> ru.txt ; python tools/resource_usage.py ru.txt
+    python -c "from hybridq_amd import build as b; log=[]; b.build(force=True, extra_flags=['-Rpass-analysis=kernel-resource-usage'], lib='/tmp/x.so', objdir='/tmp/xobj', log=log); open('ru.txt','w').write('\\n'.join(log))"
+    python tools/resource_usage.py ru.txt
 """
 import re
 import subprocess
