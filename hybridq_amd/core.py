@@ -136,6 +136,7 @@ _apply_blocked = {
 }
 
 _shard_unique_id = _define_function(_lib, 'hq_shard_unique_id', ctypes.c_int, ctypes.c_void_p)
+_shard_load_rccl = _define_function(_lib, 'hq_shard_load_rccl', ctypes.c_int)
 _shard_init_rccl = _define_function(_lib, 'hq_shard_init_rccl', ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p)
 _shard_attach_rccl = _define_function(_lib, 'hq_shard_attach_rccl', ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint)
 _shard_init_p2p = _define_function(_lib, 'hq_shard_init_p2p', ctypes.c_int, ctypes.c_uint, ctypes.c_uint)
@@ -183,7 +184,7 @@ EXPORTED = [
     'hq_probabilities_float32', 'hq_probabilities_float64', 'hq_project_float32', 'hq_project_float64',
     'hq_vdot_float32', 'hq_vdot_float64', 'hq_apply_blocked_float32', 'hq_apply_blocked_float64',
     'hq_program_begin', 'hq_program_end', 'hq_program_size', 'hq_program_run', 'hq_program_free',
-    'hq_shard_unique_id', 'hq_shard_init_rccl', 'hq_shard_attach_rccl', 'hq_shard_init_p2p', 'hq_shard_p2p_register',
+    'hq_shard_unique_id', 'hq_shard_load_rccl', 'hq_shard_init_rccl', 'hq_shard_attach_rccl', 'hq_shard_init_p2p', 'hq_shard_p2p_register',
     'hq_shard_info', 'hq_shard_free', 'hq_shard_rccl_selftest', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
     'hq_exchange_float32', 'hq_exchange_float64', 'hq_alloc', 'hq_free', 'hq_alloc_mapped', 'hq_alloc_scattered',
 ]
@@ -398,6 +399,11 @@ def shard_unique_id():
     buf = ctypes.create_string_buffer(128)
     _check(_shard_unique_id(buf), 'hq_shard_unique_id')
     return bytes(buf.raw)
+
+
+def shard_load_rccl():
+    """Bind librccl (dlopen + symbols) without creating anything: the part of the RCCL start-up a rank can fail alone."""
+    _check(_shard_load_rccl(), 'hq_shard_load_rccl')
 
 
 def shard_init_rccl(world, rank, unique_id):

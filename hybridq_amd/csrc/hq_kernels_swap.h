@@ -277,4 +277,161 @@ exchange_pack_kernel(const E* __restrict__ src0, const E* __restrict__ src1, con
   }
 }
 
+// ---------------------------------------------------------------------------------
+// bitperm_tile: ANY permutation of index bits in ONE HBM pass at full line granularity (round 3).
+//
+// dst[x] = src[pi(x)], dst bit i <-> src bit perm[i] (the convention of hq_permute_bits / swap_*).  The gather kernels
+// above read 16-byte vectors wherever the permutation sends them, so a moved low bit costs partial cache lines
+// (random permutation above bit 3: 2x the algorithmic read traffic, 3.15 TB/s), and low-bit swaps of more than 13 bits
+// took two full passes.  Here a workgroup owns a TILE of 2^tb elements spanned by the dst bits
+//     T = {0..c-1}  u  perm^-1({0..c-1})  (+ the next lowest dst bits / sources of the next lowest src bits up to tb),
+// c = 5 (4-byte) / 4 (8-byte elements): the tile is a union of >= 128-byte runs on BOTH sides.  It is read in SOURCE
+// order (tile-local source index u: bit k of u <-> src bit spos[k], 16-byte vectors of contiguous runs), dropped into LDS
+// linearly, read back in DESTINATION order (t: bit a <-> dst bit tpos[a]; u = sigma(t) is a bit permutation, so
+// every address is an XOR of per-thread, per-iteration and per-component terms computed once per kernel) and stored
+// as 16-byte vectors of contiguous runs.  A host-chosen XOR swizzle (source-index bits >= 5 folded into free bits
+// of [VB, 5)) spreads the element reads of a half-wave over the banks.  Out of place for any permutation; IN PLACE
+// (src == dst) whenever every moved bit lies inside the tile (low-bit swaps up to 15 bits: 128 KiB of LDS).
+// The destination may be split into 2^g chunks by its top g bits, each with its own base pointer (the multi-GPU
+// exchange: local send slots or the peers' receive buffers).
+// ---------------------------------------------------------------------------------
+constexpr int kBitPermMaxTile = 16;
+struct BitPermArg {
+  unsigned tb, m, cbits, planes;            // tile bits, index bits, m - g (chunk-local bits), planes per launch
+  unsigned char tpos[kBitPermMaxTile];      // dst positions of the tile bits, ascending
+  unsigned char spos[kBitPermMaxTile];      // src positions of the tile-local source index bits, ascending
+  unsigned char sigma[kBitPermMaxTile];     // dst-local bit a -> source-local bit
+  unsigned nsw;
+  unsigned char sw_hi[4], sw_lo[4];         // LDS element address ^= bit(u, sw_hi) << sw_lo
+  unsigned nfields;                         // tile base: runs of non-tile dst bits -> src bits
+  unsigned char f_from[48], f_to[48], f_len[48];
+  void* dst[kMaxShardRanks][2];             // [chunk][plane]
+};
+
+template <typename E, int BLOCK, int NV, bool VREAD, bool PREF>
+__global__ void __launch_bounds__(BLOCK)
+bitperm_tile_kernel(const E* __restrict__ src0, const E* __restrict__ src1, const BitPermArg a, const uint64_t ntiles) {
+  constexpr int VEC = 16 / (int)sizeof(E);
+  constexpr unsigned VB = VEC == 4 ? 2 : 1;
+  typedef E PackV __attribute__((ext_vector_type(VEC)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  E* buf = reinterpret_cast<E*>(smem);
+  __shared__ unsigned char* dptr[kMaxShardRanks][2];
+  const unsigned tid = threadIdx.x;
+  if (tid < 2 * kMaxShardRanks) dptr[tid >> 1][tid & 1] = reinterpret_cast<unsigned char*>(a.dst[tid >> 1][tid & 1]);
+  // ---- per-thread address terms (every map below is a bit permutation or an XOR of them: terms of disjoint parts of
+  // the thread's vector index combine by OR / XOR)
+  auto swz = [&](unsigned u) {
+    for (unsigned k = 0; k < a.nsw; ++k) u ^= ((u >> a.sw_hi[k]) & 1u) << a.sw_lo[k];
+    return u;
+  };
+  auto src_off = [&](unsigned u) {  // source-local index -> element offset inside the source plane
+    uint64_t y = 0;
+    for (unsigned k = VB; k < a.tb; ++k) y |= (uint64_t)((u >> k) & 1u) << a.spos[k];
+    return y;
+  };
+  auto dst_off = [&](unsigned t) {  // dst-local index -> dst index bits
+    uint64_t x = 0;
+    for (unsigned k = VB; k < a.tb; ++k) x |= (uint64_t)((t >> k) & 1u) << a.tpos[k];
+    return x;
+  };
+  auto sig = [&](unsigned t) {  // dst-local index -> (swizzled) LDS element address of its source
+    unsigned u = 0;
+    for (unsigned k = 0; k < a.tb; ++k) u |= ((t >> k) & 1u) << a.sigma[k];
+    return swz(u);
+  };
+  // thread part (VGPRs) and iteration part (wave-uniform: SGPRs) of every address
+  const unsigned e_tid = tid << VB;  // first element of the thread's vector 0, in either order
+  const uint64_t y_tid = src_off(e_tid), x_tid = dst_off(e_tid);
+  const unsigned w_tid = swz(e_tid), r_tid = sig(e_tid);
+  uint64_t y_it[NV], x_it[NV];
+  unsigned w_it[NV], r_it[NV], rc[VEC];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const unsigned e = ((unsigned)i * BLOCK) << VB;
+    y_it[i] = src_off(e);
+    w_it[i] = swz(e);
+    x_it[i] = dst_off(e);
+    r_it[i] = sig(e);
+  }
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) rc[c] = sig((unsigned)c);
+  const uint64_t wmask = (1ull << a.cbits) - 1;
+  auto bases = [&](uint64_t h, uint64_t& xb, uint64_t& yb) {
+    xb = h;  // deposit the tile number into the non-tile dst bits
+    for (unsigned k = 0; k < a.tb; ++k) {
+      const uint64_t lo = (1ull << a.tpos[k]) - 1;
+      xb = ((xb & ~lo) << 1) | (xb & lo);
+    }
+    yb = 0;
+    for (unsigned f = 0; f < a.nfields; ++f) yb |= ((xb >> a.f_from[f]) & ((1ull << a.f_len[f]) - 1)) << a.f_to[f];
+  };
+  const uint64_t total = ntiles * a.planes;
+  auto load_tile = [&](uint64_t ht, PackV (&v)[NV]) {
+    const uint64_t h = ht < ntiles ? ht : ht - ntiles;
+    const E* __restrict__ sp = ht < ntiles ? src0 : src1;
+    uint64_t xb, yb;
+    bases(h, xb, yb);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = __builtin_nontemporal_load(reinterpret_cast<const PackV*>(sp + (yb | y_tid | y_it[i])));
+  };
+  auto fill = [&](const PackV (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<PackV*>(buf + (w_tid ^ w_it[i])) = v[i];
+  };
+  auto permute_store = [&](uint64_t ht) {
+    const uint64_t h = ht < ntiles ? ht : ht - ntiles;
+    const unsigned plane = ht < ntiles ? 0u : 1u;
+    uint64_t xb, yb;
+    bases(h, xb, yb);
+    constexpr int CH = NV < 4 ? NV : 4;  // LDS reads and stores in batches of four vectors (16 live result registers)
+#pragma unroll
+    for (int i0 = 0; i0 < NV; i0 += CH) {
+      PackV o[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int i = i0 + j;
+        if constexpr (VREAD) {
+          o[j] = *reinterpret_cast<const PackV*>(buf + (r_tid ^ r_it[i]));
+        } else {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) o[j][c] = buf[r_tid ^ r_it[i] ^ rc[c]];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const uint64_t x = xb | x_tid | x_it[i0 + j];
+        E* dp = reinterpret_cast<E*>(dptr[x >> a.cbits][plane]) + (x & wmask);
+        __builtin_nontemporal_store(o[j], reinterpret_cast<PackV*>(dp));
+      }
+    }
+  };
+  if constexpr (PREF) {
+    // one or two workgroups per CU: the next tile is requested into registers while this one is permuted and stored
+    // (unconditional prefetch on a clamped tile number, LDS fill after the stores: the recipe of apply_blocked_kernel)
+    if (blockIdx.x >= total) return;
+    const uint64_t stride = gridDim.x;
+    PackV pr[NV];
+    load_tile(blockIdx.x, pr);
+    fill(pr);
+    load_tile(blockIdx.x + stride < total ? blockIdx.x + stride : blockIdx.x, pr);
+    for (uint64_t ht = blockIdx.x; ht < total; ht += stride) {
+      __syncthreads();
+      permute_store(ht);
+      __syncthreads();
+      fill(pr);
+      load_tile(ht + 2 * stride < total ? ht + 2 * stride : ht, pr);
+    }
+  } else {
+    for (uint64_t ht = blockIdx.x; ht < total; ht += gridDim.x) {
+      PackV v[NV];
+      load_tile(ht, v);
+      __syncthreads();  // the previous tile's LDS reads are done (and dptr is visible)
+      fill(v);
+      __syncthreads();
+      permute_store(ht);
+    }
+  }
+}
+
 }  // namespace hq

@@ -1,6 +1,7 @@
 // hq_shard.hip -- multi-GPU: high-qubit shards and the qubit exchange (hq_shard_*, hq_exchange_*, hq_ipc_*).
 #include "hq_common.h"
 #include "hq_kernels_swap.h"
+#include "hq_bitperm.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is dlopen()ed (hq_shard_init_rccl)
@@ -34,6 +35,7 @@ struct Shard {
   struct Peers { const void* local; void* peer[kMaxShardRanks]; };
   std::vector<Peers> registry;
   double last_ms = 0;
+  unsigned epoch = 0;  // bumped by hq_shard_free: a communicator creation that returns afterwards is discarded
 };
 
 static Shard& shard() {
@@ -99,13 +101,28 @@ static int copy16(Context& c, hipStream_t s, void* dst, const void* src, size_t 
   return 0;
 }
 
+// `perm`: the local bit permutation of the pack pass (m entries) or nullptr
 template <typename E>
-static int launch_pack(Context& c, hipStream_t s, const E* s0, const E* s1, const ExchArg& a) {
+static int launch_pack(Context& c, hipStream_t s, const E* s0, const E* s1, const ExchArg& a, const unsigned* perm) {
   const uint64_t size = 1ull << a.m;
   const bool al = reinterpret_cast<uintptr_t>(s0) % 16 == 0 && (!s1 || reinterpret_cast<uintptr_t>(s1) % 16 == 0);
   bool dal = true;
   for (unsigned j = 0; j < (1u << a.g); ++j)
     for (unsigned p = 0; p < a.planes; ++p) dal = dal && reinterpret_cast<uintptr_t>(a.dst[j][p]) % 16 == 0;
+  static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
+  static const bool tile_always = getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 2;
+  if (one_pass && al && dal && perm && (tile_always || !bitperm_low_run_fixed<E>(perm, a.m))) {
+    // the eviction permutation at full cache-line granularity on both sides (bitperm_tile_kernel); the gather kernel
+    // below stays for shards smaller than a tile
+    BitPermPlan P;
+    if (plan_bitperm<E>(perm, a.m, false, P)) {
+      P.a.cbits = a.m - a.g;
+      P.a.planes = a.planes;
+      for (unsigned j = 0; j < (1u << a.g); ++j)
+        for (unsigned p = 0; p < a.planes; ++p) P.a.dst[j][p] = a.dst[j][p];
+      return launch_bitperm<E>(c, s, false, s0, s1, P);
+    }
+  }
   constexpr int VEC = 16 / (int)sizeof(E);
   const bool lowfixed = (a.perm.fixed_mask & (VEC - 1)) == (uint64_t)(VEC - 1) && a.m - a.g >= 2;
   if (al && dal && lowfixed) {
@@ -172,7 +189,7 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
     a.planes = 2;
     a.dst[0][0] = D[0];
     a.dst[0][1] = D[1];
-    if (launch_pack<E>(c, c.stream, src_re, src_im, a)) return 1;
+    if (launch_pack<E>(c, c.stream, src_re, src_im, a, has_perm ? perm : nullptr)) return 1;
     *result_in_src = 0;
     return 0;
   }
@@ -191,7 +208,7 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
       a.dst[j][0] = reinterpret_cast<unsigned char*>(pr->peer[j]) + (size_t)sh.rank * chunk;
       a.dst[j][1] = reinterpret_cast<unsigned char*>(pi->peer[j]) + (size_t)sh.rank * chunk;
     }
-    if (launch_pack<E>(c, c.stream, src_re, src_im, a)) return 1;
+    if (launch_pack<E>(c, c.stream, src_re, src_im, a, has_perm ? perm : nullptr)) return 1;
     *result_in_src = 0;
     return 0;
   }
@@ -226,7 +243,7 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
   a.planes = 1;
   for (int p = 0; p < 2; ++p) {
     for (unsigned j = 0; j < G; ++j) a.dst[j][0] = D[p] + (size_t)j * chunk;
-    if (launch_pack<E>(c, c.stream, reinterpret_cast<const E*>(S[p]), (const E*)nullptr, a)) return 1;
+    if (launch_pack<E>(c, c.stream, reinterpret_cast<const E*>(S[p]), (const E*)nullptr, a, perm)) return 1;
     HQ_HIP_CHECK(hipEventRecord(sh.ev[p], c.stream));
     HQ_HIP_CHECK(hipStreamWaitEvent(cs, sh.ev[p], 0));
     HQ_NCCL_CHECK(sh, sh.api.GroupStart());
@@ -258,18 +275,39 @@ int hq_shard_unique_id(void* id128) {
   return 0;
 }
 
-int hq_shard_init_rccl(unsigned int world, unsigned int rank, const void* id128) {
+int hq_shard_load_rccl(void) {
   hq::Context& c = hq::ctx();
   std::lock_guard<std::mutex> lock(c.mu);
+  return hq::load_rccl(hq::shard());
+}
+
+int hq_shard_init_rccl(unsigned int world, unsigned int rank, const void* id128) {
+  hq::Context& c = hq::ctx();
   hq::Shard& sh = hq::shard();
-  if (hq::shard_common_init(c, sh, world, rank)) return 1;
-  if (world == 1 && !id128) { sh.transport = 0; return 0; }
-  if (!id128) return hq::fail("hq_shard_init_rccl: null id");
-  if (hq::load_rccl(sh)) return 1;
-  if (sh.comm && sh.own_comm) { (void)sh.api.CommDestroy(sh.comm); sh.comm = nullptr; }
   ncclUniqueId id;
-  memcpy(&id, id128, sizeof(id));
-  HQ_NCCL_CHECK(sh, sh.api.CommInitRank(&sh.comm, (int)world, id, (int)rank));
+  unsigned epoch = 0;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (hq::shard_common_init(c, sh, world, rank)) return 1;
+    if (world == 1 && !id128) { sh.transport = 0; return 0; }
+    if (!id128) return hq::fail("hq_shard_init_rccl: null id");
+    if (hq::load_rccl(sh)) return 1;
+    if (sh.comm && sh.own_comm) { (void)sh.api.CommDestroy(sh.comm); sh.comm = nullptr; }
+    memcpy(&id, id128, sizeof(id));
+    epoch = sh.epoch;
+  }
+  // ncclCommInitRank is collective and blocks until every rank has arrived: the context lock is NOT held meanwhile,
+  // so that a caller who gave up waiting (hybridq_amd.dist runs this in a helper thread with a timeout) can still use
+  // the library -- and cancel this creation with hq_shard_free
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = sh.api.CommInitRank(&comm, (int)world, id, (int)rank);
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (r != ncclSuccess) return hq::fail(std::string("ncclCommInitRank: ") + sh.api.GetErrorString(r));
+  if (epoch != sh.epoch) {  // cancelled while we were inside
+    (void)sh.api.CommDestroy(comm);
+    return hq::fail("hq_shard_init_rccl: cancelled by hq_shard_free");
+  }
+  sh.comm = comm;
   sh.own_comm = true;
   sh.transport = world > 1 ? 1 : 0;  // a one-rank communicator is legal (hq_shard_rccl_selftest); the exchange needs none
   return 0;
@@ -355,6 +393,7 @@ int hq_shard_free(void) {
   sh.comm = nullptr;
   sh.own_comm = false;
   sh.registry.clear();
+  ++sh.epoch;
   sh.transport = 0;
   sh.world = 1;
   sh.rank = 0;

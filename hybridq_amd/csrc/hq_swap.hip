@@ -3,6 +3,7 @@
 #include "hq_common.h"
 #include "hq_kernels_aux.h"
 #include "hq_kernels_swap.h"
+#include "hq_bitperm.h"
 
 namespace hq {
 
@@ -116,6 +117,19 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
   const unsigned table_bits = sizeof(E) == 4 ? 13 : 12;  // 32 KiB of elements + index table
   const unsigned max_lds_bits = sizeof(E) == 4 ? 15 : 14;  // 128 KiB of elements, index computed inline
   static const bool two_pass = !(getenv("HQ_SWAP_TWO_PASS") && atoi(getenv("HQ_SWAP_TWO_PASS")) == 0);
+  static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
+  static const unsigned tile_min = getenv("HQ_SWAP_TILE_MIN") ? (unsigned)atoi(getenv("HQ_SWAP_TILE_MIN")) : 0;
+  if ((s > table_bits || (tile_min && s >= tile_min)) && one_pass && reinterpret_cast<uintptr_t>(a) % 16 == 0) {
+    // s = 14, 15 (13, 14 for 8-byte elements): the whole 2^s chunk is ONE LDS tile (64 / 128 KiB) of bitperm_tile_kernel,
+    // permuted in place in a single HBM pass (round 2: two passes through 32 KiB tiles = 2x the algorithmic traffic)
+    std::vector<unsigned> full(n);
+    for (unsigned i = 0; i < n; ++i) full[i] = i < s ? pos[i] : i;
+    BitPermPlan P;
+    if (plan_bitperm<E>(full.data(), n, true, P)) {
+      P.a.dst[0][0] = a;
+      return launch_bitperm<E>(c, c.stream, true, (const E*)a, (const E*)nullptr, P);
+    }
+  }
   if (s > table_bits && two_pass && reinterpret_cast<uintptr_t>(a) % 16 == 0) {
     // 14 <= s <= 18 (17 for 8-byte elements): two in-place passes through 32 KiB LDS tiles, each at the rate of
     // the small-s kernel, instead of one 128 KiB-tile pass with the index computed inline (2.1 TB/s) or the
@@ -225,6 +239,18 @@ static int permute_bits_entry(const E* src, E* dst, const unsigned* perm, unsign
     pa.len[pa.nfields] = (unsigned char)len;
     ++pa.nfields;
     i += len;
+  }
+  static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
+  static const bool tile_always = getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 2;
+  if (one_pass && (tile_always || !bitperm_low_run_fixed<E>(perm, n)) && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
+      reinterpret_cast<uintptr_t>(dst) % 16 == 0) {
+    // one pass at full cache-line granularity on both sides, whatever bits move (bitperm_tile_kernel); the gather
+    // kernel below stays for states smaller than a tile and unaligned pointers
+    BitPermPlan P;
+    if (plan_bitperm<E>(perm, n, false, P)) {
+      P.a.dst[0][0] = dst;
+      return launch_bitperm<E>(c, c.stream, true, src, (const E*)nullptr, P);
+    }
   }
   const uint64_t size = 1ull << n;
   const bool vec16 = (pa.fixed_mask & 3) == 3 && n >= 2 && sizeof(E) == 4 &&

@@ -212,29 +212,66 @@ def fuse_evictions(schedule):
 # ------------------------------------------------------------------------------------
 # backends
 # ------------------------------------------------------------------------------------
-def exchange_selftest(torch, tdt, device, world, rank, exchange):
+def exchange_selftest(torch, tdt, device, world, rank, exchange, buffers=None):
     """Run ``exchange(src, dst, perm, m) -> result_in_src`` (collective) once without and once with a local
     permutation on rank-tagged data and check every received chunk: chunk j of the result must be chunk `rank` of
     rank j's (permuted) source.  Raises RuntimeError on a mismatch.  Transport-agnostic: the CPU test-suite runs it
-    over gloo with the host backend, HipBackend runs it on a fresh RCCL communicator."""
+    over gloo with the host backend, HipBackend runs it on a fresh RCCL communicator.
+
+    ``buffers`` = the rank's two REAL shard buffers ((2, 2^m) plane pairs, contents are overwritten): the test then
+    moves the very memory the run will move -- same allocator, same size class (a self-test on
+    torch.empty memory proves nothing about library-mapped planes).  Without them two small torch buffers are used."""
     g = int(np.log2(world))
-    m = max(2 * g + 2, 12)
+    if buffers is not None:
+        src, dst = buffers
+        m = int(src.shape[1]).bit_length() - 1
+    else:
+        m = max(2 * g + 2, 12)
+        src = torch.empty((2, 1 << m), dtype=tdt, device=device)
+        dst = torch.zeros_like(src)
     chunk = (1 << m) >> g
-    src = torch.empty((2, 1 << m), dtype=tdt, device=device)
-    dst = torch.zeros_like(src)
-    idx = torch.arange(1 << m, device=device)
+    step = min(1 << m, 1 << 24)  # fill and check in slices: no index array of the shard's size
+
+    def tag(lo, hi, r):  # exactly representable, rank-tagged
+        return (torch.arange(lo, hi, device=device) % 4096).to(tdt) + 4096.0 * r
+
     for perm in (None, np.concatenate([[1, 0], np.arange(2, m)]).astype(np.uint32)):
-        src[0] = (idx % 4096).to(tdt) + 4096.0 * rank  # exactly representable, rank-tagged
-        src[1] = -src[0]
+        for lo in range(0, 1 << m, step):
+            src[0, lo:lo + step] = tag(lo, lo + step, rank)
+            src[1, lo:lo + step] = -src[0, lo:lo + step]
         got = src if exchange(src, dst, perm, m) else dst
-        x = idx[rank * chunk:(rank + 1) * chunk]
-        if perm is not None:  # bits 0 and 1 swapped (its own inverse: independent of the direction convention)
-            x = (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1)
+        cstep = min(chunk, step)
         for j in range(world):
-            want = (x % 4096).to(tdt) + 4096.0 * j
-            if not torch.equal(got[0, j * chunk:(j + 1) * chunk], want) or \
-                    not torch.equal(got[1, j * chunk:(j + 1) * chunk], -want):
-                raise RuntimeError(f'exchange self-test: wrong data in chunk {j}' + (' (with permutation)' if perm is not None else ''))
+            for lo in range(0, chunk, cstep):
+                x = torch.arange(rank * chunk + lo, rank * chunk + lo + cstep, device=device)
+                if perm is not None:  # bits 0 and 1 swapped (its own inverse: independent of the direction convention)
+                    x = (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1)
+                want = (x % 4096).to(tdt) + 4096.0 * j
+                sl = slice(j * chunk + lo, j * chunk + lo + cstep)
+                if not torch.equal(got[0, sl], want) or not torch.equal(got[1, sl], -want):
+                    raise RuntimeError(f'exchange self-test: wrong data in chunk {j}' + (' (with permutation)' if perm is not None else ''))
+
+
+def _call_with_timeout(fn, seconds, what):
+    """Run fn() in a helper thread and give up after `seconds`: a collective whose peers never arrive (one rank failed
+    before entering it) must not hang this rank.  The abandoned thread is a daemon."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box['value'] = fn()
+        except BaseException as e:  # noqa: BLE001
+            box['error'] = e
+
+    t = threading.Thread(target=run, daemon=True, name=f'hq-{what}')
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise TimeoutError(f'{what} did not finish within {seconds:.0f} s')
+    if 'error' in box:
+        raise box['error']
+    return box.get('value')
 
 
 class HipBackend:
@@ -281,8 +318,28 @@ class HipBackend:
         return alloc_planes(m, self.tdt, self.device, vmm=self.placement == 'tuned' and self._wanted_transport() != 'p2p')
 
     # -- exchange transport ---------------------------------------------------------------
+    #: seconds a rank waits inside the collective parts of the RCCL start-up (communicator creation, self-test) before
+    #: it gives up and votes for the fallback (env HQ_SHARD_TIMEOUT)
+    SETUP_TIMEOUT = 120.0
+
+    def _agree(self, group, error):
+        """Collective over the torch process group: every rank reports its own failure ('' = fine); returns the first
+        failure anywhere, so that all ranks take the same branch."""
+        reports = [None] * self.world
+        self.dist.all_gather_object(reports, '' if error is None else repr(error), group=group)
+        bad = [(r, e) for r, e in enumerate(reports) if e]
+        return None if not bad else f'rank {bad[0][0]}: {bad[0][1]}'
+
     def setup_exchange(self, group, buffers):
-        """Collective.  `buffers`: the rank's two shard buffers (each a (2, 2^m) plane pair)."""
+        """Collective.  `buffers`: the rank's two shard buffers (each a (2, 2^m) plane pair).
+
+        Failure-safe start-up of the RCCL transport: (1) everything a rank can check ALONE
+        (librccl loads, the unique id exists) is checked and agreed on over the torch process group BEFORE anybody
+        enters ncclCommInitRank; (2) the communicator is created and (3) a real exchange -- with and without a
+        permutation, every chunk checked -- is run on the REAL shard buffers, each in a helper thread with a timeout, so
+        that a rank whose peers never arrive raises instead of waiting forever; after each phase the ranks agree again.
+        Any failure anywhere sends ALL ranks to the torch.distributed fallback together."""
+        import os
         dist = self.dist
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -293,45 +350,99 @@ class HipBackend:
         want = self.transport
         if want == 'auto':
             want = 'rccl' if dist.get_backend(group) == 'nccl' else 'p2p'
-        try:
-            if want == 'rccl':
-                uid = [self.core.shard_unique_id() if rank == 0 else None]
+        if want not in ('rccl', 'p2p', 'torch'):
+            raise ValueError(f'unknown exchange transport {want!r}')
+        timeout = float(os.environ.get('HQ_SHARD_TIMEOUT', self.SETUP_TIMEOUT))
+        failure = None
+        if want == 'rccl':
+            # phase 1 (local): the library binds librccl, rank 0 draws the unique id
+            err, uid = None, [None]
+            try:
+                self.core.shard_load_rccl()
+                if rank == 0:
+                    uid[0] = self.core.shard_unique_id()
+            except Exception as e:  # noqa: BLE001
+                err = e
+            failure = self._agree(group, err)
+            if failure is None:
                 dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                self.core.shard_init_rccl(world, rank, uid[0])
-                self._rccl_selftest(world, rank)
-            elif want == 'p2p':
-                self._setup_p2p(group, buffers)
-            elif want != 'torch':
-                raise ValueError(f'unknown exchange transport {want!r}')
-        except Exception as e:  # noqa: BLE001 -- every rank takes the same branch: the failure modes are collective
-            ok = [None] * world
-            dist.all_gather_object(ok, repr(e), group=group)
-            self.transport_note = f'{want} transport unavailable ({e!r}); using torch.distributed collectives'
+                # phase 2 (collective, may block on a missing peer): the communicator
+                err = None
+                try:
+                    dev = self.torch.cuda.current_device()
+
+                    def init():
+                        self.torch.cuda.set_device(dev)  # the HIP device is per thread
+                        self.core.shard_init_rccl(world, rank, uid[0])
+                    _call_with_timeout(init, timeout, 'ncclCommInitRank')
+                except BaseException as e:  # noqa: BLE001
+                    err = e
+                failure = self._agree(group, err)
+            if failure is None:
+                # phase 3: a real exchange on the real shard buffers
+                err = None
+                try:
+                    self._rccl_selftest(world, rank, buffers, timeout)
+                except BaseException as e:  # noqa: BLE001
+                    err = e
+                failure = self._agree(group, err)
+            if failure is not None:
+                try:
+                    self.core.shard_free()  # also cancels a communicator creation that is still pending
+                except Exception:  # noqa: BLE001
+                    pass
+        elif want == 'p2p':
+            # the same discipline: local step (export the planes), agree, collective step (gather the handles), local
+            # step (map the peers' planes), agree
+            err, mine = None, None
+            try:
+                mine = self._p2p_export(buffers)
+            except Exception as e:  # noqa: BLE001
+                err = e
+            failure = self._agree(group, err)
+            if failure is None:
+                everyone = [None] * world
+                dist.all_gather_object(everyone, [(h, o) for h, o, _ in mine], group=group)
+                err = None
+                try:
+                    self._p2p_map(buffers, everyone)
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                failure = self._agree(group, err)
+        if failure is not None:
+            self.transport_note = f'{want} transport unavailable ({failure}); using torch.distributed collectives'
             want = 'torch'
-        else:
-            ok = [None] * world
-            dist.all_gather_object(ok, '', group=group)
-            if any(ok):  # some other rank failed: everybody falls back together
-                self.transport_note = f'{want} transport unavailable on a peer ({[o for o in ok if o][0]}); using torch.distributed collectives'
-                want = 'torch'
         self.transport = want
 
-    def _rccl_selftest(self, world, rank):
-        """One small real exchange through hq_exchange_* right after the communicator exists (exchange_selftest): a
-        transport that errors or delivers the wrong chunks is detected HERE, where every rank can still agree on
-        the torch fallback."""
+    def _rccl_selftest(self, world, rank, buffers=None, timeout=None):
+        """One real exchange through hq_exchange_* right after the communicator exists (exchange_selftest), on the
+        shard buffers themselves: a transport that errors, delivers the wrong chunks or never completes is detected
+        HERE, where every rank can still agree on the torch fallback."""
+        torch = self.torch
+
         def ex(src, dst, perm, m):
             in_src = self.core.exchange(src[0], src[1], dst[0], dst[1], perm, m)
-            self.core.sync()
+            done = torch.cuda.Event()
+            done.record()  # the library runs on torch's current stream
+            import time
+            t0 = time.monotonic()
+            while not done.query():  # poll: hipStreamSynchronize on a stuck transfer would never return
+                if timeout is not None and time.monotonic() - t0 > timeout:
+                    raise TimeoutError(f'the exchange self-test did not complete within {timeout:.0f} s')
+                time.sleep(0.002)
             return in_src
-        exchange_selftest(self.torch, self.tdt, self.device, world, rank, ex)
+        use = None
+        if buffers is not None and len(buffers) == 2 and buffers[0] is not None and buffers[1] is not None:
+            use = (buffers[0], buffers[1])
+        exchange_selftest(torch, self.tdt, self.device, world, rank, ex, buffers=use)
 
-    def _setup_p2p(self, group, buffers):
-        core, dist = self.core, self.dist
+    def _p2p_export(self, buffers):
         planes = [b[p] for b in buffers for p in (0, 1)]
-        mine = [core.ipc_export(t) + (t.data_ptr(),) for t in planes]  # (handle, offset, local address)
-        everyone = [None] * self.world
-        dist.all_gather_object(everyone, [(h, o) for h, o, _ in mine], group=group)
+        return [self.core.ipc_export(t) + (t.data_ptr(),) for t in planes]  # (handle, offset, local address)
+
+    def _p2p_map(self, buffers, everyone):
+        core = self.core
+        planes = [b[p] for b in buffers for p in (0, 1)]
         core.shard_init_p2p(self.world, self.rank)
         opened = HipBackend._ipc_mappings  # process-wide: an exported allocation is mapped once
         for i, t in enumerate(planes):

@@ -189,6 +189,10 @@ int hq_permute_bits_64(const void *src, void *dst, const unsigned int *perm, uns
  * self chunk is copied by an own kernel, and with a permutation the transfer of the re plane overlaps
  * the packing of the im plane on a second stream. */
 int hq_shard_unique_id(void *id128);
+/* Binds librccl (dlopen + symbol lookup) and nothing else: the part of the RCCL start-up a rank can fail ALONE, so that
+ * the ranks can agree on it before anybody enters the collective hq_shard_init_rccl (which blocks until every rank has
+ * arrived; it does not hold the library lock meanwhile, and hq_shard_free from another thread cancels it). */
+int hq_shard_load_rccl(void);
 int hq_shard_init_rccl(unsigned int world, unsigned int rank, const void *id128);
 int hq_shard_attach_rccl(void *nccl_comm, unsigned int world, unsigned int rank);
 int hq_shard_init_p2p(unsigned int world, unsigned int rank);
