@@ -166,6 +166,12 @@ _alloc_mapped = _define_function(_lib, 'hq_alloc_mapped', ctypes.c_int, ctypes.P
 _alloc_scattered = _define_function(_lib, 'hq_alloc_scattered', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64,
                                     ctypes.c_uint64, ctypes.c_uint64)
 
+_alloc_state = _define_function(_lib, 'hq_alloc_state', ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
+                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p))
+_free_state = _define_function(_lib, 'hq_free_state', ctypes.c_int, ctypes.c_void_p)
+_state_info = _define_function(_lib, 'hq_state_info', ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64)
+_state_pool_trim = _define_function(_lib, 'hq_state_pool_trim', ctypes.c_int)
+
 _program_begin = _define_function(_lib, 'hq_program_begin', ctypes.c_int)
 _program_end = _define_function(_lib, 'hq_program_end', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p))
 _program_size = _define_function(_lib, 'hq_program_size', ctypes.c_int, ctypes.c_void_p)
@@ -187,6 +193,7 @@ EXPORTED = [
     'hq_shard_unique_id', 'hq_shard_load_rccl', 'hq_shard_init_rccl', 'hq_shard_attach_rccl', 'hq_shard_init_p2p', 'hq_shard_p2p_register',
     'hq_shard_info', 'hq_shard_free', 'hq_shard_rccl_selftest', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
     'hq_exchange_float32', 'hq_exchange_float64', 'hq_alloc', 'hq_free', 'hq_alloc_mapped', 'hq_alloc_scattered',
+    'hq_alloc_state', 'hq_free_state', 'hq_state_info', 'hq_state_pool_trim',
 ]
 
 
@@ -512,6 +519,49 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+STATE_PLAIN, STATE_NO_SEARCH, STATE_NO_POOL = 1, 2, 4
+
+
+class StatePlanes:
+    """Both planes of an n-qubit state from hq_alloc_state (tuned placement for states >= 256 MiB, pooled per size).
+    ``torch.as_tensor(obj, device='cuda')`` aliases it as a (2, stride) tensor whose rows start at the re / im planes
+    (`as_tensor` keeps this object alive); the memory goes back through hq_free_state when it dies."""
+
+    def __init__(self, n_qubits, float_dtype, flags=0):
+        ft = np.dtype(float_dtype)
+        re, im = ctypes.c_void_p(None), ctypes.c_void_p(None)
+        _check(_alloc_state(int(n_qubits), 8 * ft.itemsize, int(flags), ctypes.byref(re), ctypes.byref(im)), 'hq_alloc_state')
+        self.re, self.im = int(re.value), int(im.value)
+        self.n_qubits = int(n_qubits)
+        self.stride = (self.im - self.re) // ft.itemsize
+        self.info = state_info(self.re)
+        self.__cuda_array_interface__ = {'shape': (2, self.stride), 'typestr': '<f4' if ft.itemsize == 4 else '<f8',
+                                         'data': (self.re, False), 'version': 2, 'strides': None}
+
+    def free(self):
+        if self.re:
+            _free_state(ctypes.c_void_p(self.re))
+            self.re = self.im = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def state_info(psi_re=None):
+    """Placement report of a state (address of its re plane) or of the last hq_alloc_state (None), as a dict."""
+    import json
+    buf = ctypes.create_string_buffer(1 << 16)
+    _check(_state_info(ctypes.c_void_p(psi_re) if psi_re else None, buf, len(buf)), 'hq_state_info')
+    return json.loads(buf.value.decode() or '{}')
+
+
+def state_pool_trim():
+    _check(_state_pool_trim(), 'hq_state_pool_trim')
 
 
 def pack_blocked(gates, complex_type='complex64'):

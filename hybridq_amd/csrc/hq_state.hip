@@ -139,6 +139,323 @@ static int vdot_entry(const T* are, const T* aim, const T* bre, const T* bim, ui
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------
+// state memory: VMM-mapped placements, the draw-probe-keep search and the pool of winning placements
+// ---------------------------------------------------------------------------------
+// A VA-contiguous buffer whose physical granules (hipMemCreate, `granule` bytes each) are mapped in a chosen order.
+struct Vmm {
+  void* va = nullptr;
+  size_t size = 0, granule = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+  size_t mapped = 0;     // granules currently mapped
+  bool touched = false;  // the range has held a mapping at some point (never handed back: see vmm_destroy)
+};
+static std::vector<Vmm>& vmm_registry() { static std::vector<Vmm> r; return r; }
+
+static hipMemAllocationProp vmm_prop(const Context& c) {
+  hipMemAllocationProp prop;
+  memset(&prop, 0, sizeof(prop));
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = c.device;
+  return prop;
+}
+
+static int vmm_granule_min(const Context& c, size_t* gmin) {
+  const hipMemAllocationProp prop = vmm_prop(c);
+  HQ_HIP_CHECK(hipMemGetAllocationGranularity(gmin, &prop, hipMemAllocationGranularityMinimum));
+  return 0;
+}
+
+// Releases the physical granules.  The virtual range is NOT given back (hipMemAddressFree) unless HQ_VMM_FREE_VA=1:
+// on this stack (ROCm 7.0 runtime under torch, tools/vmm_integrity.py) a range that is unmapped and immediately
+// reserved + mapped again keeps stale translations -- reads and writes land in the old granules.  Address space is 47
+// bits wide; the pool below makes retirements rare (one search per state size and process).
+static void vmm_destroy(Vmm& v) {
+  if (v.va && v.mapped) (void)hipMemUnmap(v.va, v.size);
+  for (auto h : v.handles) (void)hipMemRelease(h);
+  static const bool free_va = getenv("HQ_VMM_FREE_VA") && atoi(getenv("HQ_VMM_FREE_VA")) != 0;
+  if (v.va && (free_va || !v.touched)) (void)hipMemAddressFree(v.va, v.size);  // a range that never held a mapping is safe to return
+  v = Vmm();
+}
+
+// granule i (creation order) -> virtual slot order[i].  Every failure releases what was created.
+static int vmm_create(const Context& c, size_t granule, const std::vector<size_t>& order, Vmm& out) {
+  const size_t ng = order.size();
+  Vmm v;
+  v.granule = granule;
+  v.size = ng * granule;
+  hipError_t e = hipMemAddressReserve(&v.va, v.size, (size_t)1 << 21, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hipMemAddressReserve: ") + hipGetErrorString(e)); }
+  const hipMemAllocationProp prop = vmm_prop(c);
+  v.handles.reserve(ng);
+  for (size_t i = 0; i < ng && e == hipSuccess; ++i) {  // physical granules are created in sequence ...
+    hipMemGenericAllocationHandle_t h;
+    e = hipMemCreate(&h, granule, &prop, 0);
+    if (e == hipSuccess) v.handles.push_back(h);
+  }
+  const char* what = "hipMemCreate";
+  if (e == hipSuccess) {
+    what = "hipMemMap";
+    for (size_t i = 0; i < ng && e == hipSuccess; ++i) {  // ... and mapped at the chosen virtual slots
+      e = hipMemMap(reinterpret_cast<unsigned char*>(v.va) + order[i] * granule, granule, 0, v.handles[i], 0);
+      if (e == hipSuccess) { v.mapped = i + 1; v.touched = true; }
+    }
+  }
+  if (e == hipSuccess) {
+    what = "hipMemSetAccess";
+    hipMemAccessDesc acc;
+    memset(&acc, 0, sizeof(acc));
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = c.device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(v.va, v.size, &acc, 1);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (v.mapped) {  // unmap granule by granule what was mapped (a partial range cannot be unmapped in one call)
+      for (size_t i = 0; i < v.mapped; ++i)
+        (void)hipMemUnmap(reinterpret_cast<unsigned char*>(v.va) + order[i] * granule, granule);
+      v.mapped = 0;
+    }
+    vmm_destroy(v);
+    return fail(std::string(what) + ": " + hipGetErrorString(e));
+  }
+  v.mapped = ng;
+  out = v;
+  return 0;
+}
+
+static std::vector<size_t> vmm_order(size_t ng, uint64_t seed) {
+  std::vector<size_t> order(ng);
+  for (size_t i = 0; i < ng; ++i) order[i] = i;
+  uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
+  if (seed)
+    for (size_t i = ng - 1; i > 0; --i) {  // Fisher-Yates with a 64-bit LCG
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      std::swap(order[i], order[(size_t)((st >> 33) % (i + 1))]);
+    }
+  return order;
+}
+
+// One state = one allocation holding both planes: re at the base, im `stride` elements later (2^n + a pad that keeps the
+// two streams of every kernel out of step in the HBM channel hash, rounded to 32 bytes: U.h:34-36 wants that alignment).
+struct StateAlloc {
+  void* re = nullptr;
+  void* im = nullptr;
+  unsigned n = 0, float_bits = 0;
+  size_t bytes = 0;
+  bool tuned = false;
+  Vmm vmm;            // tuned placements
+  void* plain = nullptr;  // hipMalloc placements
+  double probe_ms = 0;
+  std::string layout, report;
+};
+struct StatePool {
+  std::vector<StateAlloc> live, idle;
+  std::string last_report = "{}";
+};
+static StatePool& state_pool() { static StatePool p; return p; }
+
+static void state_release(StateAlloc& st) {
+  if (st.tuned) vmm_destroy(st.vmm);
+  else if (st.plain) (void)hipFree(st.plain);
+  st = StateAlloc();
+}
+
+constexpr size_t kPlanePadBytes = 12288;     // measured at n = 30 (tools/sweep_pad.py): +3..15 % for high targets
+constexpr size_t kTunedMinBytes = 1u << 28;  // states below this stay on hipMalloc memory
+
+static size_t state_stride(unsigned n, size_t itemsize) {
+  const size_t pad = n >= 12 ? kPlanePadBytes / itemsize : 0;
+  return ((((size_t)1 << n) + pad) * itemsize + 31) / 32 * 32 / itemsize;
+}
+
+// Average time of a gate application on the candidate planes (contents are overwritten): the probe of the search.
+template <typename T>
+static int state_probe(Context& c, T* re, T* im, unsigned n, double* ms) {
+  const T h = (T)0.70710678118654752440;
+  const T U1[8] = {h, 0, h, 0, h, 0, -h, 0};
+  T U2[32];
+  for (int r = 0; r < 4; ++r)
+    for (int q = 0; q < 4; ++q) {
+      U2[2 * (4 * r + q)] = (T)0.5 * (((r & q & 1) ^ ((r & q) >> 1)) ? (T)-1 : (T)1);  // H (x) H
+      U2[2 * (4 * r + q) + 1] = 0;
+    }
+  const unsigned p1[3] = {3, n / 2, n - 1}, p2[2] = {5, n - 3};
+  auto gates = [&]() -> int {
+    for (unsigned p : p1) {
+      const unsigned pos[1] = {p};
+      if ((sizeof(T) == 4 ? apply_device_f32(c, (float*)re, (float*)im, (const float*)U1, pos, n, 1)
+                          : apply_device_f64(c, (double*)re, (double*)im, (const double*)U1, pos, n, 1))) return 1;
+    }
+    return sizeof(T) == 4 ? apply_device_f32(c, (float*)re, (float*)im, (const float*)U2, p2, n, 2)
+                          : apply_device_f64(c, (double*)re, (double*)im, (const double*)U2, p2, n, 2);
+  };
+  const uint64_t size = 1ull << n;
+  const unsigned grid = (unsigned)std::min<uint64_t>((size + kBlock - 1) / kBlock, 256 * 32);
+  hipLaunchKernelGGL((init_state_kernel<T>), dim3(grid), dim3(kBlock), 0, c.stream, re, im, size, 1, (uint64_t)0,
+                     (T)std::pow(2.0, -0.5 * (double)n));
+  if (gates()) return 1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HQ_HIP_CHECK(hipEventCreate(&e0));
+  HQ_HIP_CHECK(hipEventCreate(&e1));
+  HQ_HIP_CHECK(hipStreamSynchronize(c.stream));
+  HQ_HIP_CHECK(hipEventRecord(e0, c.stream));
+  int rc = gates() || gates();
+  HQ_HIP_CHECK(hipEventRecord(e1, c.stream));
+  HQ_HIP_CHECK(hipEventSynchronize(e1));
+  float t = 0;
+  HQ_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms = t / 8.0;
+  return rc;
+}
+
+// flags: bit 0 (HQ_STATE_PLAIN) hipMalloc memory (what HIP IPC can export); bit 1 (HQ_STATE_NO_SEARCH) one mapped
+// placement without probing; bit 2 (HQ_STATE_NO_POOL) never take a pooled placement
+static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void** out_re, void** out_im) {
+  if (!out_re || !out_im) return fail("hq_alloc_state: null pointer");
+  if (float_bits != 32 && float_bits != 64) return fail("hq_alloc_state: float_bits must be 32 or 64");
+  if (n > 40) return fail("hq_alloc_state: n_qubits out of range");
+  if (c.rec) return fail("hq_alloc_state: cannot allocate while recording a program");
+  if (check_device(c)) return 1;
+  const size_t itemsize = (size_t)float_bits / 8;
+  const size_t stride = state_stride(n, itemsize);
+  const size_t bytes = 2 * stride * itemsize;
+  StatePool& pool = state_pool();
+  StateAlloc st;
+  st.n = n;
+  st.float_bits = (unsigned)float_bits;
+  st.bytes = bytes;
+  static const bool env_plain = getenv("HQ_STATE_ALLOC") && std::string(getenv("HQ_STATE_ALLOC")) != "vmm";
+  const bool tuned = !(flags & 1) && !env_plain && bytes >= kTunedMinBytes && n >= 8;
+  auto finish = [&](StateAlloc& s) {
+    *out_re = s.re;
+    *out_im = s.im;
+    pool.live.push_back(s);
+    pool.last_report = s.report;
+    return 0;
+  };
+  if (!tuned) {
+    hipError_t e = hipMalloc(&st.plain, bytes);
+    if (e != hipSuccess) {  // pooled placements are the first thing to give back
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      for (auto& s : pool.idle) state_release(s);
+      pool.idle.clear();
+      e = hipMalloc(&st.plain, bytes);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hq_alloc_state: hipMalloc: ") + hipGetErrorString(e)); }
+    st.re = st.plain;
+    st.im = reinterpret_cast<unsigned char*>(st.plain) + stride * itemsize;
+    st.layout = "hipMalloc";
+    st.report = "{\"n_qubits\": " + std::to_string(n) + ", \"chosen\": \"hipMalloc\", \"draws\": []}";
+    return finish(st);
+  }
+  // a pooled winner of the same size: no search, no new virtual range
+  if (!(flags & 4))
+    for (size_t i = 0; i < pool.idle.size(); ++i)
+      if (pool.idle[i].n == n && pool.idle[i].float_bits == (unsigned)float_bits) {
+        st = pool.idle[i];
+        pool.idle.erase(pool.idle.begin() + (long)i);
+        st.report = st.report.substr(0, st.report.rfind('}')) + ", \"from_pool\": true}";
+        return finish(st);
+      }
+  // placements of other sizes are released first: the pool must never be what makes a new state not fit
+  if (!pool.idle.empty()) {
+    (void)hipDeviceSynchronize();
+    for (auto& s : pool.idle) state_release(s);
+    pool.idle.clear();
+  }
+  size_t free_b = 0, total_b = 0;
+  HQ_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  int tries = bytes <= ((size_t)16 << 30) ? 8 : (bytes <= ((size_t)64 << 30) ? 3 : 1);
+  if (const char* e = getenv("HQ_STATE_TRIES")) tries = std::max(1, atoi(e));
+  if (flags & 2) tries = 1;
+  tries = std::max(1, std::min<int>(tries, (int)(0.6 * (double)free_b / (double)bytes)));
+  size_t gmin = 0;
+  if (vmm_granule_min(c, &gmin)) return 1;
+  // a draw that streams at least this fast ends the search early once the evidence is in (the fast family measures
+  // 6.3-6.4 TB/s at n = 30; slower winners keep the search going to its limit)
+  const double good_tbps = getenv("HQ_STATE_GOOD_TBPS") ? atof(getenv("HQ_STATE_GOOD_TBPS")) : 6.25;
+  std::vector<StateAlloc> cands;
+  std::string draws;
+  int rc = 0;
+  for (int k = 0; k < tries; ++k) {
+    if (k >= 3) {  // enough evidence?  a clear winner among slower draws, or draws that do not differ
+      std::vector<double> ms;
+      for (const auto& s : cands) ms.push_back(s.probe_ms);
+      std::sort(ms.begin(), ms.end());
+      const bool fast = 2.0 * bytes / ms[0] / 1e9 >= good_tbps;
+      if (fast && (ms[0] < 0.93 * ms[ms.size() / 2] || ms.back() < 1.03 * ms[0])) break;
+    }
+    // families that were fast at least sometimes (profiles/r02_placement_3_vmm_layouts.txt): 2 MiB granules in creation
+    // order, 4 / 8 / 16 MiB granules shuffled; which one wins differs from box to box and from draw to draw
+    static const size_t shuffled[4] = {(size_t)8 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)8 << 20};
+    size_t gran = (k % 2) ? ((size_t)2 << 20) : shuffled[(k / 2) % 4];
+    gran = std::max(gran, gmin);
+    gran = (gran + gmin - 1) / gmin * gmin;
+    const uint64_t seed = (k % 2) ? 0 : 100 + (uint64_t)k;
+    StateAlloc cand = st;
+    cand.tuned = true;
+    if (vmm_create(c, gran, vmm_order((bytes + gran - 1) / gran, seed), cand.vmm)) {
+      if (cands.empty()) rc = 1;  // not even one placement: report the driver's error
+      break;
+    }
+    cand.re = cand.vmm.va;
+    cand.im = reinterpret_cast<unsigned char*>(cand.vmm.va) + stride * itemsize;
+    cand.layout = std::to_string(gran >> 20) + " MiB granules, " + (seed ? "shuffled (seed " + std::to_string(seed) + ")" : "in creation order");
+    if (tries > 1) {
+      const int prc = float_bits == 32 ? state_probe<float>(c, (float*)cand.re, (float*)cand.im, n, &cand.probe_ms)
+                                       : state_probe<double>(c, (double*)cand.re, (double*)cand.im, n, &cand.probe_ms);
+      if (prc) { vmm_destroy(cand.vmm); rc = 1; break; }
+    }
+    draws += (draws.empty() ? "" : ", ") + std::string("{\"layout\": \"") + cand.layout + "\", \"probe_ms_per_gate\": " +
+             (tries > 1 ? std::to_string(cand.probe_ms) : std::string("null")) + "}";
+    cands.push_back(cand);  // held: the next draw must see other physical pages
+  }
+  if (cands.empty() || rc) {
+    (void)hipDeviceSynchronize();
+    for (auto& s : cands) vmm_destroy(s.vmm);
+    return rc ? 1 : fail("hq_alloc_state: no placement could be created");
+  }
+  size_t best = 0;
+  for (size_t i = 1; i < cands.size(); ++i)
+    if (cands[i].probe_ms < cands[best].probe_ms) best = i;
+  (void)hipDeviceSynchronize();
+  for (size_t i = 0; i < cands.size(); ++i)
+    if (i != best) vmm_destroy(cands[i].vmm);
+  st = cands[best];
+  const double tbps = st.probe_ms > 0 ? 2.0 * bytes / st.probe_ms / 1e9 : 0;
+  st.report = "{\"n_qubits\": " + std::to_string(n) + ", \"draws\": [" + draws + "], \"chosen\": \"" + st.layout +
+              "\", \"probe_ms_per_gate\": " + (st.probe_ms > 0 ? std::to_string(st.probe_ms) : std::string("null")) +
+              ", \"probe_TBps\": " + (tbps > 0 ? std::to_string(tbps) : std::string("null")) + "}";
+  return finish(st);
+}
+
+static int state_free(Context& c, void* re) {
+  StatePool& pool = state_pool();
+  for (size_t i = 0; i < pool.live.size(); ++i)
+    if (pool.live[i].re == re) {
+      StateAlloc st = pool.live[i];
+      pool.live.erase(pool.live.begin() + (long)i);
+      static const bool no_pool = getenv("HQ_STATE_POOL") && atoi(getenv("HQ_STATE_POOL")) == 0;
+      bool keep = st.tuned && !no_pool;
+      for (const auto& s : pool.idle) keep = keep && !(s.n == st.n && s.float_bits == st.float_bits);  // one per size
+      if (keep) {
+        pool.idle.push_back(st);  // still mapped: the next state of this size takes it without a search
+      } else {
+        (void)hipDeviceSynchronize();
+        state_release(st);
+      }
+      return 0;
+    }
+  return fail("hq_free_state: not a state of this library");
+}
+
 }  // namespace hq
 
 extern "C" {
@@ -173,8 +490,8 @@ int hq_vdot_float64(const double* are, const double* aim, const double* bre, con
   return hq::vdot_entry<double>(are, aim, bre, bim, size, out);
 }
 
-// State memory.  flags: bit 0 = physically contiguous VRAM (hipDeviceMallocContiguous): one PTE fragment
-// covers a large range, which is worth ~14 % of streaming bandwidth on this part.
+// ---- state memory --------------------------------------------------------------------------------------------------
+// flags of hq_alloc: bit 0 = physically contiguous VRAM (hipDeviceMallocContiguous).
 int hq_alloc(void** dev_ptr, uint64_t bytes, int flags) {
   hq::Context& c = hq::ctx();
   std::lock_guard<std::mutex> lock(c.mu);
@@ -190,49 +507,23 @@ int hq_alloc(void** dev_ptr, uint64_t bytes, int flags) {
   return 0;
 }
 
-// Scattered placement: a VA-contiguous buffer whose physical granules (hipMemCreate, `granule` bytes
-// each) are mapped in a seeded pseudo-random order (hipMemMap).
-struct HqVmm { void* va; size_t size, granule; std::vector<hipMemGenericAllocationHandle_t> handles; };
-static std::vector<HqVmm>& hq_vmm_registry() { static std::vector<HqVmm> r; return r; }
-
-// Explicit placement: n_granules physical granules of `granule` bytes, created in sequence, granule i mapped at
-// virtual slot va_slot[i] (a permutation of 0..n_granules-1).  *granule_min receives the driver's minimum.
 int hq_alloc_mapped(void** dev_ptr, uint64_t granule, uint64_t n_granules, const uint32_t* va_slot, uint64_t* granule_min) {
   hq::Context& c = hq::ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   if (hq::check_device(c)) return 1;
-  hipMemAllocationProp prop;
-  memset(&prop, 0, sizeof(prop));
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = c.device;
   size_t gmin = 0;
-  HQ_HIP_CHECK(hipMemGetAllocationGranularity(&gmin, &prop, hipMemAllocationGranularityMinimum));
+  if (hq::vmm_granule_min(c, &gmin)) return 1;
   if (granule_min) *granule_min = gmin;
   if (!dev_ptr || !va_slot || !n_granules) return hq::fail("hq_alloc_mapped: bad arguments");
   if (granule % gmin) return hq::fail("hq_alloc_mapped: granule is not a multiple of the driver minimum " + std::to_string(gmin));
-  HqVmm v;
-  v.granule = granule;
-  v.size = (size_t)n_granules * granule;
-  v.va = nullptr;
-  HQ_HIP_CHECK(hipMemAddressReserve(&v.va, v.size, (size_t)1 << 21, nullptr, 0));
-  v.handles.resize(n_granules);
-  for (size_t i = 0; i < n_granules; ++i) {
-    hipError_t e = hipMemCreate(&v.handles[i], granule, &prop, 0);
-    if (e != hipSuccess) return hq::fail(std::string("hipMemCreate: ") + hipGetErrorString(e));
-  }
+  std::vector<size_t> order(n_granules);
   for (size_t i = 0; i < n_granules; ++i) {
     if (va_slot[i] >= n_granules) return hq::fail("hq_alloc_mapped: slot out of range");
-    hipError_t e = hipMemMap(reinterpret_cast<unsigned char*>(v.va) + (size_t)va_slot[i] * granule, granule, 0, v.handles[i], 0);
-    if (e != hipSuccess) return hq::fail(std::string("hipMemMap: ") + hipGetErrorString(e));
+    order[i] = va_slot[i];
   }
-  hipMemAccessDesc acc;
-  memset(&acc, 0, sizeof(acc));
-  acc.location.type = hipMemLocationTypeDevice;
-  acc.location.id = c.device;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  HQ_HIP_CHECK(hipMemSetAccess(v.va, v.size, &acc, 1));
-  hq_vmm_registry().push_back(v);
+  hq::Vmm v;
+  if (hq::vmm_create(c, granule, order, v)) return 1;
+  hq::vmm_registry().push_back(v);
   *dev_ptr = v.va;
   return 0;
 }
@@ -242,68 +533,71 @@ int hq_alloc_scattered(void** dev_ptr, uint64_t bytes, uint64_t granule, uint64_
   std::lock_guard<std::mutex> lock(c.mu);
   if (!dev_ptr || !bytes) return hq::fail("hq_alloc_scattered: bad arguments");
   if (hq::check_device(c)) return 1;
-  hipMemAllocationProp prop;
-  memset(&prop, 0, sizeof(prop));
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = c.device;
   size_t gmin = 0;
-  HQ_HIP_CHECK(hipMemGetAllocationGranularity(&gmin, &prop, hipMemAllocationGranularityMinimum));
+  if (hq::vmm_granule_min(c, &gmin)) return 1;
   if (granule < gmin) granule = gmin;
   granule = (granule + gmin - 1) / gmin * gmin;
-  const size_t ng = ((size_t)bytes + granule - 1) / granule;
-  HqVmm v;
-  v.granule = granule;
-  v.size = ng * granule;
-  v.va = nullptr;
-  HQ_HIP_CHECK(hipMemAddressReserve(&v.va, v.size, (size_t)1 << 21, nullptr, 0));
-  std::vector<size_t> order(ng);
-  for (size_t i = 0; i < ng; ++i) order[i] = i;
-  uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
-  if (seed)
-    for (size_t i = ng - 1; i > 0; --i) {  // Fisher-Yates with a 64-bit LCG
-      st = st * 6364136223846793005ull + 1442695040888963407ull;
-      std::swap(order[i], order[(size_t)((st >> 33) % (i + 1))]);
-    }
-  v.handles.resize(ng);
-  for (size_t i = 0; i < ng; ++i) {  // physical granules are created in sequence ...
-    hipError_t e = hipMemCreate(&v.handles[i], granule, &prop, 0);
-    if (e != hipSuccess) return hq::fail(std::string("hipMemCreate: ") + hipGetErrorString(e));
-  }
-  for (size_t i = 0; i < ng; ++i) {  // ... and mapped at shuffled virtual slots
-    hipError_t e = hipMemMap(reinterpret_cast<unsigned char*>(v.va) + order[i] * granule, granule, 0, v.handles[i], 0);
-    if (e != hipSuccess) return hq::fail(std::string("hipMemMap: ") + hipGetErrorString(e));
-  }
-  hipMemAccessDesc acc;
-  memset(&acc, 0, sizeof(acc));
-  acc.location.type = hipMemLocationTypeDevice;
-  acc.location.id = c.device;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  HQ_HIP_CHECK(hipMemSetAccess(v.va, v.size, &acc, 1));
-  hq_vmm_registry().push_back(v);
+  hq::Vmm v;
+  if (hq::vmm_create(c, granule, hq::vmm_order(((size_t)bytes + granule - 1) / granule, seed), v)) return 1;
+  hq::vmm_registry().push_back(v);
   *dev_ptr = v.va;
   return 0;
 }
 
 int hq_free(void* dev_ptr) {
   if (!dev_ptr) return 0;
-  auto& reg = hq_vmm_registry();
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  auto& reg = hq::vmm_registry();
   for (size_t i = 0; i < reg.size(); ++i)
     if (reg[i].va == dev_ptr) {
-      // The virtual range is NOT given back (hipMemAddressFree): on this stack (ROCm 7.0 runtime under torch,
-      // measured with tools/vmm_integrity.py) a range that is unmapped and immediately reserved + mapped
-      // again keeps stale translations -- reads and writes land in the old granules.  Address space is
-      // 47 bits wide; the physical granules are what matters and they are released.
       (void)hipDeviceSynchronize();
-      (void)hipMemUnmap(reg[i].va, reg[i].size);
-      for (auto h : reg[i].handles) (void)hipMemRelease(h);
-      static const bool free_va = getenv("HQ_VMM_FREE_VA") && atoi(getenv("HQ_VMM_FREE_VA")) != 0;
-      if (free_va) (void)hipMemAddressFree(reg[i].va, reg[i].size);
+      hq::vmm_destroy(reg[i]);
       reg.erase(reg.begin() + (long)i);
       return 0;
     }
   hipError_t e = hipFree(dev_ptr);
   if (e != hipSuccess) return hq::fail(std::string("hq_free: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int hq_alloc_state(unsigned int n_qubits, int float_bits, int flags, void** psi_re, void** psi_im) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::read_env(c);
+  return hq::state_alloc(c, n_qubits, float_bits, flags, psi_re, psi_im);
+}
+
+int hq_free_state(void* psi_re) {
+  if (!psi_re) return 0;
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  return hq::state_free(c, psi_re);
+}
+
+int hq_state_info(const void* psi_re, char* buf, uint64_t cap) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  const std::string* txt = &hq::state_pool().last_report;
+  if (psi_re) {
+    txt = nullptr;
+    for (const auto& st : hq::state_pool().live)
+      if (st.re == psi_re) txt = &st.report;
+    if (!txt) return hq::fail("hq_state_info: not a state of this library");
+  }
+  if (!buf || cap == 0) return hq::fail("hq_state_info: no buffer");
+  const size_t k = std::min<size_t>(txt->size(), (size_t)cap - 1);
+  memcpy(buf, txt->data(), k);
+  buf[k] = 0;
+  return 0;
+}
+
+int hq_state_pool_trim(void) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  (void)hipDeviceSynchronize();
+  for (auto& st : hq::state_pool().idle) hq::state_release(st);
+  hq::state_pool().idle.clear();
   return 0;
 }
 
@@ -334,3 +628,34 @@ int hq_norm2_float64(const double* re, const double* im, uint64_t size, double* 
 }
 
 }  // extern "C"
+
+// Diagnostics (not part of the reference boundary; tools/placement_remap.py): the SAME physical granules of a buffer from
+// hq_alloc_mapped / hq_alloc_scattered mapped in another order into a fresh virtual range (granule i -> slot va_slot[i]).
+// The old range is unmapped and retired; *new_ptr replaces dev_ptr (free it with hq_free).
+extern "C" int hq_vmm_remap(void* dev_ptr, const uint32_t* va_slot, void** new_ptr) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (!dev_ptr || !va_slot || !new_ptr) return hq::fail("hq_vmm_remap: null pointer");
+  for (auto& v : hq::vmm_registry())
+    if (v.va == dev_ptr) {
+      const size_t ng = v.handles.size();
+      for (size_t i = 0; i < ng; ++i)
+        if (va_slot[i] >= ng) return hq::fail("hq_vmm_remap: slot out of range");
+      HQ_HIP_CHECK(hipDeviceSynchronize());
+      HQ_HIP_CHECK(hipMemUnmap(v.va, v.size));
+      void* va = nullptr;
+      HQ_HIP_CHECK(hipMemAddressReserve(&va, v.size, (size_t)1 << 21, nullptr, 0));
+      for (size_t i = 0; i < ng; ++i)
+        HQ_HIP_CHECK(hipMemMap(reinterpret_cast<unsigned char*>(va) + (size_t)va_slot[i] * v.granule, v.granule, 0, v.handles[i], 0));
+      hipMemAccessDesc acc;
+      memset(&acc, 0, sizeof(acc));
+      acc.location.type = hipMemLocationTypeDevice;
+      acc.location.id = c.device;
+      acc.flags = hipMemAccessFlagsProtReadWrite;
+      HQ_HIP_CHECK(hipMemSetAccess(va, v.size, &acc, 1));
+      v.va = va;
+      *new_ptr = va;
+      return 0;
+    }
+  return hq::fail("hq_vmm_remap: not a mapped buffer of this library");
+}

@@ -89,113 +89,24 @@ def _torch():
 PLANE_PAD_BYTES = 12288
 
 
-#: States of at least this many bytes (both planes) get a TUNED PLACEMENT: the planes are backed by HIP
-#: virtual-memory-management granules mapped by the library (hq_alloc_mapped) instead of torch's caching
-#: allocator, several placements are drawn, each is probed with a handful of gate applications, and the
-#: fastest one is kept.  Why (MI355X, n = 30, tools/alloc_effect*.py and tools/placement_lottery.py,
-#: gpurun_out/r2j..r2w): the SAME gate kernels stream 5.50-5.58 TB/s from hipMalloc / torch memory --
-#: physically contiguous or not, any distance between the planes, anywhere in HBM -- and 5.8-6.4 TB/s
-#: from 2-8 MiB granules mapped through the VMM interface, depending on which physical pages the driver
-#: hands out (reproducible per position in a fresh process, not controllable from user space; 64 MiB+
-#: granules lose the advantage, 512 KiB ones thrash the TLB).  The 900-gate benchmark circuit on the
-#: winner of 4-6 draws: 2.68-2.76 ms per gate against 3.04 ms (6.2-6.4 vs 5.6 TB/s).
+#: States of at least this many bytes (both planes) get a TUNED PLACEMENT from the library's own allocator
+#: (hq_alloc_state, include/hq_hip.h): the planes are backed by HIP virtual-memory-management granules mapped by the
+#: library instead of torch's caching allocator, several placements are drawn, each is probed with a handful of gate
+#: applications, the fastest one is kept, and a freed winner stays in a per-size pool for the next state.  Why (MI355X,
+#: n = 30, profiles/r02_placement_*.txt): the SAME gate kernels stream 5.50-5.58 TB/s from hipMalloc / torch memory and
+#: 5.8-6.4 TB/s from 2-8 MiB granules mapped through the VMM interface, depending on which physical pages the driver hands
+#: out.  The search, the probe and the pool live behind the C ABI (round 3; round 2 had them here in Python).
 #: HQ_STATE_ALLOC=torch switches the mechanism off, HQ_STATE_TRIES sets the number of draws.
 VMM_MIN_BYTES = 1 << 28
-#: a draw that streams at least this fast (TB/s in the probe) ends the search early (the fast family measures
-#: 6.3-6.4; a 6.1 draw used to end it and cost the 20-step bench run 4 %); slower ones keep the search going to its limit
-GOOD_DRAW_TBPS = 6.25
-#: what the last tuned allocation found (bench.py reports it)
+#: what the last tuned allocation found (bench.py reports it): hq_state_info's report
 last_placement = {}
-
-
-class _VmmPlanes:
-    """Owner of a VMM-backed buffer seen by torch through ``__cuda_array_interface__``; the physical
-    granules go back to the driver when the last tensor aliasing it dies (the virtual range is retired,
-    see hq_free)."""
-
-    def __init__(self, nbytes, shape, typestr, granule, shuffle_seed):
-        ng = -(-nbytes // granule)
-        slots = np.random.default_rng(shuffle_seed).permutation(ng) if shuffle_seed else np.arange(ng)
-        self.buf = core.DeviceBuffer(ng * granule, scattered=granule, va_slots=slots)
-        self.layout = f'{granule >> 20} MiB granules, ' + (f'shuffled (seed {shuffle_seed})' if shuffle_seed else 'in creation order')
-        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (self.buf.ptr, False),
-                                         'version': 2, 'strides': None}
-
-    def __del__(self):
-        try:
-            self.buf.free()
-        except Exception:
-            pass
-
-
-def _probe_ms(planes, n, float_type):
-    """Average time of a few gate applications on `planes` (any content; they are overwritten)."""
-    torch = _torch()
-    rng = np.random.default_rng(0)
-    ct = np.dtype('complex64') if np.dtype(float_type) == np.dtype('float32') else np.dtype('complex128')
-
-    def haar(d):
-        q, r = np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))
-        return (q * (np.diagonal(r) / np.abs(np.diagonal(r)))).astype(ct)
-
-    gates = [([3], haar(2)), ([n // 2], haar(2)), ([n - 1], haar(2)), ([5, n - 3], haar(4))]
-    core.init_state(planes[0], planes[1], 'plus')
-    for pos, U in gates:
-        core.apply_U(planes[0], planes[1], U, pos, n)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    core.sync()
-    e0.record()
-    for _ in range(2):
-        for pos, U in gates:
-            core.apply_U(planes[0], planes[1], U, pos, n)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / (2 * len(gates))
-
-
-def _tuned_planes(n, stride, itemsize, dev, tries):
-    """Draw up to `tries` VMM placements (alternating 8 MiB granules shuffled and 2 MiB granules in
-    creation order), probe each, keep the fastest; stop after three draws once one is clearly faster
-    than the median (> 7 %) or all agree within 3 %.  The rejected draws are held until the search
-    ends so that every draw sees different physical memory."""
-    torch = _torch()
-    core.use_torch_stream()
-    typestr = '<f4' if itemsize == 4 else '<f8'
-    ft = np.dtype('float32') if itemsize == 4 else np.dtype('float64')
-    nbytes = 2 * stride * itemsize
-    free_b, _ = torch.cuda.mem_get_info()
-    tries = max(1, min(tries, int(0.6 * free_b // nbytes)))
-    cands, log = [], []
-    for k in range(tries):
-        if k >= 3:  # enough evidence?  a clear winner among slower draws, or draws that do not differ
-            ms_all = sorted(c[0] for c in cands)
-            fast = 4 * (1 << n) * itemsize / ms_all[0] / 1e9 >= GOOD_DRAW_TBPS
-            if fast and (ms_all[0] < 0.93 * ms_all[len(ms_all) // 2] or ms_all[-1] < 1.03 * ms_all[0]):
-                break
-        # families that were fast at least sometimes (profiles/r02_placement_3_vmm_layouts.txt): 2 MiB granules in
-        # creation order, 4 / 8 / 16 MiB granules shuffled; which one wins differs from box to box and draw to draw
-        gran = (2 << 20) if k % 2 else ((8 << 20), (4 << 20), (16 << 20), (8 << 20))[(k // 2) % 4]
-        owner = _VmmPlanes(nbytes, (2, stride), typestr, gran, 0 if k % 2 else 100 + k)
-        raw = torch.as_tensor(owner, device=dev)
-        if raw.data_ptr() != owner.buf.ptr:
-            raise RuntimeError('torch did not alias the mapped buffer')
-        planes = raw[:, :1 << n]
-        ms = _probe_ms(planes, n, ft) if tries > 1 else float('nan')
-        log.append({'layout': owner.layout, 'probe_ms_per_gate': ms})
-        cands.append((ms, planes, owner.layout))  # held: the next draw must see other physical pages
-        del owner, raw, planes
-    found = min(cands, key=lambda c: c[0]) if tries > 1 else cands[0]
-    del cands
-    last_placement.clear()
-    last_placement.update({'n_qubits': n, 'draws': log, 'chosen': found[2], 'probe_ms_per_gate': found[0],
-                           'probe_TBps': 4 * (1 << n) * itemsize / found[0] / 1e9 if found[0] == found[0] else None})
-    return found[1]
 
 
 def alloc_planes(n, torch_dtype, device, vmm=True):
     """(2, 2^n) view of one allocation whose two rows are PLANE_PAD_BYTES further apart than
-    2^n elements.  planes[0] / planes[1] are contiguous, 32-byte aligned 1-D tensors.  Large states get
-    a tuned placement (VMM_MIN_BYTES above)."""
+    2^n elements.  planes[0] / planes[1] are contiguous, 32-byte aligned 1-D tensors.  Large states come from
+    hq_alloc_state with a tuned placement (VMM_MIN_BYTES above); small ones, and planes other ranks map through HIP IPC
+    (``vmm=False``), from torch's caching allocator."""
     import os
     torch = _torch()
     itemsize = torch.empty((), dtype=torch_dtype).element_size()
@@ -206,11 +117,18 @@ def alloc_planes(n, torch_dtype, device, vmm=True):
     nbytes = 2 * stride * itemsize
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
     if vmm and nbytes >= VMM_MIN_BYTES and os.environ.get('HQ_STATE_ALLOC', 'vmm') == 'vmm' and dev.index in (None, torch.cuda.current_device()):
-        default_tries = 8 if nbytes <= (16 << 30) else (3 if nbytes <= (64 << 30) else 1)
         try:
-            return _tuned_planes(n, stride, itemsize, dev, int(os.environ.get('HQ_STATE_TRIES', default_tries)))
+            core.use_torch_stream()  # the probes run on the library stream
+            owner = core.StatePlanes(n, np.dtype('float32') if itemsize == 4 else np.dtype('float64'))
+            raw = torch.as_tensor(owner, device=dev)
+            if raw.data_ptr() != owner.re or owner.stride != stride:
+                raise RuntimeError('torch did not alias the planes of hq_alloc_state')
+            last_placement.clear()
+            last_placement.update(owner.info)
+            return raw[:, :1 << n]
         except Exception as e:  # noqa: BLE001 -- the driver refused (fragmented HBM, VMM unavailable): torch's allocator
             warn(f'hybridq_amd: tuned state placement failed ({e!r}); using torch.empty')
+            core.state_pool_trim()
     raw = torch.empty((2, stride), dtype=torch_dtype, device=device)
     return raw[:, :1 << n]
 
@@ -406,8 +324,11 @@ class EvolutionState:
             new_psi, new_order = gate.apply(psi=view, order=order)
             if any(x != y for x, y in zip(order, new_order)):  # :552-554
                 raise RuntimeError("'order' has changed.")
-            if not (hasattr(new_psi, 'data_ptr') and new_psi.data_ptr() == self.planes.data_ptr()):
-                # a new array came back (:545-550): bring it into the planes (device to device)
+            same = new_psi is view or (hasattr(new_psi, 'data_ptr') and new_psi.data_ptr() == view.data_ptr() and
+                                       tuple(new_psi.shape) == tuple(view.shape) and tuple(new_psi.stride()) == tuple(view.stride()))
+            if not same:
+                # a new array came back (:545-550) -- or another VIEW of the same storage (permuted axes, a slice starting
+                # at the same address): bring it into the planes (device to device)
                 new_psi = torch.as_tensor(new_psi, device=self.planes.device).to(self.planes.dtype)
                 self.planes.copy_(new_psi.reshape(2, -1))
             return

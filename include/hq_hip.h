@@ -119,18 +119,39 @@ const char *hq_last_kernel_desc(void);
 int hq_to_complex64(float *psi_re, float *psi_im, float *psi_out, uint64_t size);
 int hq_to_complex128(double *psi_re, double *psi_im, double *psi_out, uint64_t size);
 
-/* State memory owned by the library (counterpart of the aligned planes of simulation.py:491-494).
- * flags bit 0: physically contiguous VRAM -- falls back to the caller when the driver cannot find a
- * contiguous range (returns 1).  Any device memory may be passed to the other entry points; this
- * allocator exists because placement is worth ~14 % of HBM bandwidth. */
+/* ---- State memory owned by the library (hq_alloc_state / hq_free_state; counterpart of the aligned planes
+ * of hybridq/circuit/simulation/simulation.py:491-494).  Any device memory may be passed to the other entry points; this
+ * allocator exists because WHERE the planes live is worth 70 % -> 80 % of the HBM peak for the streaming gate kernels
+ * (DESIGN.md section 2).
+ *
+ * hq_alloc_state: both planes of an n-qubit state in ONE allocation -- *psi_re at the base, *psi_im 2^n elements plus a
+ * 12 KiB pad later (the pad keeps the two streams of a kernel out of step in the memory-channel hash), both 32-byte
+ * aligned (U.h:34-36).  States of >= 256 MiB get a TUNED PLACEMENT: the library maps 2-16 MiB physical granules itself
+ * (HIP virtual-memory management), draws up to 8 placements (env HQ_STATE_TRIES), probes each with 12 gate applications
+ * on the library's stream and keeps the fastest (~0.3 s per draw at n = 30; stops after three draws once one streams
+ * >= 6.25 TB/s and is a clear winner).  hq_free_state keeps ONE winning placement per state size in a pool: the next
+ * hq_alloc_state of that size returns it at once -- no second search, no second virtual range (a retired range is never
+ * handed back to the driver: unmap + immediate remap kept stale translations on this stack; HQ_VMM_FREE_VA=1 overrides).
+ * A request of another size, a failed hipMalloc inside the library or hq_state_pool_trim() release the pool.
+ * flags: */
+#define HQ_STATE_PLAIN 1     /* hipMalloc memory: what hq_ipc_export can export (peer-to-peer transport) */
+#define HQ_STATE_NO_SEARCH 2 /* one mapped placement, no probing */
+#define HQ_STATE_NO_POOL 4   /* do not take a pooled placement */
+int hq_alloc_state(unsigned int n_qubits, int float_bits /* 32 | 64 */, int flags, void **psi_re, void **psi_im);
+int hq_free_state(void *psi_re);
+/* JSON text about the placement of a state (psi_re) or of the last allocation (NULL): the draws with their probe times,
+ * the layout kept, its probe rate in TB/s, "from_pool". */
+int hq_state_info(const void *psi_re, char *buf, uint64_t cap);
+int hq_state_pool_trim(void);
+
+/* Raw device memory.  hq_alloc flags bit 0: physically contiguous VRAM (returns 1 when the driver cannot find a
+ * contiguous range).  hq_alloc_mapped: n_granules physical granules of `granule` bytes (a multiple of the driver
+ * minimum, returned in *granule_min when non-NULL) are created in sequence and granule i is mapped at virtual slot
+ * va_slot[i] (a permutation of 0..n_granules-1) of ONE contiguous virtual range.  hq_alloc_scattered:
+ * ceil(bytes / granule) granules in creation order (seed 0) or shuffled by `seed`.  Every failure releases what was
+ * created.  Free with hq_free. */
 int hq_alloc(void **dev_ptr, uint64_t bytes, int flags);
 int hq_free(void *dev_ptr);
-/* The same through HIP's virtual-memory-management calls: n_granules physical granules of `granule` bytes (a multiple
- * of the driver minimum, returned in *granule_min when non-NULL) are created in sequence and granule i is mapped at
- * virtual slot va_slot[i] (a permutation of 0..n_granules-1) of ONE contiguous virtual range.  hq_alloc_scattered:
- * ceil(bytes / granule) granules in creation order (seed 0) or shuffled by `seed`.  Free with hq_free (the physical
- * granules are released, the virtual range is retired).  hybridq_amd.simulation.alloc_planes draws a few such
- * placements, probes each with gate applications and keeps the fastest. */
 int hq_alloc_mapped(void **dev_ptr, uint64_t granule, uint64_t n_granules, const uint32_t *va_slot, uint64_t *granule_min);
 int hq_alloc_scattered(void **dev_ptr, uint64_t bytes, uint64_t granule, uint64_t seed);
 

@@ -121,3 +121,71 @@ def test_rccl_moves_the_memory_the_product_allocates(torch_cuda):
     idx = torch.arange(1 << m, device='cuda', dtype=torch.int64)
     y = _source_index(torch, idx, perm)
     assert torch.equal(b[0], ref[0][y]) and torch.equal(b[1], ref[1][y])
+
+
+def test_state_allocator_behind_the_c_abi(torch_cuda):
+    """hq_alloc_state / hq_free_state / hq_state_info: a 512 MiB state gets a mapped placement found by the
+    library's own draw-and-probe search, works with every entry point exactly like torch memory, returns to a per-size
+    pool when freed (the next state of that size is the same placement, no second search), and HQ_STATE_PLAIN gives
+    hipMalloc memory."""
+    from hybridq_amd import core
+    from hybridq_amd.circuits import rqc_1q2q
+    torch = torch_cuda
+    core.use_torch_stream()
+    core.state_pool_trim()
+    n = 26
+    os.environ['HQ_STATE_TRIES'] = '3'
+    try:
+        owner = core.StatePlanes(n, np.float32)
+    finally:
+        del os.environ['HQ_STATE_TRIES']
+    info = owner.info
+    assert len(info['draws']) == 3 and info['chosen'] in [d['layout'] for d in info['draws']]
+    assert min(d['probe_ms_per_gate'] for d in info['draws']) == pytest.approx(info['probe_ms_per_gate'], rel=1e-6)
+    assert owner.re % 32 == 0 and owner.im % 32 == 0 and owner.stride >= (1 << n)
+    a = torch.as_tensor(owner, device='cuda')[:, :1 << n]
+    b = torch.empty((2, 1 << n), dtype=torch.float32, device='cuda')
+    for pl in (a, b):
+        core.init_state(pl[0], pl[1], 'plus')
+        for U, qs in rqc_1q2q(n, depth=2, seed=3):
+            core.apply_U(pl[0], pl[1], U, [n - 1 - q for q in reversed(qs)], n)
+    core.sync()
+    assert torch.equal(a, b)  # same kernels, same arithmetic: the placement changes nothing but the speed
+    ptr = owner.re
+    del a
+    owner.free()
+    again = core.StatePlanes(n, np.float32)
+    assert again.re == ptr and again.info.get('from_pool') is True
+    again.free()
+    core.state_pool_trim()
+    fresh = core.StatePlanes(n, np.float32, flags=core.STATE_NO_SEARCH)
+    assert not fresh.info.get('from_pool') and len(fresh.info['draws']) == 1
+    fresh.free()
+    plain = core.StatePlanes(n, np.float32, flags=core.STATE_PLAIN)
+    assert plain.info['chosen'] == 'hipMalloc'
+    handle, off = core.ipc_export(plain.re)  # what the peer-to-peer transport needs (core._ptr accepts an address)
+    assert len(handle) == 64
+    plain.free()
+    core.state_pool_trim()
+    small = core.StatePlanes(12, np.float64)  # below 256 MiB: plain memory, no search
+    assert small.info['chosen'] == 'hipMalloc' and small.stride == (1 << 12) + 12288 // 8
+    small.free()
+
+
+def test_c_abi_state_demo_without_python(torch_cuda, tmp_path):
+    """examples/abi_state_demo.cpp: hq_alloc_state from C (no Python, no torch in the process) -- plain against tuned
+    placement under the reference's own entry point, and the pool on the second allocation."""
+    import shutil
+    import subprocess
+    from hybridq_amd import core
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    exe = str(tmp_path / 'abi_state_demo')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'examples', 'abi_state_demo.cpp'), '-o', exe, '-ldl'])
+    out = subprocess.run([exe, core._LIB_PATH, '28'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('n=28')][0]
+    vals = dict(kv.split('=') for kv in line.split())
+    print('\n  ' + line)
+    assert vals['from_pool'] == '1' and float(vals['realloc_s']) < 0.05
+    assert float(vals['tuned_TBps']) > 0.97 * float(vals['plain_TBps'])  # never worse than the caller's own hipMalloc planes

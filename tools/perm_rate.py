@@ -55,9 +55,11 @@ for dt, m in ((torch.float32, n), (torch.float64, n - 1)):
     nbytes = src.numel() * src.element_size()
     for name, p in perms(m).items():
         timeit(f'{str(dt)[6:]} permute_bits {name}', lambda: core.permute_bits(src, dst, p, m), 2 * nbytes)
-    for s in (13, 14, 15, 16):
+    for s in (8, 11, 13, 14, 15, 16):
         pos = rng.permutation(s)
-        timeit(f'{str(dt)[6:]} swap in place s={s}', lambda: core.swap(src, pos, m), 2 * nbytes)
+        timeit(f'{str(dt)[6:]} swap in place s={s} ({sum(int(p) != i for i, p in enumerate(pos))} moved)', lambda: core.swap(src, pos, m), 2 * nbytes)
+    pos = np.roll(np.arange(16), 3)  # no fixed point
+    timeit(f'{str(dt)[6:]} swap in place s=16 (all 16 moved)', lambda: core.swap(src, pos, m), 2 * nbytes)
     del src, dst
     # the pack pass of the exchange on both planes (one rank: the permutation alone)
     core.shard_free()

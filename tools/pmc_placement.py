@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hybridq_amd import core  # noqa: E402
 from hybridq_amd.circuits import haar_unitary  # noqa: E402
-from hybridq_amd import simulation as sim  # noqa: E402
+import placement_util as sim  # noqa: E402
 
 n = 30
 N = 1 << n

@@ -15,7 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hybridq_amd import core  # noqa: E402
-from hybridq_amd import simulation as sim  # noqa: E402
+import placement_util as sim  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 26  # 2 planes x 256 MiB
 core.use_torch_stream()
@@ -23,7 +23,7 @@ dev = torch.device('cuda', 0)
 
 
 def vmm_planes(gran, seed):
-    stride = (1 << m) + sim.PLANE_PAD_BYTES // 4
+    stride = (1 << m) + 12288 // 4
     owner = sim._VmmPlanes(2 * stride * 4, (2, stride), '<f4', gran, seed)
     raw = torch.as_tensor(owner, device=dev)
     assert raw.data_ptr() == owner.buf.ptr
