@@ -156,6 +156,7 @@ def parity_check(complex_type, depth, n=24):
     for name, kw in (('per_gate', dict(compress=0)), ('fused_k4', dict(compress=4)), ('blocked', dict(blocked=True))):
         psi = simulate(gates, initial_state='0' * n, complex_type=complex_type, qubits=list(range(n)), **kw).reshape(-1)
         out['max_rel_diff_' + name] = float(np.abs(psi - ref).max() / scale)
+        out['literal_bar_met_' + name] = bool(out['max_rel_diff_' + name] <= bar)  # north_star's number itself, whatever the model allows
         ok = ok and out['max_rel_diff_' + name] <= out['tolerance_two_evolutions']
         results[name] = psi
     if complex_type == 'complex64':
@@ -174,6 +175,7 @@ def parity_check(complex_type, depth, n=24):
         out['max_rel_diff_first_%d_gates' % len(short)] = float(np.abs(g2 - r2).max() / float(np.abs(r2).max()))
         ok = ok and out['max_rel_diff_first_%d_gates' % len(short)] <= bar
     out['pass'] = bool(ok)
+    out['literal_bar_met'] = bool(all(v for k, v in out.items() if k.startswith('literal_bar_met_')))
     return out
 
 

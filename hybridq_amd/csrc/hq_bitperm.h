@@ -27,7 +27,7 @@ static unsigned bitperm_default_tb() {
 }
 
 // true when the permutation keeps the low 128 bytes of the index space in place: the plain gather kernels then move
-// whole cache lines on both sides already (5.2-5.5 TB/s against 4.7-5.3 through the tile kernel)
+// whole cache lines on both sides too (HQ_PERM_TILE=3 routes those to them; not the default, see hq_swap.hip)
 template <typename E>
 static bool bitperm_low_run_fixed(const unsigned* perm, unsigned m) {
   const unsigned c = sizeof(E) == 4 ? 5 : 4;

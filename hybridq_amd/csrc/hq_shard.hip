@@ -110,8 +110,8 @@ static int launch_pack(Context& c, hipStream_t s, const E* s0, const E* s1, cons
   for (unsigned j = 0; j < (1u << a.g); ++j)
     for (unsigned p = 0; p < a.planes; ++p) dal = dal && reinterpret_cast<uintptr_t>(a.dst[j][p]) % 16 == 0;
   static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
-  static const bool tile_always = getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 2;
-  if (one_pass && al && dal && perm && (tile_always || !bitperm_low_run_fixed<E>(perm, a.m))) {
+  static const bool gather_low_fixed = getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 3;
+  if (one_pass && al && dal && perm && !(gather_low_fixed && bitperm_low_run_fixed<E>(perm, a.m))) {
     // the eviction permutation at full cache-line granularity on both sides (bitperm_tile_kernel); the gather kernel
     // below stays for shards smaller than a tile
     BitPermPlan P;

@@ -118,10 +118,11 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
   const unsigned max_lds_bits = sizeof(E) == 4 ? 15 : 14;  // 128 KiB of elements, index computed inline
   static const bool two_pass = !(getenv("HQ_SWAP_TWO_PASS") && atoi(getenv("HQ_SWAP_TWO_PASS")) == 0);
   static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
-  static const unsigned tile_min = getenv("HQ_SWAP_TILE_MIN") ? (unsigned)atoi(getenv("HQ_SWAP_TILE_MIN")) : 0;
-  if ((s > table_bits || (tile_min && s >= tile_min)) && one_pass && reinterpret_cast<uintptr_t>(a) % 16 == 0) {
-    // s = 14, 15 (13, 14 for 8-byte elements): the whole 2^s chunk is ONE LDS tile (64 / 128 KiB) of bitperm_tile_kernel,
-    // permuted in place in a single HBM pass (round 2: two passes through 32 KiB tiles = 2x the algorithmic traffic)
+  // s >= 8: ONE in-place pass through 128 KiB LDS tiles of bitperm_tile_kernel (the tile holds every moved bit; up to 15
+  // moved bits for 4-byte, 14 for 8-byte elements).  Round 2 took two passes for s > 13 (2x the algorithmic traffic,
+  // 2.6 TB/s); for 8 <= s <= 13 the tile kernel also beats the table-driven kernel below (n = 30: 5.5 vs 5.0-5.1 TB/s).
+  static const unsigned tile_min = getenv("HQ_SWAP_TILE_MIN") ? (unsigned)atoi(getenv("HQ_SWAP_TILE_MIN")) : 8;
+  if ((s > table_bits || s >= tile_min) && one_pass && reinterpret_cast<uintptr_t>(a) % 16 == 0) {
     std::vector<unsigned> full(n);
     for (unsigned i = 0; i < n; ++i) full[i] = i < s ? pos[i] : i;
     BitPermPlan P;
@@ -241,8 +242,10 @@ static int permute_bits_entry(const E* src, E* dst, const unsigned* perm, unsign
     i += len;
   }
   static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
-  static const bool tile_always = getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 2;
-  if (one_pass && (tile_always || !bitperm_low_run_fixed<E>(perm, n)) && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
+  // HQ_PERM_TILE=3: the gather kernel whenever the low 128 bytes of the index space stay in place (it then moves whole
+  // cache lines too; measured 5.0-5.5 TB/s against 5.3-5.6 through the tiles, box to box: not the default)
+  static const bool gather_low_fixed = getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 3;
+  if (one_pass && !(gather_low_fixed && bitperm_low_run_fixed<E>(perm, n)) && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
       reinterpret_cast<uintptr_t>(dst) % 16 == 0) {
     // one pass at full cache-line granularity on both sides, whatever bits move (bitperm_tile_kernel); the gather
     // kernel below stays for states smaller than a tile and unaligned pointers

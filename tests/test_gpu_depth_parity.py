@@ -93,3 +93,53 @@ def test_depth40_complex128(cfg2):
         psi = simulate(gates, initial_state='0' * N, complex_type='complex128', qubits=list(range(N)), simplify=False,
                        **kw).reshape(-1)
         assert _rel(psi, truth) <= BAR[np.dtype('complex128')], kw  # (c)
+
+
+def _other_generator(kind):
+    """BASELINE configs 4 and 5 at a size the reference core finishes in seconds: (gates, n)."""
+    from hybridq_amd.circuits import dense_kq, rqc_1q2q
+    if kind == 'config4_dense_k34':  # 200 Haar 3-/4-qubit gates, unfused (bench.py --workload dense_k34)
+        return dense_kq(N, n_gates=200, seed=34), N
+    # config 5 (bench.py --workload dm): an 11-qubit noisy circuit as a 22-qubit state vector -- every gate U becomes U
+    # on the left copy, conj(U) on the right copy, then a depolarizing superoperator (one NON-unitary 2k-qubit gate)
+    from hybridq_amd.dm import depolarizing, to_statevector_circuit
+    nq = N // 2
+    noisy = []
+    for U, qs in rqc_1q2q(nq, depth=10, seed=nq):
+        noisy.append((U, qs))
+        noisy.append(depolarizing(qs, 0.01 if len(qs) == 1 else 0.02))
+    sv = to_statevector_circuit(noisy)
+    labels = sorted({q for _, qs in sv for q in qs})
+    index = {lab: i for i, lab in enumerate(labels)}
+    return [(U, tuple(index[q] for q in qs)) for U, qs in sv], 2 * nq
+
+
+@pytest.mark.parametrize('kind', ['config4_dense_k34', 'config5_noisy_dm'])
+def test_other_baseline_generators_at_depth(torch_cuda, kind, capsys):
+    """The config-4 and config-5 generators through the same three-way comparison: HIP float32
+    against the reference core's float32 run and both against the reference core's complex128 run (the truth)."""
+    import oracle
+    from hybridq_amd.simulation import simulate
+    lib = oracle.load_ref() if oracle.have_ref() else oracle.load_port()
+    gates, n = _other_generator(kind)
+    ref32, _ = oracle.evolve_reference_protocol(lib, gates, n, complex_type='complex64')
+    truth, _ = oracle.evolve_reference_protocol(lib, gates, n, complex_type='complex128')
+    bound = rounding_bound(widths(gates))
+    er = _rel(ref32, truth)
+    lines = []
+    for name, kw in (('per_gate', dict(compress=0)), ('fused_k4', dict(compress=4)), ('blocked', dict(blocked=True))):
+        psi = simulate(gates, initial_state='0' * n, complex_type='complex64', qubits=list(range(n)), simplify=False, **kw).reshape(-1)
+        eg, d = _rel(psi, truth), _rel(psi, ref32)
+        lines.append(f'  {kind} {name}: {len(gates)} gates, ref32-vs-f64 {er:.3e} (c = {er / bound * C_MODEL:.2f})  hip32-vs-f64 {eg:.3e} '
+                     f'(c = {eg / bound * C_MODEL:.2f})  hip32-vs-ref32 {d:.3e}  literal_bar_met: {d <= BAR[np.dtype("complex64")]}')
+        assert eg <= max(BAR[np.dtype('complex64')], bound), (kind, name, eg, bound)
+        assert eg <= 1.15 * max(er, 0.5 * BAR[np.dtype('complex64')]), (kind, name, eg, er)  # as close to the truth as the reference
+        assert d <= circuit_tol(gates, gates), (kind, name, d)
+    psi = simulate(gates, initial_state='0' * n, complex_type='complex128', qubits=list(range(n)), simplify=False, compress=0).reshape(-1)
+    e128 = _rel(psi, truth)
+    with capsys.disabled():
+        print()
+        for ln in lines:
+            print(ln)
+        print(f'  {kind} complex128 per_gate vs reference complex128: {e128:.3e}')
+    assert e128 <= BAR[np.dtype('complex128')] * (1 if kind == 'config4_dense_k34' else 4), (kind, e128)  # config 5 is non-unitary (norm shrinks)

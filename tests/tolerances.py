@@ -13,9 +13,12 @@ Measured constants (tests/test_gpu_depth_parity.py prints them on every run): BA
 generator, n = 22..24, depth 40 (660-720 one- and two-qubit gates): reference-f32 vs complex128
 c = 0.16..0.40 along the circuit, this repo's per-gate path the same 0.16..0.40, fused 0.28, blocked
 0.22; the 13 fused four-qubit gates of examples/circuit_simple.qasm (structured H/CZ/T products):
-0.73 between two float32 runs.  The tests take c = 1 (above everything measured, so they fail on a
-real defect -- a wrong matrix element is O(1e-2), a mis-rounded accumulation O(1e-5) -- and not on
-noise) and never go below the bar itself.  Two independent float32 evolutions may be apart by the
+0.73 between two float32 runs (0.52 per evolution); config-4 generator (200 dense 3-/4-qubit gates)
+0.2..0.3; config-5 generator (noisy 11-qubit circuit as a 22-qubit state vector, non-unitary
+superoperators) 0.3..0.4.  The tests take c = 0.6 (round 3; 1.0 before: VERDICT r02 -- 1.5x above the
+largest constant measured, so a kernel that loses a factor of two in accuracy fails, rounding noise does
+not) and never go below the bar itself.  Every end-to-end check also reports whether the LITERAL bar was
+met (`literal_bar_met`), whatever the model allows.  Two independent float32 evolutions may be apart by the
 root-sum-square of their individual bounds.  The depth test does NOT lean on this bound alone: it
 asserts that the HIP result is as close to the complex128 truth as the reference's own float32
 result is, prefix by prefix.
@@ -24,7 +27,7 @@ import numpy as np
 
 BAR = {np.dtype('complex64'): 1e-6, np.dtype('complex128'): 1e-12}
 _UNIT = {np.dtype('complex64'): float(np.finfo(np.float32).eps) / 2, np.dtype('complex128'): float(np.finfo(np.float64).eps) / 2}
-C_MODEL = 1.0
+C_MODEL = 0.6
 
 
 def widths(gates):
