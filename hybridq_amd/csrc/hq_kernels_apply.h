@@ -4,6 +4,15 @@
 #pragma once
 #include "hq_kernels_common.h"
 
+// Pins a wave-uniform value to scalar registers (stops the optimiser from hoisting per-lane copies of it out of a loop).
+// Under AddressSanitizer (-DHQ_ASAN: tools/asan_smoke.sh) the instrumented code computes it per lane and the constraint
+// cannot be met: the pin is dropped there, it only matters for speed.
+#ifdef HQ_ASAN
+#define HQ_PIN_SGPR(x) ((void)0)
+#else
+#define HQ_PIN_SGPR(x) asm volatile("" : "+s"(x))
+#endif
+
 namespace hq {
 
 // ---------------------------------------------------------------------------------
@@ -317,7 +326,7 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
   // loads they would be 2^NR live 64-bit values across the whole MFMA phase (spills at k = 6)
   auto store_x = [&](V (&x)[NL], const uint64_t it) {
     int64_t st_off = (int64_t)(16 * spread(it * 16));
-    asm volatile("" : "+s"(st_off));
+    HQ_PIN_SGPR(st_off);
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
       V* ptr = reinterpret_cast<V*>(lane_base + (st_off + tab.off[ld]));
@@ -895,7 +904,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 #pragma unroll
     for (unsigned i = 0; i < (PREF ? NPV : 1); ++i) {
       uint64_t sb = b | off_blk[i];
-      asm volatile("" : "+s"(sb));
+      HQ_PIN_SGPR(sb);
       pr[i] = __builtin_nontemporal_load(vre + (sb | off_tid));
       pi[i] = __builtin_nontemporal_load(vim + (sb | off_tid));
     }
@@ -1026,7 +1035,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 #pragma unroll
       for (unsigned i = 0; i < NPV; ++i) {
         uint64_t sb = base | off_blk[i];
-        asm volatile("" : "+s"(sb));
+        HQ_PIN_SGPR(sb);
         const uint64_t g = sb | off_tid;
         __builtin_nontemporal_store(sr[i], vre + g);
         __builtin_nontemporal_store(si[i], vim + g);
@@ -1165,7 +1174,7 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       uint64_t sb = b | off_blk[i];
-      asm volatile("" : "+s"(sb));
+      HQ_PIN_SGPR(sb);
       pr[i] = __builtin_nontemporal_load(pre + (sb | off_tid));
       pi[i] = __builtin_nontemporal_load(pim + (sb | off_tid));
     }
@@ -1255,7 +1264,7 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         uint64_t sb = base | off_blk[i];
-        asm volatile("" : "+s"(sb));
+        HQ_PIN_SGPR(sb);
         __builtin_nontemporal_store(sr[i], pre + (sb | off_tid));
         __builtin_nontemporal_store(si[i], pim + (sb | off_tid));
       }

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import golden_util as gu
-from tolerances import circuit_tol
+from tolerances import C_STRUCTURED, circuit_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -65,7 +65,7 @@ def test_simple_qasm_trace_and_circuit(torch_cuda):
     scale = np.abs(z['psi_sample']).max()
     psi = _replay_on_gpu(torch, z, 'trace_', n, torch.float32)
     calls = _trace_widths(z, 'trace_')  # the same 13 fused calls on both sides, both float32
-    tol = circuit_tol(calls, calls)
+    tol = circuit_tol(calls, calls, c=C_STRUCTURED)
     assert np.abs(psi[::stride] - z['psi_sample']).max() / scale < tol
     assert np.abs(psi[:8] - z['psi_head']).max() / scale < tol
     gates = gu.simple_qasm_gates(z)

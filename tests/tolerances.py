@@ -28,6 +28,10 @@ import numpy as np
 BAR = {np.dtype('complex64'): 1e-6, np.dtype('complex128'): 1e-12}
 _UNIT = {np.dtype('complex64'): float(np.finfo(np.float32).eps) / 2, np.dtype('complex128'): float(np.finfo(np.float64).eps) / 2}
 C_MODEL = 0.6
+#: circuits of STRUCTURED gates (examples/circuit_simple.qasm: H / CZ / T / sqrt-X products fused to 4 qubits; matrix
+#: entries 0, +-1/2, +-1/sqrt(2)...): the rounding errors of successive gates are correlated instead of a random walk;
+#: measured 0.73 between the reference's float32 run and ours (both schedules), so these tests take 0.8
+C_STRUCTURED = 0.8
 
 
 def widths(gates):
@@ -49,7 +53,7 @@ def widths(gates):
     return out
 
 
-def rounding_bound(gate_widths, complex_type='complex64'):
+def rounding_bound(gate_widths, complex_type='complex64', c=None):
     """c * u * sqrt(sum kappa_g 2^(k_g+1)): modelled distance of ONE evolution in `complex_type` from
     the exact one.  kappa_g = 1 for unitary gates.  A NON-unitary gate (the reference's own tests
     use Ginibre matrices, tests.py:299-391, 2335-2369) can amplify the relative error already
@@ -62,14 +66,14 @@ def rounding_bound(gate_widths, complex_type='complex64'):
     for w in gate_widths:
         k, kappa = (w if isinstance(w, tuple) else (w, 1.0))
         tot += kappa * 2.0 ** (k + 1)
-    return C_MODEL * _UNIT[ct] * float(np.sqrt(tot))
+    return (C_MODEL if c is None else c) * _UNIT[ct] * float(np.sqrt(tot))
 
 
-def circuit_tol(gates_a, gates_b=None, complex_type='complex64'):
+def circuit_tol(gates_a, gates_b=None, complex_type='complex64', c=None):
     """Allowed max|d| / max|psi| between an evolution applying `gates_a` and one applying `gates_b`
     (both in `complex_type`; ``gates_b=None``: the other side is exact / higher precision).
     Never below north_star's bar."""
     ct = np.dtype(complex_type)
-    ea = rounding_bound(widths(gates_a), ct)
-    eb = rounding_bound(widths(gates_b), ct) if gates_b is not None else 0.0
+    ea = rounding_bound(widths(gates_a), ct, c)
+    eb = rounding_bound(widths(gates_b), ct, c) if gates_b is not None else 0.0
     return max(BAR[ct], float(np.hypot(ea, eb)))
