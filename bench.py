@@ -438,6 +438,26 @@ def main():
                 'exchanges_per_step': n_exchanges,
                 'of_which_with_folded_permutation': n_permutes,
             }
+            # what the first record on a real multi-GPU node should show (VERDICT r02 next #1d): every figure below is
+            # arithmetic on the sizes, the 153 GB/s per xGMI link of the guide and single-GPU rates measured in
+            # profiles/ (r03_perm_rate.txt: pack pass 5.3-5.7 TB/s; r03_v1_bench.json: 6.2-6.4 TB/s gate kernels)
+            gate_ms_model = bytes_per_gate / 6.3e12 * 1e3
+            pack_ms_model = 2 * shard_bytes / 5.4e12 * 1e3
+            link_ms = chunk_bytes / 153e9 * 1e3
+            n_local_gates = len(gates)
+            result['exchange']['expected'] = {
+                'bytes_per_link_per_exchange': chunk_bytes,          # both planes, one peer; the G-1 links of a GPU run in parallel
+                'ms_at_153GBps': link_ms,
+                'pack_pass_ms_at_5.4TBps': pack_ms_model,            # only exchanges with a folded permutation pack
+                'self_chunk_copy_ms_at_5TBps': 2 * chunk_bytes / 5.0e12 * 1e3,
+                'ms_per_exchange_model': link_ms,
+                'ms_per_exchange_with_folded_permutation_model': [max(link_ms, pack_ms_model), link_ms + pack_ms_model],  # [planes overlap fully, not at all]
+                'local_gate_ms_at_6.3TBps': gate_ms_model,
+                'ms_per_step_model': n_local_gates * gate_ms_model + (n_exchanges - n_permutes) * link_ms + n_permutes * (link_ms + pack_ms_model),
+                'exchange_share_of_step_model': ((n_exchanges - n_permutes) * link_ms + n_permutes * (link_ms + pack_ms_model)) /
+                                                max(1e-9, n_local_gates * gate_ms_model + (n_exchanges - n_permutes) * link_ms + n_permutes * (link_ms + pack_ms_model)),
+                'note': 'model, not a measurement: compare with ms_per_exchange / GBps_per_link above on a node with xGMI',
+            }
         except Exception as e:  # noqa: BLE001
             result['extras_error'] = repr(e)
     if rank == 0 and (events is not None or (sharded_path and op_timer is not None)):

@@ -219,3 +219,30 @@ def test_simulate_and_dm_simulate_sharded_api(torch_cuda, tmp_path, world):
     exp = oracle.evolve_tensordot(gates, n, initial_state=init, qubits=list(range(n)))
     assert np.abs(out['psi'] - exp).max() / np.abs(exp).max() < 1e-12
     assert np.abs(out['cat'] - exp).max() / np.abs(exp).max() < 1e-12  # rank-ordered shards = canonical state
+
+
+@pytest.mark.parametrize('workload,qubits', [('rqc_1q2q', 21), ('dm', 20)])
+def test_bench_eight_ranks_sharing_the_gpu(torch_cuda, workload, qubits):
+    """`bench.py --gpus 8` exactly as the driver launches it (torch.distributed.run, one process per rank), both sharded
+    workloads (BASELINE configs 3 and 5 at toy size), with the eight ranks sharing the one GPU of this box
+    (HQ_BENCH_SHARE_GPU=1: gloo process group, peer-to-peer exchange through HIP IPC): the whole N > 1 code path of the
+    bench -- planner, exchanges with folded permutations, per-op events, exchange timing block with its analytic
+    expectation -- runs and prints ONE well-formed JSON line.  The numbers mean nothing on a shared GPU."""
+    import json
+    import subprocess
+    env = dict(os.environ, HQ_BENCH_SHARE_GPU='1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+           '--qubits', str(qubits), '--depth', '6', '--workload', workload, '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['steps'] == 2 and d['value'] > 0
+    assert d['config']['n_qubits'] == qubits and d['config']['exchanges_per_step'] >= 1
+    ex = d['exchange']
+    assert ex['transport'] == 'p2p' and not ex['transport_note'], ex
+    assert ex['expected']['bytes_per_link_per_exchange'] == ex['bytes_per_link'] == d['config']['state_bytes_per_gpu'] // 8
+    assert ex['expected']['ms_at_153GBps'] == pytest.approx(ex['bytes_per_link'] / 153e9 * 1e3)
+    assert 'extras_error' not in d, d['extras_error']

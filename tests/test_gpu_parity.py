@@ -18,8 +18,11 @@ CT_OF = {np.dtype('float32'): 'complex64', np.dtype('float64'): 'complex128'}
 
 def wide_tol(ft, k):
     """One k-qubit call, HIP vs the oracle in the SAME precision: the bar, or the rounding model of
-    two 2^(k+1)-term accumulations (tests/tolerances.py) once that exceeds it (k >= 8 in float32)."""
-    return circuit_tol([k], [k], complex_type=CT_OF[np.dtype(ft)])
+    two 2^(k+1)-term accumulations (tests/tolerances.py) once that exceeds it (k >= 7 in float32).  ONE wide call is
+    not a random walk over many gates: the figure is the maximum over 2^n amplitudes of a single 2^(k+1)-term sum with
+    Gaussian matrix entries, i.e. the tail of that distribution -- measured constant 0.78 at k = 7 (1.05e-6 between the
+    matrix-core kernel and the C oracle, n = 12) -- so this bound keeps c = 1 while the end-to-end tests use C_MODEL."""
+    return circuit_tol([k], [k], complex_type=CT_OF[np.dtype(ft)], c=1.0)
 
 
 def _rand_state(rng, n, ft):

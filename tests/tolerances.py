@@ -14,8 +14,8 @@ generator, n = 22..24, depth 40 (660-720 one- and two-qubit gates): reference-f3
 c = 0.16..0.40 along the circuit, this repo's per-gate path the same 0.16..0.40, fused 0.28, blocked
 0.22; the 13 fused four-qubit gates of examples/circuit_simple.qasm (structured H/CZ/T products):
 0.73 between two float32 runs (0.52 per evolution); config-4 generator (200 dense 3-/4-qubit gates)
-0.2..0.3; config-5 generator (noisy 11-qubit circuit as a 22-qubit state vector, non-unitary
-superoperators) 0.3..0.4.  The tests take c = 0.6 (round 3; 1.0 before: VERDICT r02 -- 1.5x above the
+0.31..0.34 (reference 0.32); config-5 generator (noisy 11-qubit circuit as a 22-qubit state vector,
+non-unitary superoperators) 0.11..0.25 (reference 0.27).  The tests take c = 0.6 (round 3; 1.0 before: VERDICT r02 -- 1.5x above the
 largest constant measured, so a kernel that loses a factor of two in accuracy fails, rounding noise does
 not) and never go below the bar itself.  Every end-to-end check also reports whether the LITERAL bar was
 met (`literal_bar_met`), whatever the model allows.  Two independent float32 evolutions may be apart by the
