@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import golden_util as gu
-from tolerances import BAR, circuit_tol
+from tolerances import BAR, C_STRUCTURED, circuit_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -167,8 +167,8 @@ def test_qasm_text_to_gpu(torch_cuda):
     stride = int(z['sample_stride'])
     scale = np.abs(z['psi_sample']).max()
     calls = [len(pos) for kind, pos, _ in gu.trace(z, 'trace_') if kind == 'U']
-    assert np.abs(psi[::stride] - z['psi_sample']).max() / scale < circuit_tol(calls, calls)
-    assert np.abs(psi[:8] - z['psi_head']).max() / scale < circuit_tol(calls, calls)
+    assert np.abs(psi[::stride] - z['psi_sample']).max() / scale < circuit_tol(calls, calls, c=C_STRUCTURED)
+    assert np.abs(psi[:8] - z['psi_head']).max() / scale < circuit_tol(calls, calls, c=C_STRUCTURED)
 
 
 def test_stream_switch_is_ordered(torch_cuda):
