@@ -333,7 +333,7 @@ static int launch_mfma_big_kv(Context& c, T* re, T* im, const T* dA, const MfmaP
   // experiment / candidate default: one wave per SIMD with two register sets and the memory operations interleaved into
   // the MFMA stream (apply_mfma_stream_kernel); HQ_BIG_STREAM = quarters of the phase the memory operations span (2..4)
   static const int stream_q = getenv("HQ_BIG_STREAM") ? atoi(getenv("HQ_BIG_STREAM")) : 0;
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (sizeof(T) == 4) {  // complex128 k = 6 with two register sets spills (256 + 256 registers, 308 B scratch): float only
     if (stream_q >= 2 && stream_q <= 4) {
       constexpr unsigned CBs = Vec<T>::VB;
       constexpr int NSs = KBITS - 2, NRBs = 1 << (NSs - 2), NSTEPs = 1 << NSs;

@@ -140,7 +140,9 @@ def test_state_allocator_behind_the_c_abi(torch_cuda):
     finally:
         del os.environ['HQ_STATE_TRIES']
     info = owner.info
-    assert len(info['draws']) == 3 and info['chosen'] in [d['layout'] for d in info['draws']]
+    fresh = [d for d in info['draws'] if 'the same granules' not in d['layout']]  # + the winner's granules re-probed in creation order
+    assert len(fresh) == 3 and len(info['draws']) in (3, 4)
+    assert info['chosen'].split(', remapped')[0] in [d['layout'] for d in fresh]
     assert min(d['probe_ms_per_gate'] for d in info['draws']) == pytest.approx(info['probe_ms_per_gate'], rel=1e-6)
     assert owner.re % 32 == 0 and owner.im % 32 == 0 and owner.stride >= (1 << n)
     a = torch.as_tensor(owner, device='cuda')[:, :1 << n]
