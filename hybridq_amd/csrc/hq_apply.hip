@@ -753,6 +753,18 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
     case Mode::Auto:
       break;
   }
+  // north_star reserves the matrix cores for k >= 4.  Measured per position class on both placements
+  // (profiles/r03_sweep_valu_vs_mfma.txt, n = 30): with every target at index bit >= 8 the VALU butterfly kernel ties with the
+  // role kernel (+-1 %) and wins 1.5-4 % for pairs / triples of high targets, at the same power and clock; with a target
+  // below bit 8 the role kernel wins 2-40 % (its q digits turn the stride into a permutation of a contiguous run).  So
+  // Auto sends k <= 3 gates whose targets all sit at bit >= 8 to the VALU kernel and keeps the role kernel for the rest
+  // (HQ_VALU_HIGH=0: role kernel everywhere, the round-2 default).
+  static const bool valu_high = !(getenv("HQ_VALU_HIGH") && atoi(getenv("HQ_VALU_HIGH")) == 0);
+  if (c.mode == Mode::Auto && valu_high && can_direct && k <= 3 && n >= 20 && sizeof(T) == 4) {  // measured for complex64 only
+    unsigned lo = pos[0];
+    for (unsigned j = 1; j < k; ++j) lo = std::min(lo, pos[j]);
+    if (lo >= 8) return launch_direct<T>(c, re, im, U, pos, n, k);
+  }
   if (can_mfma) return run_mfma();
   if (can_direct) return launch_direct<T>(c, re, im, U, pos, n, k);
   if ((c.mode == Mode::Auto || c.mode == Mode::Mfma) && mfma_tile_ok<T>(n, k))

@@ -370,6 +370,52 @@ class EvolutionState:
         core.to_complex(self.planes[0], self.planes[1], out)
         return out
 
+    def to_numpy(self):
+        """The state as ONE complex numpy array (the reference's return value, simulation.py:669-675).  Large states never
+        exist as a 2^n complex tensor in HBM (round 3; at n = 34 planes + complex copy + scratch would not fit 288 GB):
+        to_complex runs chunk by chunk -- 128 MiB of interleaved amplitudes at a time into a small ring of device
+        staging buffers, each followed by its asynchronous copy into page-locked host memory, while four threads move
+        finished chunks into the result array (the chunked return path of _to_host with the interleave fused in)."""
+        torch = _torch()
+        cdt = {np.dtype('complex64'): torch.complex64, np.dtype('complex128'): torch.complex128}[self.complex_type]
+        size = 1 << self.n
+        chunk = (128 << 20) // self.complex_type.itemsize
+        stage = None
+        if size * self.complex_type.itemsize >= CHUNKED_RETURN_MIN_BYTES and size % chunk == 0:
+            try:
+                stage = [torch.empty(chunk, dtype=cdt, pin_memory=True) for _ in range(8)]
+            except RuntimeError:  # no page-locked memory to be had: the one-shot path
+                stage = None
+        if stage is None:
+            out = self.to_complex()
+            core.sync()
+            return _to_host(out)
+        from concurrent.futures import ThreadPoolExecutor
+        core.use_torch_stream()
+        depth = len(stage)
+        dev = [torch.empty(chunk, dtype=cdt, device=self.device) for _ in range(4)]
+        res = np.empty(size, dtype=self.complex_type)
+        done = [torch.cuda.Event() for _ in range(depth)]
+        futures = [None] * depth
+
+        def drain(c, s):
+            done[s].synchronize()
+            res[c * chunk:(c + 1) * chunk] = stage[s].numpy()
+
+        with ThreadPoolExecutor(4) as pool:
+            for c in range(size // chunk):
+                s, d = c % depth, c % len(dev)
+                if futures[s] is not None:
+                    futures[s].result()  # the staging buffer is free again (its device buffer was read 4 chunks ago)
+                core.to_complex(self.planes[0][c * chunk:(c + 1) * chunk], self.planes[1][c * chunk:(c + 1) * chunk], dev[d])
+                stage[s].copy_(dev[d], non_blocking=True)  # same stream: ordered behind the interleave kernel
+                done[s].record()
+                futures[s] = pool.submit(drain, c, s)
+            for f in futures:
+                if f is not None:
+                    f.result()
+        return res
+
     def norm2(self):
         core.use_torch_stream()
         return core.norm2(self.planes[0], self.planes[1])
@@ -616,9 +662,7 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     info['n_qubits'] = n
 
     if kwargs['return_numpy_array']:
-        out = state.to_complex()
-        core.sync()
-        psi = _to_host(out).reshape((2,) * n)
+        psi = state.to_numpy().reshape((2,) * n)
     else:
         psi = state
     return (psi, info) if kwargs['return_info'] else psi

@@ -191,3 +191,48 @@ def test_c_abi_state_demo_without_python(torch_cuda, tmp_path):
     print('\n  ' + line)
     assert vals['from_pool'] == '1' and float(vals['realloc_s']) < 0.05
     assert float(vals['tuned_TBps']) > 0.97 * float(vals['plain_TBps'])  # never worse than the caller's own hipMalloc planes
+
+
+def test_auto_dispatch_follows_the_measured_rule(torch_cuda):
+    """Auto dispatch for k <= 3 in complex64 (north_star: matrix cores only where they pay): every target at index bit >= 8
+    -> the VALU butterfly kernel, any target below bit 8 -> the matrix-core role kernel; k >= 4 always matrix cores.  Both
+    against the oracle at the per-call bar."""
+    import oracle
+    from oracle.binding import aligned_empty
+    from hybridq_amd import core
+    torch = torch_cuda
+    lib = oracle.load_port()
+    n = 21
+    rng = np.random.default_rng(8)
+    core.use_torch_stream()
+    for pos, want in (([8], 'direct'), ([20], 'direct'), ([9, 17], 'direct'), ([19, 8, 13], 'direct'), ([7], 'mfma'), ([3, 15], 'mfma'),
+                      ([0, 9, 20], 'mfma'), ([8, 9, 10, 11], 'mfma'), ([10, 12, 14, 16, 18], 'mfma')):
+        k = len(pos)
+        pl = aligned_empty((2, 1 << n), np.float32)
+        pl[:] = rng.standard_normal((2, 1 << n)).astype(np.float32)
+        U = ((rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k))) / np.sqrt(2.0 * (1 << k))).astype(np.complex64)
+        dev = torch.from_numpy(pl.copy()).cuda()
+        core.apply_U(dev[0], dev[1], U, pos, n)
+        core.sync()
+        assert core.last_kernel() == want, (pos, core.last_kernel())
+        assert lib.apply_U(pl[0], pl[1], U, pos) == 0
+        got = dev.cpu().numpy()
+        assert np.abs(got - pl).max() / np.abs(pl).max() <= 1e-6, pos
+
+
+def test_to_numpy_never_holds_the_complex_state_in_hbm(torch_cuda):
+    """EvolutionState.to_numpy (simulate's return path): interleave fused into the chunked device -> host copy -- the extra
+    device memory stays at the four 128 MiB staging chunks whatever the state size (n = 27: a 1 GiB complex copy before)."""
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    torch = torch_cuda
+    n = 27
+    st = simulate(rqc_1q2q(n, depth=2, seed=5), initial_state='+' * n, qubits=list(range(n)), return_numpy_array=False, compress=0)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.memory_allocated()
+    psi = st.to_numpy()
+    extra = torch.cuda.max_memory_allocated() - before
+    assert extra <= 4 * (128 << 20) + (16 << 20), extra
+    ref = st.to_complex().cpu().numpy()
+    assert psi.dtype == np.complex64 and np.array_equal(psi, ref)

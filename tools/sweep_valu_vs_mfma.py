@@ -43,4 +43,38 @@ for pos in cases:
     core.set_apply_mode('auto')
     d, m = row['direct'][0], row['mfma'][0]
     print(f'k={len(pos)} pos={str(pos):<14} direct {d:6.3f} ms ({row["direct"][1]})  mfma {m:6.3f} ms  mfma/direct {m / d:5.3f}', flush=True)
-print('sum', tot)
+print('sum', tot, 'placement', os.environ.get('HQ_STATE_ALLOC', 'vmm (tuned)'))
+
+# power / clock under each family (rocm-smi sampled in the middle of a 300-launch loop)
+import subprocess
+import threading
+
+
+def smi():
+    try:
+        out = subprocess.run(['rocm-smi', '--showpower', '--showclocks'], capture_output=True, text=True, timeout=20).stdout
+        keep = [ln.split('GPU[0]')[-1].strip(' :\t') for ln in out.splitlines() if any(k in ln for k in ('Power (W)', 'sclk'))]
+        return ' | '.join(keep)
+    except Exception as e:  # noqa: BLE001
+        return repr(e)
+
+
+for pos in ([12], [5, 20], [2, 3], [10, 17, 25]):
+    U = haar_unitary(1 << len(pos), rng)
+    for mode in ('direct', 'mfma'):
+        core.set_apply_mode(mode)
+        core.apply_U(planes[0], planes[1], U, pos)
+        torch.cuda.synchronize()
+        box = {}
+        t = threading.Thread(target=lambda: box.update(s=smi()))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(300):
+            core.apply_U(planes[0], planes[1], U, pos)
+            if i == 60:
+                t.start()
+        e1.record()
+        torch.cuda.synchronize()
+        t.join()
+        print(f'k={len(pos)} pos={str(pos):<14} {mode:<6} {e0.elapsed_time(e1) / 300:6.3f} ms   [{box.get("s")}]', flush=True)
+    core.set_apply_mode('auto')
