@@ -628,6 +628,29 @@ def main():
         except Exception as e:  # noqa: BLE001
             result['valu_direct_only_error'] = repr(e)
     if rank == 0 and not sharded_path and not args.no_fused:
+        try:  # a reported extra: the same step through the matrix-core role kernel ONLY (the round-2 default; Auto now sends
+            # k <= 3 gates with every target at bit >= 8 to the VALU kernel): same state, same process, back to back
+            core.set_apply_mode('mfma')
+            try:
+                run_step()
+                barrier()
+                t0r = time.perf_counter()
+                run_step()
+                barrier()
+                elr = time.perf_counter() - t0r
+            finally:
+                core.set_apply_mode('auto')
+            run_step()
+            barrier()
+            t0a = time.perf_counter()
+            run_step()
+            barrier()
+            ela = time.perf_counter() - t0a
+            result['role_kernel_only'] = {'ms_per_step': 1e3 * elr, 'gate_apps_per_s': len(gates) / elr,
+                                          'auto_ms_per_step_back_to_back': 1e3 * ela, 'auto_gate_apps_per_s_back_to_back': len(gates) / ela}
+        except Exception as e:  # noqa: BLE001
+            result['role_kernel_only_error'] = repr(e)
+    if rank == 0 and not sharded_path and not args.no_fused:
         try:  # a reported extra: a failure here must never cost the headline line
             # one gate of every width on the same resident state (k >= 5 reach the matrix cores through
             # apply_mfma_big_kernel / apply_gemm_kernel): ms per gate, HBM rate and MFMA rate
