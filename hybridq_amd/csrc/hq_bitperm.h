@@ -13,6 +13,7 @@ struct BitPermPlan {
   bool vread = false;   // the vector-component bits stay: 16-byte LDS reads
   unsigned block = 256, nv = 4;
   bool pref = false;
+  int split = 0;        // 1..3: one moved bit more than the 128 KiB tile holds (bitperm_tile_kernel SPLIT mode)
   size_t lds = 0;
 };
 
@@ -50,6 +51,8 @@ static bool plan_bitperm(const unsigned* perm, unsigned m, bool inplace, BitPerm
   for (unsigned i = 0; i < m; ++i) inv[perm[i]] = i;
   uint64_t T = 0;
   unsigned tb;
+  unsigned split_b = 0, split_rank = 0;
+  bool split_b_set = false;
   if (inplace) {
     for (unsigned b = 0; b < c; ++b) T |= 1ull << b;
     for (unsigned i = 0; i < m; ++i)
@@ -60,8 +63,29 @@ static bool plan_bitperm(const unsigned* perm, unsigned m, bool inplace, BitPerm
     // on 64 KiB tiles 4.2-4.9 (HQ_PERM_INPLACE_TB overrides)
     static const int forced_ip = getenv("HQ_PERM_INPLACE_TB") ? atoi(getenv("HQ_PERM_INPLACE_TB")) : 0;
     tb = std::max(need, std::min(m, forced_ip ? (unsigned)forced_ip - (sizeof(E) == 4 ? 0u : 1u) : max_tb));
-    if (need > max_tb || tb > m || tb > max_tb) return false;
-    for (unsigned b = 0; b < m && (unsigned)__builtin_popcountll(T) < tb; ++b) T |= 1ull << b;  // lowest fixed bits
+    static const bool allow_split = !(getenv("HQ_PERM_SPLIT") && atoi(getenv("HQ_PERM_SPLIT")) == 0);
+    if (need == max_tb + 1 && allow_split) {
+      // one moved bit too many for the LDS tile: take a moved bit b out of the tile (SPLIT mode of the kernel).  b must be
+      // one of the three highest tile bits whose source side rank is an iteration bit, and neither b nor perm[b] may be
+      // one of the contiguous run bits
+      std::vector<unsigned> Tb;
+      for (unsigned i = 0; i < m; ++i) if ((T >> i) & 1) Tb.push_back(i);
+      for (int cand = (int)Tb.size() - 1; cand >= (int)Tb.size() - 3 && !split_b_set; --cand) {
+        const unsigned b = Tb[cand], pb = perm[b];
+        if (pb == b || b < c || pb < c) continue;
+        unsigned rank = 0;  // rank of b among the source bits of the reduced tile: S' = T minus {pb}
+        for (unsigned v : Tb) if (v < b && v != pb) ++rank;
+        const unsigned tbr = max_tb;
+        if (rank + 3 < tbr) continue;
+        split_b = b; split_rank = rank; split_b_set = true;
+      }
+      if (!split_b_set) return false;
+      T &= ~(1ull << split_b);
+      tb = max_tb;
+    } else {
+      if (need > max_tb || tb > m || tb > max_tb) return false;
+      for (unsigned b = 0; b < m && (unsigned)__builtin_popcountll(T) < tb; ++b) T |= 1ull << b;  // lowest fixed bits
+    }
   } else {
     tb = bitperm_default_tb<E>();
     if (tb > m) return false;
@@ -128,6 +152,16 @@ static bool plan_bitperm(const unsigned* perm, unsigned m, bool inplace, BitPerm
     ++a.nfields;
     i += len;
   }
+  // bits the tile number skips when it is deposited into the index
+  a.nb = 0;
+  for (unsigned b = 0; b < m; ++b)
+    if (((T >> b) & 1) || (split_b_set && b == split_b)) a.bpos[a.nb++] = (unsigned char)b;
+  P.split = 0;
+  if (split_b_set) {
+    a.half_x = 1ull << split_b;
+    a.half_y = 1ull << perm[split_b];
+    P.split = (int)(split_rank - (tb - 3)) + 1;
+  }
   P.vread = true;
   for (unsigned b = 0; b < VB; ++b) P.vread = P.vread && perm[b] == b;
   const unsigned nvec = (1u << tb) >> VB;
@@ -148,12 +182,12 @@ static bool plan_bitperm(const unsigned* perm, unsigned m, bool inplace, BitPerm
   return true;
 }
 
-template <typename E, int BLOCK, int NV, bool VREAD, bool PREF>
+template <typename E, int BLOCK, int NV, bool VREAD, bool PREF, int SPLIT = 0>
 static int launch_bitperm_inst(Context& c, hipStream_t s, bool on_lib_stream, const E* s0, const E* s1, const BitPermPlan& P,
                                uint64_t ntiles) {
   static bool attr_done = false;  // per instantiation, under the context mutex
   if (!attr_done) {
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF>,
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     attr_done = true;
   }
@@ -164,9 +198,9 @@ static int launch_bitperm_inst(Context& c, hipStream_t s, bool on_lib_stream, co
   const unsigned grid = (unsigned)std::min<uint64_t>(total, 256 * per_cu * (BLOCK == 256 ? (uint64_t)grid_mult : 1));
   const BitPermArg a = P.a;
   if (on_lib_stream) {
-    HQ_LAUNCH(c, (bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF>), dim3(grid), dim3(BLOCK), P.lds, s0, s1, a, ntiles);
+    HQ_LAUNCH(c, (bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF, SPLIT>), dim3(grid), dim3(BLOCK), P.lds, s0, s1, a, ntiles);
   } else {
-    hipLaunchKernelGGL((bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF>), dim3(grid), dim3(BLOCK), P.lds, s, s0, s1, a, ntiles);
+    hipLaunchKernelGGL((bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF, SPLIT>), dim3(grid), dim3(BLOCK), P.lds, s, s0, s1, a, ntiles);
   }
   HQ_HIP_CHECK(hipGetLastError());
   return 0;
@@ -175,7 +209,15 @@ static int launch_bitperm_inst(Context& c, hipStream_t s, bool on_lib_stream, co
 // s = stream to launch on; on_lib_stream = it is the library stream (the launch may then be recorded into a program)
 template <typename E>
 static int launch_bitperm(Context& c, hipStream_t s, bool on_lib_stream, const E* s0, const E* s1, const BitPermPlan& P) {
-  const uint64_t ntiles = 1ull << (P.a.m - P.a.tb);
+  const uint64_t ntiles = 1ull << (P.a.m - P.a.nb);
+  if (P.split) {
+    if (P.block != 1024 || P.nv != 8 || P.a.planes != 1) return fail("bitperm: bad split plan");
+#define HQ_BPS(V, S) return launch_bitperm_inst<E, 1024, 8, V, false, S>(c, s, on_lib_stream, s0, s1, P, ntiles)
+    if (P.vread) { switch (P.split) { case 1: HQ_BPS(true, 1); case 2: HQ_BPS(true, 2); case 3: HQ_BPS(true, 3); } }
+    else { switch (P.split) { case 1: HQ_BPS(false, 1); case 2: HQ_BPS(false, 2); case 3: HQ_BPS(false, 3); } }
+#undef HQ_BPS
+    return fail("bitperm: bad split plan");
+  }
 #define HQ_BP(B, N, V, PF) return launch_bitperm_inst<E, B, N, V, PF>(c, s, on_lib_stream, s0, s1, P, ntiles)
   if (P.block == 256) {
     if (P.vread) {

@@ -27,24 +27,13 @@ interleave4_kernel(const T* __restrict__ re, const T* __restrict__ im, T* __rest
                    const uint64_t nquads) {
   using Q = typename Vec<T>::quad;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  // streamed once: non-temporal loads and stores, two quads per plane in flight per thread (round 3: 5.25 -> see
-  // profiles/r03_*bench*.json `aux.to_complex`)
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nquads; i += 2 * stride) {
-    const uint64_t i2 = i + stride < nquads ? i + stride : i;
-    const Q r = __builtin_nontemporal_load(reinterpret_cast<const Q*>(re) + i);
-    const Q m = __builtin_nontemporal_load(reinterpret_cast<const Q*>(im) + i);
-    const Q r2 = __builtin_nontemporal_load(reinterpret_cast<const Q*>(re) + i2);
-    const Q m2 = __builtin_nontemporal_load(reinterpret_cast<const Q*>(im) + i2);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nquads; i += stride) {
+    const Q r = reinterpret_cast<const Q*>(re)[i];
+    const Q m = reinterpret_cast<const Q*>(im)[i];
     Q o0 = {r[0], m[0], r[1], m[1]};
     Q o1 = {r[2], m[2], r[3], m[3]};
-    __builtin_nontemporal_store(o0, reinterpret_cast<Q*>(out) + 2 * i);
-    __builtin_nontemporal_store(o1, reinterpret_cast<Q*>(out) + 2 * i + 1);
-    if (i2 != i) {
-      Q p0 = {r2[0], m2[0], r2[1], m2[1]};
-      Q p1 = {r2[2], m2[2], r2[3], m2[3]};
-      __builtin_nontemporal_store(p0, reinterpret_cast<Q*>(out) + 2 * i2);
-      __builtin_nontemporal_store(p1, reinterpret_cast<Q*>(out) + 2 * i2 + 1);
-    }
+    reinterpret_cast<Q*>(out)[2 * i] = o0;  // (non-temporal loads / stores with two quads in flight measured SLOWER: 4.46 vs 5.29 TB/s)
+    reinterpret_cast<Q*>(out)[2 * i + 1] = o1;
   }
 }
 

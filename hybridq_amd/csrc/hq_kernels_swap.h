@@ -305,10 +305,19 @@ struct BitPermArg {
   unsigned char sw_hi[4], sw_lo[4];         // LDS element address ^= bit(u, sw_hi) << sw_lo
   unsigned nfields;                         // tile base: runs of non-tile dst bits -> src bits
   unsigned char f_from[48], f_to[48], f_len[48];
+  unsigned nb;                              // bits the tile number skips: the tile bits (+ the half bit in SPLIT mode), ascending
+  unsigned char bpos[kBitPermMaxTile + 1];
+  uint64_t half_x, half_y;                  // SPLIT: 1 << b (dst side), 1 << perm[b] (src side)
   void* dst[kMaxShardRanks][2];             // [chunk][plane]
 };
 
-template <typename E, int BLOCK, int NV, bool VREAD, bool PREF>
+// SPLIT = 1, 2, 3 (in place, BLOCK = 1024, NV = 8): ONE bit more than 128 KiB of LDS hold.  The 2^(tb+1)-element block is
+// cut by a moved dst bit b (x_b = v) on the destination side and by p = perm[b] (y_p = v) on the source side; the four
+// address quarters Q(b, p) are handled in the order  read S0 = Q(0,0) u Q(1,0) -> LDS;  read Q(0,1) -> REGISTERS;
+// write D0 = Q(0,0) u Q(0,1);  LDS <- S1 = Q(0,1) (from the registers) u Q(1,1) (from memory, still untouched);
+// write D1 = Q(1,0) u Q(1,1): every element is read once before its address is overwritten, one HBM pass.  On the source
+// side b is iteration bit SPLIT-1 of a thread's eight vectors, so the register-held quarter is a static half of them.
+template <typename E, int BLOCK, int NV, bool VREAD, bool PREF, int SPLIT = 0>
 __global__ void __launch_bounds__(BLOCK)
 bitperm_tile_kernel(const E* __restrict__ src0, const E* __restrict__ src1, const BitPermArg a, const uint64_t ntiles) {
   constexpr int VEC = 16 / (int)sizeof(E);
@@ -359,8 +368,8 @@ bitperm_tile_kernel(const E* __restrict__ src0, const E* __restrict__ src1, cons
   const uint64_t wmask = (1ull << a.cbits) - 1;
   auto bases = [&](uint64_t h, uint64_t& xb, uint64_t& yb) {
     xb = h;  // deposit the tile number into the non-tile dst bits
-    for (unsigned k = 0; k < a.tb; ++k) {
-      const uint64_t lo = (1ull << a.tpos[k]) - 1;
+    for (unsigned k = 0; k < a.nb; ++k) {
+      const uint64_t lo = (1ull << a.bpos[k]) - 1;
       xb = ((xb & ~lo) << 1) | (xb & lo);
     }
     yb = 0;
@@ -406,7 +415,58 @@ bitperm_tile_kernel(const E* __restrict__ src0, const E* __restrict__ src1, cons
       }
     }
   };
-  if constexpr (PREF) {
+  if constexpr (SPLIT > 0) {
+    static_assert(NV == 8 && !PREF, "split mode: eight vectors per thread");
+    constexpr int UB = SPLIT - 1;  // iteration bit that is address bit b on the source side
+    auto store_half = [&](uint64_t xb) {
+      constexpr int CH = VREAD ? 4 : 2;  // element gathers: two vectors at a time keep the kernel inside 128 registers
+#pragma unroll
+      for (int i0 = 0; i0 < NV; i0 += CH) {
+        PackV o[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const int i = i0 + j;
+          if constexpr (VREAD) {
+            o[j] = *reinterpret_cast<const PackV*>(buf + (r_tid ^ r_it[i]));
+          } else {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) o[j][c] = buf[r_tid ^ r_it[i] ^ rc[c]];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const uint64_t x = xb | x_tid | x_it[i0 + j];
+          __builtin_nontemporal_store(o[j], reinterpret_cast<PackV*>(reinterpret_cast<E*>(dptr[0][0]) + x));
+        }
+      }
+    };
+    for (uint64_t h = blockIdx.x; h < ntiles; h += gridDim.x) {  // ntiles = number of 2^(tb+1) blocks
+      uint64_t xb, yb;
+      bases(h, xb, yb);
+      PackV v[NV], q[NV / 2];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = __builtin_nontemporal_load(reinterpret_cast<const PackV*>(src0 + (yb | y_tid | y_it[i])));
+      __syncthreads();  // the previous block's LDS reads are done (and dptr is visible)
+      fill(v);
+#pragma unroll
+      for (int i = 0, k = 0; i < NV; ++i)
+        if (!((i >> UB) & 1)) q[k++] = __builtin_nontemporal_load(reinterpret_cast<const PackV*>(src0 + (yb | a.half_y | y_tid | y_it[i])));
+      // Q(0,1) must have been READ by every thread before any thread overwrites it with D0: the loads are waited for HERE,
+      // in front of the barrier (a load still in flight across the barrier could see another wave's store)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      store_half(xb);
+      __syncthreads();  // also keeps the loads below from being scheduled into the gathers above (register pressure)
+#pragma unroll
+      for (int i = 0, k = 0; i < NV; ++i) {
+        if (!((i >> UB) & 1)) v[i] = q[k++];
+        else v[i] = __builtin_nontemporal_load(reinterpret_cast<const PackV*>(src0 + (yb | a.half_y | y_tid | y_it[i])));
+      }
+      fill(v);
+      __syncthreads();
+      store_half(xb | a.half_x);
+    }
+  } else if constexpr (PREF) {
     // one or two workgroups per CU: the next tile is requested into registers while this one is permuted and stored
     // (unconditional prefetch on a clamped tile number, LDS fill after the stores: the recipe of apply_blocked_kernel)
     if (blockIdx.x >= total) return;

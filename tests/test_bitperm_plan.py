@@ -20,3 +20,6 @@ def test_bitperm_planner_and_index_arithmetic(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     assert ' 0 failed' in run.stdout and ' 0 skipped' in run.stdout, run.stdout
+    import re
+    m = re.search(r'split mode: (\d+) cases ran', run.stdout)  # 16 / 15 moved bits in place through the register-held quarter
+    assert m and int(m.group(1)) >= 8, run.stdout

@@ -50,10 +50,11 @@ def test_permute_bits_one_pass_tiles(torch_cuda, dt, m):
         assert torch.equal(dst, data[_source_index(torch, idx, perm)]), (dt, m, name, list(perm))
 
 
-@pytest.mark.parametrize('dt,n,sizes', [('float32', 26, (14, 15)), ('float64', 25, (13, 14)), ('int32', 15, (14, 15)), ('int64', 14, (13, 14))])
+@pytest.mark.parametrize('dt,n,sizes', [('float32', 26, (14, 15, 16)), ('float64', 25, (13, 14, 15)), ('int32', 16, (14, 15, 16)), ('int64', 15, (13, 14, 15))])
 def test_swap_one_pass_in_place(torch_cuda, dt, n, sizes):
-    """swap_* with 14 / 15 moved low bits (13 / 14 for 8-byte elements): ONE in-place pass through a 64 / 128 KiB LDS tile
-    with the register prefetch of the next tile, many tiles per workgroup (n = 25 / 26) and exactly one tile (n = s)."""
+    """swap_* with 14 / 15 / 16 moved low bits (13 / 14 / 15 for 8-byte elements): ONE in-place pass through a 128 KiB LDS
+    tile -- for the widest one a quarter of each block waits in registers (SPLIT mode) --, many tiles per workgroup
+    (n = 25 / 26) and exactly one block (n = s); random permutations, a reversal and a rotation (no fixed point)."""
     from hybridq_amd import core
     torch = torch_cuda
     rng = np.random.default_rng(n)

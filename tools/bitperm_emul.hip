@@ -80,6 +80,65 @@ static int emulate(const std::vector<unsigned>& perm, bool inplace, int* worst_c
   return 0;
 }
 
+// SPLIT mode (in place, one moved bit more than the tile holds): the kernel's exact order of reads and writes on ONE array
+template <typename E>
+static int emulate_split(const std::vector<unsigned>& perm) {
+  using namespace hq;
+  constexpr unsigned VB = sizeof(E) == 4 ? 2 : 1, VEC = 1u << VB;
+  const unsigned m = (unsigned)perm.size();
+  BitPermPlan P;
+  if (!plan_bitperm<E>(perm.data(), m, true, P)) return -1;
+  if (!P.split) return -2;
+  const BitPermArg& a = P.a;
+  const unsigned BLOCK = P.block, NV = P.nv, UB = (unsigned)P.split - 1;
+  if (BLOCK != 1024 || NV != 8) { printf("split: bad shape\n"); return 1; }
+  const uint64_t size = 1ull << m, nblocks = 1ull << (m - a.nb);
+  std::vector<uint64_t> mem(size), lds(1ull << a.tb);
+  for (uint64_t i = 0; i < size; ++i) mem[i] = i;
+  auto swz = [&](unsigned u) { for (unsigned k = 0; k < a.nsw; ++k) u ^= ((u >> a.sw_hi[k]) & 1u) << a.sw_lo[k]; return u; };
+  auto src_off = [&](unsigned u) { uint64_t y = 0; for (unsigned k = VB; k < a.tb; ++k) y |= (uint64_t)((u >> k) & 1u) << a.spos[k]; return y; };
+  auto dst_off = [&](unsigned t) { uint64_t x = 0; for (unsigned k = VB; k < a.tb; ++k) x |= (uint64_t)((t >> k) & 1u) << a.tpos[k]; return x; };
+  auto sig = [&](unsigned t) { unsigned u = 0; for (unsigned k = 0; k < a.tb; ++k) u |= ((t >> k) & 1u) << a.sigma[k]; return swz(u); };
+  for (uint64_t h = 0; h < nblocks; ++h) {
+    uint64_t xb = h;
+    for (unsigned k = 0; k < a.nb; ++k) { const uint64_t lo = (1ull << a.bpos[k]) - 1; xb = ((xb & ~lo) << 1) | (xb & lo); }
+    uint64_t yb = 0;
+    for (unsigned f = 0; f < a.nfields; ++f) yb |= ((xb >> a.f_from[f]) & ((1ull << a.f_len[f]) - 1)) << a.f_to[f];
+    std::vector<std::vector<uint64_t>> v(BLOCK * NV, std::vector<uint64_t>(VEC)), q(BLOCK * NV, std::vector<uint64_t>(VEC));
+    auto ld = [&](uint64_t base, unsigned tid, unsigned i, std::vector<uint64_t>& out) {
+      const uint64_t y = base | src_off(tid << VB) | src_off((i * BLOCK) << VB);
+      for (unsigned c = 0; c < VEC; ++c) out[c] = mem[y + c];
+    };
+    auto fill = [&]() {
+      for (unsigned tid = 0; tid < BLOCK; ++tid) for (unsigned i = 0; i < NV; ++i) {
+        const unsigned w = swz(tid << VB) ^ swz((i * BLOCK) << VB);
+        for (unsigned c = 0; c < VEC; ++c) lds[w + c] = v[tid * NV + i][c];
+      }
+    };
+    auto store_half = [&](uint64_t xbase) {
+      for (unsigned tid = 0; tid < BLOCK; ++tid) for (unsigned i = 0; i < NV; ++i) {
+        const uint64_t x = xbase | dst_off(tid << VB) | dst_off((i * BLOCK) << VB);
+        for (unsigned c = 0; c < VEC; ++c) mem[x + c] = lds[sig(tid << VB) ^ sig((i * BLOCK) << VB) ^ sig(c)];
+      }
+    };
+    for (unsigned tid = 0; tid < BLOCK; ++tid) for (unsigned i = 0; i < NV; ++i) ld(yb, tid, i, v[tid * NV + i]);
+    for (unsigned tid = 0; tid < BLOCK; ++tid) for (unsigned i = 0; i < NV; ++i) if (!((i >> UB) & 1)) ld(yb | a.half_y, tid, i, q[tid * NV + i]);
+    fill();
+    store_half(xb);
+    for (unsigned tid = 0; tid < BLOCK; ++tid) for (unsigned i = 0; i < NV; ++i) {
+      if (!((i >> UB) & 1)) v[tid * NV + i] = q[tid * NV + i]; else ld(yb | a.half_y, tid, i, v[tid * NV + i]);
+    }
+    fill();
+    store_half(xb | a.half_x);
+  }
+  for (uint64_t x = 0; x < size; ++x) {
+    uint64_t y = 0;
+    for (unsigned i = 0; i < m; ++i) y |= ((x >> i) & 1ull) << perm[i];
+    if (mem[x] != y) { printf("split: wrong element at %llu\n", (unsigned long long)x); return 1; }
+  }
+  return 0;
+}
+
 int main() {
   std::mt19937 rng(7);
   int bad = 0, ran = 0, skipped = 0, worst = 0;
@@ -107,6 +166,22 @@ int main() {
     if (r < 0) ++skipped; else { ++ran; bad += r; }
     if (s <= 14) { r = emulate<uint64_t>(perm, true, nullptr); if (r < 0) ++skipped; else { ++ran; bad += r; } }
   }
+  int split_ran = 0, split_skipped = 0;  // skipped: no suitable half bit among the three highest tile bits -> the two-pass path
+  for (int trial = 0; trial < 8; ++trial) {  // 16 (4-byte) / 15 (8-byte) moved low bits, in place, a few fixed bits above
+    for (int wide = 0; wide < 2; ++wide) {
+      const unsigned s = wide ? 15u : 16u;
+      std::vector<unsigned> perm(s + 1 + trial % 2);
+      for (unsigned i = 0; i < perm.size(); ++i) perm[i] = i;
+      if (trial == 0) std::rotate(perm.begin(), perm.begin() + 3, perm.begin() + s);
+      else if (trial == 1) std::reverse(perm.begin(), perm.begin() + s);
+      else {  // random derangement-ish: shuffle until no fixed point
+        do { std::shuffle(perm.begin(), perm.begin() + s, rng); } while ([&] { for (unsigned i = 0; i < s; ++i) if (perm[i] == i) return true; return false; }());
+      }
+      const int r = wide ? emulate_split<uint64_t>(perm) : emulate_split<uint32_t>(perm);
+      if (r == -1 || r == -2) ++split_skipped; else { ++ran; ++split_ran; bad += r; }
+    }
+  }
+  printf("split mode: %d cases ran, %d left to the two-pass path\n", split_ran, split_skipped);
   printf("bitperm emulation: %d cases ran, %d skipped by the planner, %d failed; worst half-wave bank multiplicity %d\n", ran, skipped, bad, worst);
   return bad != 0;
 }
