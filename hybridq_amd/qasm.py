@@ -87,12 +87,32 @@ def _parse_extensions(lines):
             if val is None:
                 raise ValueError(f'extension {key!r}: malformed JSON value')
         else:
-            val = json.loads(val)
+            try:
+                val = json.loads(val)
+            except json.JSONDecodeError as e:
+                raise ValueError(f'line {i}: extension {key!r}: malformed JSON value ({e.msg})') from None
         if key == 'qubits':
-            qmap = {int(k): (int(v) if str(v).lstrip('-').isdigit() else v) for k, v in val.items()}
+            qmap = {int(k): _label_from_text(v) for k, v in val.items()}
         else:
             pending[key] = val
     return records, qmap
+
+
+def _label_from_text(v):
+    """Qubit label as the writer spelled it: digit strings are ints, '(…)' spellings of tuples (the density-matrix
+    front-end labels qubits (side, q)) are read back with ast.literal_eval, everything else stays a string."""
+    v = str(v)
+    if v.lstrip('-').isdigit():
+        return int(v)
+    if v.startswith('(') and v.endswith(')'):
+        import ast
+        try:
+            lab = ast.literal_eval(v)
+            if isinstance(lab, tuple):
+                return lab
+        except (ValueError, SyntaxError):
+            pass
+    return v
 
 
 def from_qasm(text):
@@ -162,6 +182,14 @@ def to_qasm(gates, qubits_map=None):
     import json
     gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
     labels = sorted({q for _, qs in gates for q in qs}, key=lambda q: (type(q).__name__, q))
+    # the text form of a label must identify it: '3' and 3 would both come back as the int 3, and a string spelled like a
+    # tuple would come back as one
+    spelled = {}
+    for q in labels:
+        if isinstance(q, str) and _label_from_text(q) != q:
+            raise ValueError(f'qubit label {q!r} would not survive the round trip (it reads back as {_label_from_text(q)!r})')
+        if spelled.setdefault(str(q), q) != q:
+            raise ValueError(f'qubit labels {spelled[str(q)]!r} and {q!r} have the same spelling')
     if qubits_map is None:
         qubits_map = {q: i for i, q in enumerate(labels)}
     lines = [str(len(labels)), '#@ qubits = ']

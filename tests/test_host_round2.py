@@ -200,3 +200,17 @@ def test_to_qasm_round_trip():
         assert tuple(qs) == tuple(ps) and np.array_equal(np.asarray(U, dtype=np.complex128), V)
     with pytest.raises(ValueError):
         to_qasm([(np.eye(2), (0, 1))])
+
+
+def test_qasm_labels_round_trip_or_are_rejected():
+    """labels that cannot survive the text form are refused by the writer ('3' next to 3, a string spelled
+    like a tuple), tuple labels (the dm front-end's (side, q)) come back as tuples, malformed inline JSON names its line."""
+    from hybridq_amd.qasm import from_qasm, to_qasm
+    I = np.eye(2)
+    back = from_qasm(to_qasm([(I, ((0, 1),)), (I, ((1, 1),)), (I, ('anc',)), (I, (7,))]))
+    assert [qs for _, qs in back] == [((0, 1),), ((1, 1),), ('anc',), (7,)]
+    for bad in ([(I, ('3',)), (I, (3,))], [(I, ('(0, 1)',))]):
+        with pytest.raises(ValueError):
+            to_qasm(bad)
+    with pytest.raises(ValueError, match='line 2'):
+        from_qasm('1\n#@ power = {bad\nx 0\n')
