@@ -918,7 +918,21 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
     if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
     const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes;
-    if (pref) {
+    // experiment (HQ_BLOCKED_GPRE=1): the operand / lane-table reads of the NEXT inner gate issued in front of the barrier that
+    // ends the current one.  Measured on the n = 30 benchmark circuit: 138.6 ms with it, 136.8 without -- the per-gate
+    // prologue is not what holds the matrix pipe at 73 % -- so it stays off.
+    static int use_gpre = getenv("HQ_BLOCKED_GPRE") ? atoi(getenv("HQ_BLOCKED_GPRE")) : 0;
+    if (pref && use_gpre && sizeof(T) == 4) {  // complex128 has no registers left for it
+      static bool attr2 = false;
+      if (!attr2) {
+        if constexpr (sizeof(T) == 4)
+          HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<T, 512, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr2 = true;
+      }
+      if constexpr (sizeof(T) == 4)
+        HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
+                  n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+    } else if (pref) {
       HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
                 n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
     } else {

@@ -809,9 +809,19 @@ __device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ t
   }
 }
 
-template <typename T, int KBITS, int VMASK, int BLOCK>
+// The prologue of the NEXT gate (4 operand values and the lane entry of a k <= 3 gate: the reads whose address hangs on the
+// gate descriptor's scalar load) requested while the current gate runs; the 4 register-digit entries are read at the
+// gate's start (holding them too spills: 128 registers is the budget of four waves per SIMD).  Unconditional, whatever the next
+// gate's kind (wider gates load the rest themselves): a conditional request would merge old and new register values.
+template <typename T> struct BlockedPre {
+  T a[4];
+  unsigned L;
+};
+
+template <typename T, int KBITS, int VMASK, int BLOCK, bool USEPRE = false>
 __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
-                                                       const BlockedTabT* __restrict__ tab, const unsigned niter
+                                                       const BlockedTabT* __restrict__ tab, const unsigned niter,
+                                                       const BlockedPre<T>& pre
 #ifdef HQ_EXP_TIMELINE
                                                        , const bool hq_tl_flag = false
 #endif
@@ -831,14 +841,24 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
 #endif
   HQ_STAMP(1);
   T a[NRB][NSTEP];
-#pragma unroll
-  for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
-  const unsigned L = tab[kBlockedTabLane + lane];
+  unsigned L;
   unsigned OFF[NL];
+  if constexpr (USEPRE && KBITS == 4) {  // requested one gate ahead (apply_blocked_kernel): nothing to wait for here
+    static_assert(NRB == 1 && NSTEP == 4 && NL <= 4, "k <= 3 shape");
 #pragma unroll
-  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
+    for (int s = 0; s < NSTEP; ++s) a[0][s] = pre.a[s];
+    L = pre.L;
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
+  } else {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
+    L = tab[kBlockedTabLane + lane];
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
+  }
   typedef __attribute__((address_space(3))) V LdsV;  // addresses are absolute LDS byte addresses (base folded in LANE)
   HQ_STAMP(2);
   for (unsigned it = wave; it < niter; it += 1u << WB) {
@@ -1002,7 +1022,7 @@ __device__ __forceinline__ void blocked_inner_gate_valu(T* __restrict__ xr, T* _
 // before the gates of the current tile start and dropped into LDS after its stores were issued.  Needs the
 // no-scratch register budget: a scratch reload is a vector-memory load and would queue (vmcnt is in order) behind
 // the prefetch it was supposed to overlap.
-template <typename T, int BLOCK, bool ALDS, bool PREF>
+template <typename T, int BLOCK, bool ALDS, bool PREF, bool GPRE = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* __restrict__ gates,
                      const unsigned ngates, const T* __restrict__ Atab, const unsigned a_elems,
@@ -1118,9 +1138,20 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     }
     __syncthreads();
     HQ_TSTAMP(2);
+    BlockedPre<T> pre_next;
+    auto request = [&](unsigned gn) {  // prologue of gate gn (clamped by the caller): LDS reads only, waited for when used
+      const T* An = als + gates[gn].a_off;
+      const BlockedTabT* tn = tabs + gn * kBlockedTabWords;
+      const unsigned lane = tid & 63;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) pre_next.a[s2] = An[s2 * 64 + lane];
+      pre_next.L = tn[kBlockedTabLane + lane];
+    };
+    if constexpr (GPRE && ALDS) request(0);
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedGate& G = gates[gi];
       const T* A = ALDS ? als + G.a_off : Atab + G.a_off;
+      const BlockedPre<T>& pre = pre_next;  // consumed in the gate's first instructions; re-requested after its last
 #ifdef HQ_EXP_TIMELINE
       const bool hq_tl_flag = blockIdx.x == 7 && tile == blockIdx.x + 3 * stride && gi == 3;
       const bool hq_tl_rec = hq_tl_flag && (threadIdx.x & 63) == 0;
@@ -1136,7 +1167,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 #define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
   do {                                                                                                  \
     if constexpr (ALDS)                                                                                 \
-      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * kBlockedTabWords, (1u << (tvb - G.n_addr)) >> 4 HQ_TL_ARG); \
+      blocked_inner_gate_tab<T, KB, VM, BLOCK, GPRE>(A, tabs + gi * kBlockedTabWords, (1u << (tvb - G.n_addr)) >> 4, pre HQ_TL_ARG); \
     else                                                                                                \
       blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
   } while (0)
@@ -1167,6 +1198,9 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 #ifdef HQ_EXP_TIMELINE
       HQ_STAMP(11);
 #endif
+      // the next gate's prologue reads are issued in front of the barrier and land while the workgroup gathers at it
+      // (requested at the gate's START they cost 5 more live registers through the MFMA phase: spills)
+      if constexpr (GPRE && ALDS) request(gi + 1 < ngates ? gi + 1 : gi);
       __syncthreads();
 #ifdef HQ_EXP_TIMELINE
       HQ_STAMP(12);
