@@ -7,6 +7,9 @@
 // Pins a wave-uniform value to scalar registers (stops the optimiser from hoisting per-lane copies of it out of a loop).
 // Under AddressSanitizer (-DHQ_ASAN: tools/asan_smoke.sh) the instrumented code computes it per lane and the constraint
 // cannot be met: the pin is dropped there, it only matters for speed.
+#ifndef HQ_BIG_F64_PIPE
+#define HQ_BIG_F64_PIPE 0  // 1: keep the operand double buffer in the complex128 k = 6 kernel (218 registers, spills)
+#endif
 #ifdef HQ_ASAN
 #define HQ_PIN_SGPR(x) ((void)0)
 #else
@@ -349,6 +352,7 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
   // available after 40: back-to-back MFMAs on ONE accumulator lose a fifth of the pipe).  The
   // pipeline runs across column blocks (the operand sequence repeats): only the first read of an
   // iteration is exposed.  Alone this phase runs at 149 of 157 TFLOP/s (k = 6 knock-out).
+  constexpr bool kOperandPipe = !(sizeof(T) == 8 && NL == 32) || HQ_BIG_F64_PIPE;
   auto compute = [&](V (&x)[NL]) {
     V a0 = Al[0], a1 = Al[NG * 64];
 #pragma unroll
@@ -361,9 +365,16 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
         const int sg = g / NP, rb = 2 * (g % NP);
         const int gn = (g + 1) % NGRP, sgn = gn / NP, rbn = 2 * (gn % NP);
         V n0 = a0, n1 = a1;
-        if (g + 1 < NGRP || cf + 1 < NCB) {
-          n0 = Al[(rbn * NG + sgn) * 64];
-          n1 = Al[((rbn + 1) * NG + sgn) * 64];
+        if constexpr (kOperandPipe) {
+          if (g + 1 < NGRP || cf + 1 < NCB) {
+            n0 = Al[(rbn * NG + sgn) * 64];
+            n1 = Al[((rbn + 1) * NG + sgn) * 64];
+          }
+        } else {  // complex128 k = 6 without a component target: no registers for a second operand pair
+          a0 = Al[(rb * NG + sg) * 64];
+          a1 = Al[((rb + 1) * NG + sg) * 64];
+          n0 = a0;
+          n1 = a1;
         }
         __builtin_amdgcn_sched_barrier(0);  // the reads of the NEXT pair-group stay in front of ...
 #pragma unroll

@@ -12,11 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 #: kernels allowed to spill, with the measured consequence
 ALLOWED_SCRATCH = {
-    # complex128 k = 6 with no target on index bit 0: 32 loaded vectors (128 registers) + 8 f64 accumulator
-    # blocks (64) + operand prefetch (16) + addressing = 218 of the 256 registers two waves per SIMD allow; the
-    # allocator does not pack the 4- and 8-register tuples that tightly and spills ~21 dwords.  Measured 4.8 ms
-    # at n = 29 = 57 TFLOP/s = 73 % of the f64 matrix-core peak (profiles/r02_sweep_k56.txt).
-    r'apply_mfma_big_kernel<double, 7, 0, (true|false), 512, (true|false)>': 128,
+    # complex128 k = 6 with no target on index bit 0: 32 loaded vectors (128 registers) + 8 f64 accumulator blocks (64)
+    # + one operand pair (8) + addressing = 210 of the 256 registers two waves per SIMD allow; the allocator does not
+    # pack the 4- and 8-register tuples that tightly and spills 13 dwords (round 3: the operand double buffer of this
+    # instantiation was dropped, 116 -> 52 B/lane and 4.88 -> 4.69 ms at n = 29 = 59 TFLOP/s = 75 % of the f64 peak).
+    r'apply_mfma_big_kernel<double, 7, 0, (true|false), 512, (true|false)>': 64,
 }
 
 
