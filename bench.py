@@ -494,7 +494,7 @@ def main():
             'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic,
             'traffic_source': (None if traffic is None else
-                               'stored PMC measurement (profiles/traffic.json <- profiles/r02_pmc_hbm_traffic.csv: '
+                               'stored PMC measurement (profiles/traffic.json <- profiles/r02_pmc_hbm_traffic.csv, r03_pmc_hbm_traffic.csv: '
                                '2 x FETCH_SIZE + WRITE_SIZE of this kernel at this n, separate rocprofv3 --pmc passes), '
                                'not a counter of this run'),
             'algorithmic_bytes_per_launch': bytes_per_gate,

@@ -23,5 +23,30 @@ for pos in ([12], [3], [0], [12, 20], [2, 3], [0, 15], [10, 15, 20], [10, 14, 18
             [0, 4, 8, 11, 13, 19, 22, 27], [1, 3, 6, 10, 12, 16, 20, 24, 28]):
     core.apply_U(planes[0], planes[1], haar_unitary(1 << len(pos), rng), pos)
     print(pos, core.last_kernel_desc())
+# round 3: Auto sends k <= 3 gates with every target at bit >= 8 to the VALU kernel; the role kernel on the same positions
+core.set_apply_mode('mfma')
+for pos in ([12], [12, 20], [10, 15, 20]):
+    core.apply_U(planes[0], planes[1], haar_unitary(1 << len(pos), rng), pos)
+    print(pos, core.last_kernel_desc())
+core.set_apply_mode('auto')
+# round 3: index-bit permutations through bitperm_tile_kernel (algorithmic bytes: one plane read + written = 8 * 2^n B for
+# permute_bits / swap, both planes = 16 * 2^n B for the exchange pack)
+tmp = torch.empty(1 << n, dtype=torch.float32, device='cuda')
+rng2 = np.random.default_rng(1)
+for name, perm in (('random above bit 4', np.concatenate([np.arange(4), 4 + rng2.permutation(n - 4)])), ('random every bit', rng2.permutation(n)),
+                   ('bit reversal', np.arange(n)[::-1].copy())):
+    core.permute_bits(planes[0], tmp, perm, n)
+    print('permute_bits', name)
+for s in (8, 13, 15, 16):
+    pos = np.roll(np.arange(s), 3)
+    core.swap(planes[0], pos, n)
+    print('swap in place s =', s)
+del tmp
+core.shard_free()
+half = planes[:, :1 << (n - 1)]
+dst = torch.empty((2, 1 << (n - 1)), dtype=torch.float32, device='cuda')
+ev = [4, 12, 21]
+core.exchange(half[0], half[1], dst[0], dst[1], np.array([b for b in range(n - 1) if b not in ev] + ev), n - 1)
+print('exchange pack, both planes of an n-1 qubit shard')
 core.sync()
 print('norm2', core.norm2(planes[0], planes[1]))

@@ -47,7 +47,7 @@ else:
         w.writerow(['kernel', 'dispatch', 'FETCH_SIZE_KiB_raw', 'fetch_bytes_corrected', 'WRITE_SIZE_KiB', 'write_bytes',
                     'hbm_bytes_per_launch', 'ratio_to_algorithmic'])
         for k, d in fetch.items():
-            if 'apply_' not in d['kernel'] or k not in write:
+            if not any(t in d['kernel'] for t in ('apply_', 'bitperm_', 'swap_', 'exchange_pack', 'permute_bits')) or k not in write:
                 continue
             fb = d.get('FETCH_SIZE', 0.0) * 2 * 1024
             wb = write[k].get('WRITE_SIZE', 0.0) * 1024
