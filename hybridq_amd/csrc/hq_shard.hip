@@ -388,8 +388,14 @@ int hq_shard_free(void) {
   hq::Context& c = hq::ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   hq::Shard& sh = hq::shard();
-  if (sh.comm_stream) (void)hipStreamSynchronize(sh.comm_stream);
-  if (sh.comm && sh.own_comm && sh.api.CommDestroy) (void)sh.api.CommDestroy(sh.comm);
+  // a transfer that never completed (the reason the caller gives the transport up) must not hang the cleanup too: the
+  // communication stream is only waited for, and the communicator only destroyed, when nothing is pending on it
+  bool idle = true;
+  if (sh.comm_stream) {
+    idle = hipStreamQuery(sh.comm_stream) == hipSuccess;
+    if (!idle) (void)hipGetLastError();
+  }
+  if (idle && sh.comm && sh.own_comm && sh.api.CommDestroy) (void)sh.api.CommDestroy(sh.comm);
   sh.comm = nullptr;
   sh.own_comm = false;
   sh.registry.clear();
