@@ -33,4 +33,46 @@ for t in range(200):
     exp=oracle.swap_numpy(a,pos)
     tt=torch.from_numpy(a.copy()).cuda(); core.swap(tt,pos,n); core.sync()
     if not (tt.cpu().numpy()==exp).all(): bad+=1; print('swap FAIL',dt.__name__,s,n,list(pos))
+# round 3: arbitrary bit permutations (out of place), the exchange pack (one rank, both planes), in-place swaps through the tile
+# kernel incl. SPLIT mode, against index arithmetic on the device
+def src_index(idx, perm):
+    y=torch.zeros_like(idx)
+    for i,p in enumerate(perm): y|=((idx>>i)&1)<<int(p)
+    return y
+core.shard_free()
+for t in range(int(os.environ.get('PERM_TRIALS','150'))):
+    dt=[torch.float32,torch.float64,torch.int32,torch.int64][t%4]; n=int(rng.integers(10,26))
+    kind=t%5
+    perm=np.arange(n)
+    if kind==0: perm=rng.permutation(n)
+    elif kind==1: lo=int(rng.integers(0,6)); perm[lo:]=lo+rng.permutation(n-lo)
+    elif kind==2: perm=perm[::-1].copy()
+    elif kind==3:
+        ev=sorted(rng.permutation(n)[:int(rng.integers(1,4))]); perm=np.array([b for b in range(n) if b not in ev]+list(ev))
+    else: perm=np.roll(perm,int(rng.integers(1,n)))
+    idx=torch.arange(1<<n,device='cuda',dtype=torch.int64)
+    data=(idx%1000003).to(dt); dst=torch.empty_like(data)
+    core.permute_bits(data,dst,perm,n); core.sync()
+    if not torch.equal(dst,data[src_index(idx,perm)]): bad+=1; print('permute_bits FAIL',dt,n,list(perm))
+    if n>=12 and dt in (torch.float32,torch.float64):
+        two=torch.stack([data[:1<<(n-1)],-data[:1<<(n-1)]]).contiguous(); out=torch.zeros_like(two)
+        p2=rng.permutation(n-1); core.exchange(two[0],two[1],out[0],out[1],p2,n-1); core.sync()
+        y=src_index(idx[:1<<(n-1)],p2)
+        if not (torch.equal(out[0],two[0][y]) and torch.equal(out[1],two[1][y])): bad+=1; print('exchange pack FAIL',dt,n,list(p2))
+    s=int(rng.integers(8,min(n,17)+1)); pos=rng.permutation(s) if t%2 else np.roll(np.arange(s),1+t%3)
+    full=np.concatenate([pos,np.arange(s,n)]); exp=data[src_index(idx,full)]
+    core.swap(data,pos,n); core.sync()
+    if not torch.equal(data,exp): bad+=1; print('swap(tile) FAIL',dt,n,s,list(pos))
+    del idx,data,dst,exp
+# round 3: the state allocator (search, pool, trim) in a loop: every state must work and come back intact
+for t in range(int(os.environ.get('ALLOC_TRIALS','6'))):
+    n=26+t%2
+    os.environ['HQ_STATE_TRIES']=str(1+t%3)
+    st=core.StatePlanes(n,np.float32,flags=(core.STATE_NO_POOL if t%3==2 else 0))
+    pl=torch.as_tensor(st,device='cuda')[:,:1<<n]
+    core.init_state(pl[0],pl[1],'plus'); U=haar_unitary(4,rng)
+    core.apply_U(pl[0],pl[1],U,[3,n-1],n); nrm=core.norm2(pl[0],pl[1])
+    if abs(nrm-1)>1e-4: bad+=1; print('alloc_state FAIL',n,st.info,nrm)
+    del pl; st.free()
+    if t%2: core.state_pool_trim()
 print('soak seed',seed,'failures',bad)
