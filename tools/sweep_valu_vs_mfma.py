@@ -12,9 +12,10 @@ from hybridq_amd import core  # noqa: E402
 from hybridq_amd.circuits import haar_unitary  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+DT = torch.float64 if len(sys.argv) > 2 and sys.argv[2] == 'complex128' else torch.float32
 core.set_stream(torch.cuda.current_stream().cuda_stream)
 from hybridq_amd.simulation import alloc_planes  # noqa: E402
-planes = alloc_planes(n, torch.float32, torch.device('cuda'))
+planes = alloc_planes(n, DT, torch.device('cuda'))
 core.init_state(planes[0], planes[1], 'plus')
 rng = np.random.default_rng(0)
 for p in range(0, n, 2):
