@@ -237,3 +237,27 @@ def test_to_numpy_never_holds_the_complex_state_in_hbm(torch_cuda):
     assert extra <= 4 * (128 << 20) + (16 << 20), extra
     ref = st.to_complex().cpu().numpy()
     assert psi.dtype == np.complex64 and np.array_equal(psi, ref)
+
+
+@pytest.mark.parametrize('ct', ['complex64', 'complex128'])
+def test_reference_driver_protocol_over_the_host_pointer_path(torch_cuda, ct):
+    """INTEGRATION path A as far as it can run on a GPU box (the reference Python cannot travel): libhq_hip.so loaded
+    under the reference's OWN symbol names and argtypes (oracle.binding.OracleLib is the reference's ctypes table), host
+    numpy planes, and the reference driver protocol -- swap the lowest 8 bits whenever a target sits below
+    log2_pack_size = 3, apply_U, final restore, to_complex (simulation.py:491-675) -- restated in oracle/evolution.py.
+    Every call is staged H2D -> kernel -> D2H by the library; the result must equal the same protocol on the CPU core."""
+    import oracle
+    from oracle.binding import OracleLib
+    from hybridq_amd import core
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    n = 14
+    gates = rqc_1q2q(n, depth=6, seed=4) + random_dense(n, 20, kmax=5, seed=5, unitary=True)
+    cpu = oracle.load_ref() if oracle.have_ref() else oracle.load_port()
+    hip = OracleLib(core._LIB_PATH, kind='hip, host pointers')
+    assert hip.log2_pack_size >= 1  # truthy, else the reference falls back to einsum (simulation.py:393-397)
+    trace_cpu, trace_hip = [], []
+    exp, _ = oracle.evolve_reference_protocol(cpu, gates, n, complex_type=ct, log2_pack_size=3, trace=trace_cpu)
+    got, info = oracle.evolve_reference_protocol(hip, gates, n, complex_type=ct, log2_pack_size=3, trace=trace_hip)
+    assert trace_hip == trace_cpu and any(t[0] == 'S' for t in trace_hip)  # the same C-ABI call sequence, swaps included
+    err = np.abs(got - exp).max() / np.abs(exp).max()
+    assert err <= (1e-6 if ct == 'complex64' else 1e-12), err
