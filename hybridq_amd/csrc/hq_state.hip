@@ -247,21 +247,34 @@ static int vmm_remap(const Context& c, Vmm& v, const std::vector<size_t>& order,
   nv.granule = v.granule;
   nv.size = v.size;
   HQ_HIP_CHECK(hipMemAddressReserve(&nv.va, nv.size, (size_t)1 << 21, nullptr, 0));
-  HQ_HIP_CHECK(hipMemUnmap(v.va, v.size));
-  v.mapped = 0;
-  nv.handles = v.handles;
-  v.handles.clear();
-  for (size_t i = 0; i < nv.handles.size(); ++i) {
-    HQ_HIP_CHECK(hipMemMap(reinterpret_cast<unsigned char*>(nv.va) + order[i] * nv.granule, nv.granule, 0, nv.handles[i], 0));
-    nv.mapped = i + 1;
-    nv.touched = true;
+  hipError_t e = hipMemUnmap(v.va, v.size);
+  if (e != hipSuccess) {
+    (void)hipMemAddressFree(nv.va, nv.size);
+    return fail(std::string("hipMemUnmap: ") + hipGetErrorString(e));
   }
-  hipMemAccessDesc acc;
-  memset(&acc, 0, sizeof(acc));
-  acc.location.type = hipMemLocationTypeDevice;
-  acc.location.id = c.device;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  HQ_HIP_CHECK(hipMemSetAccess(nv.va, nv.size, &acc, 1));
+  v.mapped = 0;
+  nv.handles.swap(v.handles);  // from here on nv owns the physical granules: every failure below releases them
+  const char* what = "hipMemMap";
+  for (size_t i = 0; i < nv.handles.size() && e == hipSuccess; ++i) {
+    e = hipMemMap(reinterpret_cast<unsigned char*>(nv.va) + order[i] * nv.granule, nv.granule, 0, nv.handles[i], 0);
+    if (e == hipSuccess) { nv.mapped = i + 1; nv.touched = true; }
+  }
+  if (e == hipSuccess) {
+    what = "hipMemSetAccess";
+    hipMemAccessDesc acc;
+    memset(&acc, 0, sizeof(acc));
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = c.device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(nv.va, nv.size, &acc, 1);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    for (size_t i = 0; i < nv.mapped; ++i) (void)hipMemUnmap(reinterpret_cast<unsigned char*>(nv.va) + order[i] * nv.granule, nv.granule);
+    nv.mapped = 0;
+    vmm_destroy(nv);
+    return fail(std::string(what) + ": " + hipGetErrorString(e));
+  }
   out = nv;
   return 0;
 }
@@ -482,7 +495,7 @@ static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void**
       } else {  // back to the shuffled mapping (again a fresh range: the old one is retired)
         std::vector<size_t> order = st.vmm_order_used;
         Vmm back;
-        if (vmm_remap(c, alt, order, back) != 0) return 1;
+        if (vmm_remap(c, alt, order, back) != 0) return 1;  // (the granules were released by vmm_remap; nothing else is held here)
         st.vmm = back;
         st.re = back.va;
         st.im = reinterpret_cast<unsigned char*>(back.va) + stride * itemsize;
