@@ -480,7 +480,11 @@ static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void**
     std::vector<size_t> ident(st.vmm.handles.size());
     for (size_t i = 0; i < ident.size(); ++i) ident[i] = i;
     double ms_alt = 0;
-    if (vmm_remap(c, st.vmm, ident, alt) == 0) {
+    if (vmm_remap(c, st.vmm, ident, alt) != 0) {  // the winner's mapping may be gone: give everything back and report
+      vmm_destroy(st.vmm);
+      return 1;
+    }
+    {
       void* are = alt.va;
       void* aim = reinterpret_cast<unsigned char*>(alt.va) + stride * itemsize;
       const int prc = float_bits == 32 ? state_probe<float>(c, (float*)are, (float*)aim, n, &ms_alt)
@@ -495,7 +499,10 @@ static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void**
       } else {  // back to the shuffled mapping (again a fresh range: the old one is retired)
         std::vector<size_t> order = st.vmm_order_used;
         Vmm back;
-        if (vmm_remap(c, alt, order, back) != 0) return 1;  // (the granules were released by vmm_remap; nothing else is held here)
+        if (vmm_remap(c, alt, order, back) != 0) {
+          vmm_destroy(alt);
+          return 1;
+        }
         st.vmm = back;
         st.re = back.va;
         st.im = reinterpret_cast<unsigned char*>(back.va) + stride * itemsize;
