@@ -7,6 +7,9 @@
 // Pins a wave-uniform value to scalar registers (stops the optimiser from hoisting per-lane copies of it out of a loop).
 // Under AddressSanitizer (-DHQ_ASAN: tools/asan_smoke.sh) the instrumented code computes it per lane and the constraint
 // cannot be met: the pin is dropped there, it only matters for speed.
+#ifndef HQ_BLOCKED_MERGE2
+#define HQ_BLOCKED_MERGE2 0  // experiment: both wave-iterations of a k <= 3 inner gate as one body (139.0 vs 137.0 ms: off)
+#endif
 #ifndef HQ_BIG_F64_PIPE
 #define HQ_BIG_F64_PIPE 0  // 1: keep the operand double buffer in the complex128 k = 6 kernel (218 registers, spills)
 #endif
@@ -872,6 +875,57 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
   }
   typedef __attribute__((address_space(3))) V LdsV;  // addresses are absolute LDS byte addresses (base folded in LANE)
   HQ_STAMP(2);
+#if HQ_BLOCKED_MERGE2
+  // The usual case of a k <= 3 gate on a 2^13 tile: exactly TWO wave-iterations per wave.  Both as ONE body -- 2 NL reads,
+  // 32 MFMAs alternating between the two iterations' accumulators, 2 NL writes -- instead of read / 16 MFMAs / write twice:
+  // one drain of the matrix pipe per gate and wave instead of two (tools/lds_mfma_overlap.hip: 2601 -> 2429 cycles per
+  // 16 wave-iterations with the per-gate barrier).
+  if constexpr (KBITS == 4 && NRB == 1) {
+    if (niter == (2u << WB)) {
+      const unsigned Lt0 = L ^ tab[kBlockedTabIter + wave], Lt1 = L ^ tab[kBlockedTabIter + wave + (1u << WB)];
+      unsigned ad0[NL], ad1[NL];
+      V x0[NL], x1[NL];
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld) {
+        ad0[ld] = Lt0 ^ OFF[ld];
+        x0[ld] = *reinterpret_cast<LdsV*>((uintptr_t)ad0[ld]);
+      }
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld) {
+        ad1[ld] = Lt1 ^ OFF[ld];
+        x1[ld] = *reinterpret_cast<LdsV*>((uintptr_t)ad1[ld]);
+      }
+      Acc c0[NCB], c1[NCB];
+#pragma unroll
+      for (int cf = 0; cf < NCB; ++cf) { c0[cf] = Acc{0, 0, 0, 0}; c1[cf] = Acc{0, 0, 0, 0}; }
+#pragma unroll
+      for (int s2 = 0; s2 < NSTEP; ++s2) {
+        const int ck = s2 & ((1 << KV) - 1), ld = s2 >> KV;
+#pragma unroll
+        for (int cf = 0; cf < NCB; ++cf) {
+          const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+          c0[cf] = Mfma<T>::run(a[0][s2], x0[ld][comp], c0[cf]);
+          c1[cf] = Mfma<T>::run(a[0][s2], x1[ld][comp], c1[cf]);
+        }
+      }
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld) {
+        V y0, y1;
+#pragma unroll
+        for (int comp = 0; comp < NCOMP; ++comp) {
+          const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
+          const int so = ck | (ld << KV);
+          y0[comp] = c0[cf][so & 3];
+          y1[comp] = c1[cf][so & 3];
+        }
+        *reinterpret_cast<LdsV*>((uintptr_t)ad0[ld]) = y0;
+        *reinterpret_cast<LdsV*>((uintptr_t)ad1[ld]) = y1;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      return;
+    }
+  }
+#endif
   for (unsigned it = wave; it < niter; it += 1u << WB) {
     const unsigned Lt = L ^ tab[kBlockedTabIter + it];
     unsigned addr[NL];

@@ -35,6 +35,30 @@ __global__ void __launch_bounds__(512) k(float* out, int iters, int mode, float 
       if ((flags & 1) && (it & 1)) __syncthreads();
     }
     acc[0][0] += big[0][0] + big[1][0];
+  } else if ((mode & 4) && (flags & 32)) {
+    // MERGED: the two iterations of a "gate" as one body -- 8 reads, 32 MFMAs on 8 accumulators, 8 writes -- and the barrier
+    f32x4 acc2[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    f32x4 y[4];
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = tile[slot + ((r * 64 + it * 256) & 1023 & ~63u)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = tile[slot + ((r * 64 + (it + 1) * 256) & 1023 & ~63u)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[s][c], acc[c], 0, 0, 0);
+          acc2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, y[s][c], acc2[c], 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[slot + ((r * 64 + it * 256) & 1023 & ~63u)] = acc[r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[slot + ((r * 64 + (it + 1) * 256) & 1023 & ~63u)] = acc2[r];
+      if (flags & 1) __syncthreads();
+    }
+    acc[0][0] += acc2[0][0];
   } else if (mode & 4) {
     // flags bit 0: workgroup barrier every 2 iterations ("per gate"); bit 1: ~25 dependent VALU ops of address
     // arithmetic per iteration; bit 2: a "gate prologue" every 2 iterations (8 ds_read_b32 + ~50 dependent VALU ops)
@@ -114,7 +138,8 @@ int main() {
                         {4, 4, " + prologue / 2 it"}, {4, 3, " + barrier + VALU"}, {4, 5, " + barrier + prologue"},
                         {4, 7, " + barrier + VALU + prologue"}, {4, 8, " + 2 dependent s_loads / 2 it"},
                         {4, 9, " + barrier + s_loads"}, {4, 15, " + barrier + VALU + prologue + s_loads"},
-                        {4, 16, "32x32x2: read, MFMA, write"}, {4, 17, "32x32x2 + barrier / 2 it"}};
+                        {4, 16, "32x32x2: read, MFMA, write"}, {4, 17, "32x32x2 + barrier / 2 it"},
+                        {4, 32, "merged pair: 8 rd, 32 MFMA, 8 wr"}, {4, 33, "merged pair + barrier / pair"}};
   unsigned* desc;
   hipMalloc(&desc, 64 * 4);
   hipMemset(desc, 0, 64 * 4);
