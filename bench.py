@@ -716,6 +716,7 @@ def main():
                      core.permute_bits(re_, tmp_, p, n), 2 * P)
             del tmp_
             time_aux('norm2', lambda: core.norm2(re_, im_), 2 * P)
+            time_aux('vdot_with_itself', lambda: core.vdot(re_, im_, re_, im_), 2 * P)
             time_aux('probabilities_k3', lambda: core.probabilities(re_, im_, [3, n // 2, n - 2], n), 2 * P)
             time_aux('init_state', lambda: core.init_state(re_, im_, 'plus'), 2 * P)
             result['aux'] = aux

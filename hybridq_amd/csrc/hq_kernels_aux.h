@@ -249,10 +249,27 @@ vdot_kernel(const T* __restrict__ are, const T* __restrict__ aim, const T* __res
   __shared__ double part[2][kBlock / 64];
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   double sr = 0, si = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
-    const double ar = are[i], ai = aim[i], br = bre[i], bi = bim[i];
-    sr += ar * br + ai * bi;
-    si += ar * bi - ai * br;
+  using V = typename Vec<T>::type;
+  constexpr int VE = 1 << Vec<T>::VB;
+  const bool al = size % VE == 0 && reinterpret_cast<uintptr_t>(are) % 16 == 0 && reinterpret_cast<uintptr_t>(aim) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(bre) % 16 == 0 && reinterpret_cast<uintptr_t>(bim) % 16 == 0;
+  if (al) {  // 16-byte non-temporal loads of the four planes (as norm2_kernel)
+    const uint64_t nvec = size / VE;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+      const V ar = __builtin_nontemporal_load(reinterpret_cast<const V*>(are) + i), ai = __builtin_nontemporal_load(reinterpret_cast<const V*>(aim) + i);
+      const V br = __builtin_nontemporal_load(reinterpret_cast<const V*>(bre) + i), bi = __builtin_nontemporal_load(reinterpret_cast<const V*>(bim) + i);
+#pragma unroll
+      for (int c = 0; c < VE; ++c) {
+        sr += (double)ar[c] * (double)br[c] + (double)ai[c] * (double)bi[c];
+        si += (double)ar[c] * (double)bi[c] - (double)ai[c] * (double)br[c];
+      }
+    }
+  } else {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
+      const double ar = are[i], ai = aim[i], br = bre[i], bi = bim[i];
+      sr += ar * br + ai * bi;
+      si += ar * bi - ai * br;
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     sr += __shfl_down(sr, o, 64);
