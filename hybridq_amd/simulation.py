@@ -501,6 +501,9 @@ BLOCKED_OVERLAP_MS = 1.3  # ... what of the stream does NOT hide behind the gate
 #                            fitted on the benchmark circuit's tiles; complex128 at n - 1 measures 15 % above the model)
 BLOCKED_INNER_MS = {1: 0.38, 2: 0.63, 3: 0.63, 4: 1.20}
 TUNED_PLACEMENT_SEARCH_MS = 2500.0  # what alloc_planes' draw-and-probe search costs (n = 30; measured 2.5 s)
+#: host time of planning one candidate schedule, per matrix gate of the circuit (measured on the benchmark circuits,
+#: n = 16..30: fusion to 4 ~0.04 ms / gate, to 5 ~0.07, the blocked planner ~0.13)
+PLAN_HOST_MS_PER_GATE = {'per_gate': 0.0, 'fused_4': 0.045, 'fused_5': 0.075, 'blocked': 0.13}
 LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)
 
 
@@ -532,13 +535,21 @@ def choose_schedule(circuit, qubits, n, ctype):
              'fused_5': dict(compress=5, blocked=False)}
     if n >= 14:
         cands['blocked'] = dict(compress=5, blocked=True)
-    plans, est = {}, {}
+    plans, est, skipped = {}, {}, []
+    n_matrix = sum(1 for g in circuit if not _is_functional(g))
     for name, kw in cands.items():
+        # Planning is host time the caller waits for as well: a candidate is only planned when the best plan so far
+        # still costs more device time than planning it would cost on the host -- no schedule can save more than
+        # that.  Small states (n <~ 24 for the benchmark circuit) therefore run gate by gate straight away.
+        if est and min(est.values()) < PLAN_HOST_MS_PER_GATE[name] * n_matrix:
+            skipped.append(name)
+            continue
         plans[name] = _plan_ops(circuit, qubits, n, ctype, kw['compress'], kw['blocked'])
         est[name] = estimate_ms(plans[name], n, ctype)
     best = min(est, key=est.get)
     return plans[best], {'chosen': best, 'modelled_ms': {k: round(v, 4) for k, v in est.items()},
-                         'passes': {k: sum(1 for g in v if not _is_functional(g)) for k, v in plans.items()}}
+                         'passes': {k: sum(1 for g in v if not _is_functional(g)) for k, v in plans.items()},
+                         'not_planned': skipped}
 
 
 def _execute_ops(state, gates):

@@ -310,7 +310,7 @@ def test_evolution_hip_chooses_a_schedule(torch_cuda):
         psi, info = simulate(gates, initial_state='0' * n, optimize='evolution-hip', return_info=True, qubits=list(range(n)))
         sch = info['schedule']
         assert sch['chosen'] in sch['modelled_ms'] and sch['modelled_ms'][sch['chosen']] == min(sch['modelled_ms'].values())
-        assert ('blocked' in sch['modelled_ms']) == (n >= 14)
+        assert ('blocked' in list(sch['modelled_ms']) + sch['not_planned']) == (n >= 14)
         exp = oracle.evolve_tensordot(gates, n, qubits=list(range(n)))
         assert np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max() < circuit_tol(gates), (n, sch)
     # an explicit setting overrides the model
@@ -320,7 +320,7 @@ def test_evolution_hip_chooses_a_schedule(torch_cuda):
     g20 = rqc_1q2q(20, depth=12, seed=2)
     psi_a, info_a = simulate(g20, initial_state='0' * 20, optimize='evolution', return_info=True, qubits=list(range(20)))
     psi_h, info_h = simulate(g20, initial_state='0' * 20, optimize='evolution-hybridq', return_info=True, qubits=list(range(20)))
-    assert info_a['schedule']['chosen'] == 'blocked' and 'schedule' not in info_h
+    assert info_a['schedule']['chosen'] == 'per_gate' and 'schedule' not in info_h  # short loop: nothing to win back
     assert np.abs(psi_a - psi_h).max() / np.abs(psi_h).max() < 2 * circuit_tol(g20)
 
 

@@ -29,8 +29,15 @@ def test_choose_schedule_cost_model():
     assert estimate_ms(plain, n, np.dtype('complex128')) == pytest.approx(2 * estimate_ms(plain, n, np.dtype('complex64')))
     # tiny states: the launch floor decides, i.e. the fewest calls win; blocking needs n >= 14
     _, small = choose_schedule(rqc_1q2q(10, depth=8, seed=1), list(range(10)), 10, np.dtype('complex64'))
-    assert 'blocked' not in small['modelled_ms'] and small['chosen'] in ('fused_4', 'fused_5')
-    assert small['passes'][small['chosen']] == min(small['passes'].values())
+    assert 'blocked' not in small['modelled_ms'] and 'blocked' not in small['not_planned']
+    # ... and planning is host time too: a candidate is planned only while the best plan so far costs more device
+    # time than planning it costs on the host, so short loops run gate by gate at once and n = 30 plans everything
+    assert small['chosen'] == 'per_gate' and small['not_planned'] == ['fused_4', 'fused_5']
+    assert info['not_planned'] == []
+    _, mid = choose_schedule(rqc_1q2q(20, depth=40, seed=20), list(range(20)), 20, np.dtype('complex64'))
+    assert mid['chosen'] == 'per_gate' and mid['not_planned'] == ['fused_4', 'fused_5', 'blocked']
+    _, m28 = choose_schedule(rqc_1q2q(28, depth=40, seed=28), list(range(28)), 28, np.dtype('complex64'))
+    assert m28['chosen'] == 'fused_5' and m28['not_planned'] == ['blocked']  # 117 ms of planning to save ~40 ms
     # wide gates are priced by their own width
     wide = [g for g in random_dense(20, 40, kmax=7, seed=3) if len(g[1]) >= 6][:3]
     _, w = choose_schedule(wide, list(range(20)), 20, np.dtype('complex64'))
