@@ -65,6 +65,19 @@ def _gate_qubits_matrix(gate):
     raise RuntimeError(f"'{gate}' not supported")  # simulation.py:648-649
 
 
+def flatten(circuit):
+    """``utils.flatten`` (hybridq/circuit/utils.py:26-42, called at simulation.py:239): container gates -- anything that is
+    not a ``(U, qubits)`` pair, provides ``flatten`` and iterates over its gates, the reference's TupleGate duck-typed --
+    are replaced by their gates (nested containers too: a superset of the reference's one level)."""
+    out = []
+    for g in circuit:
+        if not isinstance(g, (tuple, list, np.ndarray)) and callable(getattr(g, 'flatten', None)):
+            out.extend(flatten(list(g)))
+        else:
+            out.append(g)
+    return out
+
+
 def all_qubits(circuit):
     """Sorted qubit labels (hybridq/circuit/circuit.py:406-451)."""
     qs = {q for g in circuit for q in (g.qubits if _is_functional(g) else _gate_qubits_matrix(g)[0])}
@@ -615,7 +628,7 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     if initial_state is None:  # simulation.py:421-423
         raise ValueError("'initial_state' must be specified for optimize='evolution'.")
 
-    circuit = list(circuit)
+    circuit = flatten(circuit)  # simulation.py:239
     # Stochastic gates (simulation.py:241-256): anything with a ``.sample()`` method -- the reference's
     # ``StochasticGate`` duck-typed -- is replaced by one draw when `allow_sampling` is set; `sampling_seed`
     # seeds numpy's global generator for the draws and the previous state is restored afterwards.

@@ -221,3 +221,24 @@ def test_qasm_labels_round_trip_or_are_rejected():
             to_qasm(bad)
     with pytest.raises(ValueError, match='line 2'):
         from_qasm('1\n#@ power = {bad\nx 0\n')
+
+
+def test_flatten_container_gates():
+    """simulate() flattens container gates first (reference simulation.py:239, circuit/utils.py:26-42): anything that
+    provides flatten and iterates over gates -- nested too --; (U, qubits) pairs and matrices are left alone."""
+    from hybridq_amd.simulation import all_qubits, flatten
+
+    class Tup:
+        def __init__(self, gates):
+            self.gates = list(gates)
+
+        def __iter__(self):
+            return iter(self.gates)
+
+        def flatten(self):
+            return self
+
+    gs = [(np.eye(2) * (i + 1), (i,)) for i in range(6)]
+    flat = flatten([gs[0], Tup([gs[1], Tup([gs[2], gs[3]])]), Tup([]), [gs[4][0], gs[4][1]], Tup([gs[5]])])
+    assert [g[1] for g in flat] == [(i,) for i in range(6)] and all(np.array_equal(a[0], b[0]) for a, b in zip(flat, gs))
+    assert all_qubits(flat) == list(range(6))
