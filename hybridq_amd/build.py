@@ -15,7 +15,7 @@ LIB = os.path.join(CSRC, 'libhq_hip.so')
 UNITS = ['hq_core', 'hq_apply', 'hq_swap', 'hq_shard', 'hq_state']
 SOURCES = [os.path.join(CSRC, u + '.hip') for u in UNITS]
 HEADERS = [os.path.join(CSRC, h) for h in ('hq_common.h', 'hq_kernels_common.h', 'hq_kernels_apply.h', 'hq_kernels_swap.h',
-                                           'hq_kernels_aux.h')] + [os.path.join(HERE, '..', 'include', 'hq_hip.h')]
+                                           'hq_kernels_aux.h', 'hq_bitperm.h')] + [os.path.join(HERE, '..', 'include', 'hq_hip.h')]
 ARCH = '--offload-arch=gfx950'
 CFLAGS = [ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 LDFLAGS = [ARCH, '-shared', '-fPIC']

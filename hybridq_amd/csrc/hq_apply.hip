@@ -297,7 +297,7 @@ static int launch_mfma_big_var(Context& c, T* re, T* im, const T* dA, const Mfma
   }
   const uint64_t niter = (1ull << (n - CB - P.n_addr)) >> 4;  // 16 slots per wave iteration
   const uint64_t wgs = (niter + BLOCK / 64 - 1) / (BLOCK / 64);
-  static const int grid_cap = getenv("HQ_BIG_GRID") ? atoi(getenv("HQ_BIG_GRID")) : 2048;
+  static const int grid_cap = env_int("HQ_BIG_GRID", 2048);
   const unsigned grid = (unsigned)std::min<uint64_t>(wgs, (uint64_t)grid_cap);
   const MfmaRoles ro = P.ro;
   if (P.nt)
@@ -312,7 +312,7 @@ static int launch_mfma_big_var(Context& c, T* re, T* im, const T* dA, const Mfma
 //   k = 6 instantiation needs 218 of 256 registers and spills ~100 B/lane inside the MFMA phase: with the
 //   partner wave parked at the barrier nothing covers the reloads)
 static bool big_phased(int kbits, bool is_double) {
-  static const int forced = getenv("HQ_BIG_PHASED") ? atoi(getenv("HQ_BIG_PHASED")) : -1;
+  static const int forced = env_int("HQ_BIG_PHASED", -1);
   return forced >= 0 ? forced != 0 : !(kbits >= 7 && is_double);
 }
 
@@ -332,14 +332,14 @@ static int launch_mfma_big_kv(Context& c, T* re, T* im, const T* dA, const MfmaP
   }
   // experiment / candidate default: one wave per SIMD with two register sets and the memory operations interleaved into
   // the MFMA stream (apply_mfma_stream_kernel); HQ_BIG_STREAM = quarters of the phase the memory operations span (2..4)
-  static const int stream_q = getenv("HQ_BIG_STREAM") ? atoi(getenv("HQ_BIG_STREAM")) : 0;
+  static const int stream_q = env_int("HQ_BIG_STREAM", 0);
   if constexpr (sizeof(T) == 4) {  // complex128 k = 6 with two register sets spills (256 + 256 registers, 308 B scratch): float only
     if (stream_q >= 2 && stream_q <= 4) {
       constexpr unsigned CBs = Vec<T>::VB;
       constexpr int NSs = KBITS - 2, NRBs = 1 << (NSs - 2), NSTEPs = 1 << NSs;
       constexpr size_t lds = (size_t)NRBs * NSTEPs * 64 * sizeof(T);
       const uint64_t niter = (1ull << (n - CBs - P.n_addr)) >> 4;
-      static const int sgrid = getenv("HQ_BIG_GRID") ? atoi(getenv("HQ_BIG_GRID")) : 256;
+      static const int sgrid = env_int("HQ_BIG_GRID", 256);
       const unsigned grid = (unsigned)std::min<uint64_t>((niter + 3) / 4, (uint64_t)sgrid);
       const MfmaRoles ro = P.ro;
       auto go = [&](auto nt_tag, auto q_tag) -> int {
@@ -484,7 +484,7 @@ static int launch_generic(Context& c, T* re, T* im, const T* U, const unsigned* 
 // copy and MFMA phases overlap each other).  HQ_GEMM_TB overrides (experiments).
 template <typename T>
 static unsigned gemm_tile_bits(unsigned k) {
-  static const int forced = getenv("HQ_GEMM_TB") ? atoi(getenv("HQ_GEMM_TB")) : 0;
+  static const int forced = env_int("HQ_GEMM_TB", 0);
   const unsigned big = sizeof(T) == 4 ? 14 : 13;
   if (forced) return std::min<unsigned>(big, std::max<unsigned>((unsigned)forced, k + 4));
   // measured at n = 30 / 29 (gpurun_out/sweep_gemm_tb.txt): 32 columns (f32) / 16 columns (f64)
@@ -515,7 +515,7 @@ static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned*
   constexpr int CBv = sizeof(T) == 4 ? 2 : 1;
   constexpr int NPVx = sizeof(T) == 4 ? (CBW == 2 && RBW == 1 ? 2 : 0)  // f32: k = 7 only (2 x 2, k = 8: no gain, -3 % for some positions; 4 x 2 would spill)
                                      : (CBW == 1 ? (RBW == 1 ? 2 : (RBW == 2 ? 4 : (RBW == 4 ? 8 : 0))) : 0);
-  static const int use_pref = getenv("HQ_GEMM_PREF") ? atoi(getenv("HQ_GEMM_PREF")) : 1;
+  static const int use_pref = env_int("HQ_GEMM_PREF", 1);
   if constexpr (NPVx > 0) {
     if (use_pref && ((1u << (a.tb - CBv)) == (unsigned)NPVx * kGemmBlock)) {
       static bool attr2 = false;
@@ -759,7 +759,7 @@ static int apply_device(Context& c, T* re, T* im, const T* U, const unsigned* po
   // below bit 8 the role kernel wins 2-40 % (its q digits turn the stride into a permutation of a contiguous run).  So
   // Auto sends k <= 3 gates whose targets all sit at bit >= 8 to the VALU kernel and keeps the role kernel for the rest
   // (HQ_VALU_HIGH=0: role kernel everywhere, the round-2 default).
-  static const bool valu_high = !(getenv("HQ_VALU_HIGH") && atoi(getenv("HQ_VALU_HIGH")) == 0);
+  static const bool valu_high = env_int("HQ_VALU_HIGH", 1) != 0;
   if (c.mode == Mode::Auto && valu_high && can_direct && k <= 3 && n >= 20 && sizeof(T) == 4) {  // measured for complex64 only
     unsigned lo = pos[0];
     for (unsigned j = 1; j < k; ++j) lo = std::min(lo, pos[j]);
@@ -850,7 +850,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     if (check_positions(lp, tb, k)) return fail("apply_blocked: duplicate targets");
     // largest k that takes the register butterfly on the LDS tile (blocked_inner_gate_valu) instead
     // of the matrix-core form with identity dummies: measured, k = 1 wins (4x fewer flops), k = 2 does not
-    static int valu_kmax = getenv("HQ_BLOCKED_VALU") ? atoi(getenv("HQ_BLOCKED_VALU")) : 1;
+    static int valu_kmax = env_int("HQ_BLOCKED_VALU", 1);
     if (k <= 2 && (int)k <= valu_kmax) {
       std::vector<T> Us;
       unsigned sp[kMaxK];
@@ -901,8 +901,8 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     attr_done = true;
   }
   const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
-  static int block_threads = getenv("HQ_BLOCKED_THREADS") ? atoi(getenv("HQ_BLOCKED_THREADS")) : 512;
-  static int a_in_lds = getenv("HQ_BLOCKED_ALDS") ? atoi(getenv("HQ_BLOCKED_ALDS")) : 1;
+  static int block_threads = env_int("HQ_BLOCKED_THREADS", 512);
+  static int a_in_lds = env_int("HQ_BLOCKED_ALDS", 1);
   // LDS left per workgroup behind the tile when `per_cu` workgroups share a CU
   const size_t a_budget = (160 * 1024) / per_cu - tile_bytes > 2048 ? (160 * 1024) / per_cu - tile_bytes - 1024 : 0;
   // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
@@ -911,7 +911,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
   // register prefetch of the next tile (512 threads, 4 vectors per thread and plane = 13 (f32) / 12 (f64) tile bits;
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
-  static int use_pref = getenv("HQ_BLOCKED_PREF") ? atoi(getenv("HQ_BLOCKED_PREF")) : 1;
+  static int use_pref = env_int("HQ_BLOCKED_PREF", 1);
   const bool pref = use_pref && block_threads != 256 && tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits);
   if (fits) {
     void *dG = nullptr, *dA = nullptr;
@@ -921,7 +921,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     // experiment (HQ_BLOCKED_GPRE=1): the operand / lane-table reads of the NEXT inner gate issued in front of the barrier that
     // ends the current one.  Measured on the n = 30 benchmark circuit: 138.6 ms with it, 136.8 without -- the per-gate
     // prologue is not what holds the matrix pipe at 73 % -- so it stays off.
-    static int use_gpre = getenv("HQ_BLOCKED_GPRE") ? atoi(getenv("HQ_BLOCKED_GPRE")) : 0;
+    static int use_gpre = env_int("HQ_BLOCKED_GPRE", 0);
     if (pref && use_gpre && sizeof(T) == 4) {  // complex128 has no registers left for it
       static bool attr2 = false;
       if (!attr2) {

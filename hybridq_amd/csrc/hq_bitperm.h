@@ -21,7 +21,7 @@ struct BitPermPlan {
 // runs win -- 2^13 float32 elements (32 KiB, four 256-thread workgroups per CU) 4.6-5.5 TB/s, 2^12 4.2-4.8, 2^11 2.5-3.4
 template <typename E>
 static unsigned bitperm_default_tb() {
-  static const int forced = getenv("HQ_PERM_TB") ? atoi(getenv("HQ_PERM_TB")) : 0;
+  static const int forced = env_int("HQ_PERM_TB", 0);
   const unsigned lo = sizeof(E) == 4 ? 10 : 9, hi = sizeof(E) == 4 ? 15 : 14;
   if (forced) return std::min(hi, std::max(lo, (unsigned)forced - (sizeof(E) == 4 ? 0u : 1u)));
   return sizeof(E) == 4 ? 13 : 12;
@@ -61,9 +61,9 @@ static bool plan_bitperm(const unsigned* perm, unsigned m, bool inplace, BitPerm
     const unsigned max_tb = sizeof(E) == 4 ? 15 : 14;  // 128 KiB
     // the largest tile the state allows: one 1024-thread workgroup per CU on 128 KiB tiles measured 5.1-5.3 TB/s, two
     // on 64 KiB tiles 4.2-4.9 (HQ_PERM_INPLACE_TB overrides)
-    static const int forced_ip = getenv("HQ_PERM_INPLACE_TB") ? atoi(getenv("HQ_PERM_INPLACE_TB")) : 0;
+    static const int forced_ip = env_int("HQ_PERM_INPLACE_TB", 0);
     tb = std::max(need, std::min(m, forced_ip ? (unsigned)forced_ip - (sizeof(E) == 4 ? 0u : 1u) : max_tb));
-    static const bool allow_split = !(getenv("HQ_PERM_SPLIT") && atoi(getenv("HQ_PERM_SPLIT")) == 0);
+    static const bool allow_split = env_int("HQ_PERM_SPLIT", 1) != 0;
     if (need == max_tb + 1 && allow_split) {
       // one moved bit too many for the LDS tile: take a moved bit b out of the tile (SPLIT mode of the kernel).  b must be
       // one of the three highest tile bits whose source side rank is an iteration bit, and neither b nor perm[b] may be
@@ -167,7 +167,7 @@ static bool plan_bitperm(const unsigned* perm, unsigned m, bool inplace, BitPerm
   const unsigned nvec = (1u << tb) >> VB;
   // register prefetch of the next tile: measured slower on 64 KiB tiles (4.19 vs 4.89 TB/s) and on 128 KiB tiles (5.13 vs
   // 5.32): off unless HQ_PERM_PREF=1
-  static const int use_pref = getenv("HQ_PERM_PREF") ? atoi(getenv("HQ_PERM_PREF")) : 0;
+  static const int use_pref = env_int("HQ_PERM_PREF", 0);
   if (nvec <= 8 * 256) {
     P.block = 256;
     P.nv = nvec / 256;
@@ -193,7 +193,7 @@ static int launch_bitperm_inst(Context& c, hipStream_t s, bool on_lib_stream, co
   }
   const uint64_t total = ntiles * P.a.planes;
   // one resident set of workgroups looping over the tiles measured best (n = 30: grid x1 5.35-5.85 TB/s, x4 4.86-5.69, x32 3.5-4.3)
-  static const int grid_mult = getenv("HQ_PERM_GRID") ? std::max(1, atoi(getenv("HQ_PERM_GRID"))) : 1;
+  static const int grid_mult = std::max(1, env_int("HQ_PERM_GRID", 1));
   const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>((160 * 1024) / (P.lds + 512), 2048 / BLOCK));
   const unsigned grid = (unsigned)std::min<uint64_t>(total, 256 * per_cu * (BLOCK == 256 ? (uint64_t)grid_mult : 1));
   const BitPermArg a = P.a;

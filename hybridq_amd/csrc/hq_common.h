@@ -66,6 +66,11 @@ struct Context {
 
 Context& ctx();
 int fail(const std::string& msg);
+// integer switch from the environment (experiment knobs: HQ_*), `dflt` when unset
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 void read_env(Context& c);
 // The library keeps its upload arena and scratch buffers on ONE device (one process per GPU); a second
 // device in the same process is refused loudly.

@@ -109,8 +109,8 @@ static int launch_pack(Context& c, hipStream_t s, const E* s0, const E* s1, cons
   bool dal = true;
   for (unsigned j = 0; j < (1u << a.g); ++j)
     for (unsigned p = 0; p < a.planes; ++p) dal = dal && reinterpret_cast<uintptr_t>(a.dst[j][p]) % 16 == 0;
-  static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
-  static const bool gather_low_fixed = getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 3;
+  static const bool one_pass = env_int("HQ_PERM_TILE", 1) != 0;
+  static const bool gather_low_fixed = env_int("HQ_PERM_TILE", 0) == 3;
   if (one_pass && al && dal && perm && !(gather_low_fixed && bitperm_low_run_fixed<E>(perm, a.m))) {
     // the eviction permutation at full cache-line granularity on both sides (bitperm_tile_kernel); the gather kernel
     // below stays for shards smaller than a tile

@@ -175,7 +175,7 @@ static int vmm_granule_min(const Context& c, size_t* gmin) {
 static void vmm_destroy(Vmm& v) {
   if (v.va && v.mapped) (void)hipMemUnmap(v.va, v.size);
   for (auto h : v.handles) (void)hipMemRelease(h);
-  static const bool free_va = getenv("HQ_VMM_FREE_VA") && atoi(getenv("HQ_VMM_FREE_VA")) != 0;
+  static const bool free_va = env_int("HQ_VMM_FREE_VA", 0) != 0;
   if (v.va && (free_va || !v.touched)) (void)hipMemAddressFree(v.va, v.size);  // a range that never held a mapping is safe to return
   v = Vmm();
 }
@@ -371,7 +371,8 @@ static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void**
   st.n = n;
   st.float_bits = (unsigned)float_bits;
   st.bytes = bytes;
-  static const bool env_plain = getenv("HQ_STATE_ALLOC") && std::string(getenv("HQ_STATE_ALLOC")) != "vmm";
+  const char* env_alloc = getenv("HQ_STATE_ALLOC");
+  const bool env_plain = env_alloc && std::string(env_alloc) != "vmm";
   const bool tuned = !(flags & 1) && !env_plain && bytes >= kTunedMinBytes && n >= 8;
   auto finish = [&](StateAlloc& s) {
     *out_re = s.re;
@@ -421,7 +422,8 @@ static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void**
   if (vmm_granule_min(c, &gmin)) return 1;
   // a draw that streams at least this fast ends the search early once the evidence is in (the fast family measures
   // 6.3-6.4 TB/s at n = 30; slower winners keep the search going to its limit)
-  const double good_tbps = getenv("HQ_STATE_GOOD_TBPS") ? atof(getenv("HQ_STATE_GOOD_TBPS")) : 6.25;
+  const char* env_good = getenv("HQ_STATE_GOOD_TBPS");
+  const double good_tbps = env_good ? atof(env_good) : 6.25;
   std::vector<StateAlloc> cands;
   std::string draws;
   int rc = 0;
@@ -522,7 +524,7 @@ static int state_free(Context& c, void* re) {
     if (pool.live[i].re == re) {
       StateAlloc st = pool.live[i];
       pool.live.erase(pool.live.begin() + (long)i);
-      static const bool no_pool = getenv("HQ_STATE_POOL") && atoi(getenv("HQ_STATE_POOL")) == 0;
+      static const bool no_pool = env_int("HQ_STATE_POOL", 1) == 0;
       bool keep = st.tuned && !no_pool;
       for (const auto& s : pool.idle) keep = keep && !(s.n == st.n && s.float_bits == st.float_bits);  // one per size
       if (keep) {

@@ -42,7 +42,7 @@ static int launch_tile_permute(Context& c, E* a, unsigned n, const std::vector<u
   }
   const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
   // register prefetch of the next tile for the 32 KiB tiles of 4-byte elements (as in swap_lds_kernel; HQ_SWAP_PREF=0: off)
-  static const int use_pref = getenv("HQ_SWAP_PREF") ? atoi(getenv("HQ_SWAP_PREF")) : 1;
+  static const int use_pref = env_int("HQ_SWAP_PREF", 1);
   if (use_pref && sizeof(E) == 4 && ((1u << ta.tb) / VEC) == 8u * kBlock) {
     if constexpr (sizeof(E) == 4) HQ_LAUNCH(c, (tile_permute_kernel<E, VEC, 8>), dim3(grid), dim3(kBlock), lds, a, ta, ntiles);
   } else {
@@ -116,12 +116,12 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
   if (identity) return 0;
   const unsigned table_bits = sizeof(E) == 4 ? 13 : 12;  // 32 KiB of elements + index table
   const unsigned max_lds_bits = sizeof(E) == 4 ? 15 : 14;  // 128 KiB of elements, index computed inline
-  static const bool two_pass = !(getenv("HQ_SWAP_TWO_PASS") && atoi(getenv("HQ_SWAP_TWO_PASS")) == 0);
-  static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
+  static const bool two_pass = env_int("HQ_SWAP_TWO_PASS", 1) != 0;
+  static const bool one_pass = env_int("HQ_PERM_TILE", 1) != 0;
   // s >= 8: ONE in-place pass through 128 KiB LDS tiles of bitperm_tile_kernel (the tile holds every moved bit; up to 15
   // moved bits for 4-byte, 14 for 8-byte elements).  Round 2 took two passes for s > 13 (2x the algorithmic traffic,
   // 2.6 TB/s); for 8 <= s <= 13 the tile kernel also beats the table-driven kernel below (n = 30: 5.5 vs 5.0-5.1 TB/s).
-  static const unsigned tile_min = getenv("HQ_SWAP_TILE_MIN") ? (unsigned)atoi(getenv("HQ_SWAP_TILE_MIN")) : 8;
+  static const unsigned tile_min = (unsigned)env_int("HQ_SWAP_TILE_MIN", 8);
   if ((s > table_bits || s >= tile_min) && one_pass && reinterpret_cast<uintptr_t>(a) % 16 == 0) {
     std::vector<unsigned> full(n);
     for (unsigned i = 0; i < n; ++i) full[i] = i < s ? pos[i] : i;
@@ -161,7 +161,7 @@ static int swap_device(Context& c, E* a, const unsigned* pos, unsigned n, unsign
     // register prefetch of the next tile: pays for the 32 KiB tiles of 4-byte elements only (s = 13 and the first
     // pass of the two-pass path: 4.39 -> 5.09 TB/s); smaller tiles already overlap through their many resident
     // workgroups and lose 5-9 % with it (tools/swap_rate.py).  HQ_SWAP_PREF=0 switches it off
-    static const int use_pref = getenv("HQ_SWAP_PREF") ? atoi(getenv("HQ_SWAP_PREF")) : 1;
+    static const int use_pref = env_int("HQ_SWAP_PREF", 1);
     const unsigned npv = vec ? (1u << tile_bits) / (kBlock * VEC) : 0;
     if (!table)
       HQ_LAUNCH(c, (swap_lds_kernel<E, VEC, false, 0>), dim3(grid), dim3(kBlock), lds, a, sa, tile_bits, ntiles);
@@ -241,10 +241,10 @@ static int permute_bits_entry(const E* src, E* dst, const unsigned* perm, unsign
     ++pa.nfields;
     i += len;
   }
-  static const bool one_pass = !(getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 0);
+  static const bool one_pass = env_int("HQ_PERM_TILE", 1) != 0;
   // HQ_PERM_TILE=3: the gather kernel whenever the low 128 bytes of the index space stay in place (it then moves whole
   // cache lines too; measured 5.0-5.5 TB/s against 5.3-5.6 through the tiles, box to box: not the default)
-  static const bool gather_low_fixed = getenv("HQ_PERM_TILE") && atoi(getenv("HQ_PERM_TILE")) == 3;
+  static const bool gather_low_fixed = env_int("HQ_PERM_TILE", 0) == 3;
   if (one_pass && !(gather_low_fixed && bitperm_low_run_fixed<E>(perm, n)) && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
       reinterpret_cast<uintptr_t>(dst) % 16 == 0) {
     // one pass at full cache-line granularity on both sides, whatever bits move (bitperm_tile_kernel); the gather
