@@ -222,4 +222,5 @@ def test_dm_1__simulation_1(torch_cuda):
     expected = np.kron(psi_1.ravel(), psi_1.ravel().conj())
     assert_allclose(expected, rho_1.ravel())
     sv = dm.to_statevector_circuit(circuit)
-    assert np.abs(expected - rho_1.ravel()).max() / np.abs(expected).max() < circuit_tol(sv, circuit)
+    # rho's own rounding (400 one-sided gates) against psi (x) psi*, which carries psi's rounding twice
+    assert np.abs(expected - rho_1.ravel()).max() / np.abs(expected).max() < 2 * circuit_tol(sv, circuit)
