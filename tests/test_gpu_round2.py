@@ -299,7 +299,7 @@ def test_functional_gates_with_dot_inplace_on_device(torch_cuda):
     assert np.abs(b - exp2).max() / np.abs(exp2).max() < 1e-12
 
 
-def test_evolution_hip_chooses_a_schedule(torch_cuda):
+def test_evolution_hip_chooses_a_schedule(torch_cuda, monkeypatch):
     """optimize='evolution-hip': the cost model picks between gate-by-gate / fused 4 / fused 5 / cache-blocked
     and records the choice; whatever it picks, the state is the circuit's."""
     import oracle
@@ -322,6 +322,12 @@ def test_evolution_hip_chooses_a_schedule(torch_cuda):
     psi_h, info_h = simulate(g20, initial_state='0' * 20, optimize='evolution-hybridq', return_info=True, qubits=list(range(20)))
     assert info_a['schedule']['chosen'] == 'per_gate' and 'schedule' not in info_h  # short loop: nothing to win back
     assert np.abs(psi_a - psi_h).max() / np.abs(psi_h).max() < 2 * circuit_tol(g20)
+    # with planning priced at nothing every candidate is planned and the cache-blocked schedule wins, as at n = 30
+    from hybridq_amd import simulation
+    monkeypatch.setattr(simulation, 'PLAN_HOST_MS_PER_GATE', dict.fromkeys(simulation.PLAN_HOST_MS_PER_GATE, 0.0))
+    psi_b, info_b = simulate(g20, initial_state='0' * 20, optimize='evolution', return_info=True, qubits=list(range(20)))
+    assert info_b['schedule']['chosen'] == 'blocked' and info_b['schedule']['not_planned'] == []
+    assert np.abs(psi_b - psi_h).max() / np.abs(psi_h).max() < 2 * circuit_tol(g20)
 
 
 @pytest.mark.parametrize('ct,n,tb', [('complex64', 25, 13), ('complex128', 24, 12), ('complex64', 23, 13)])
