@@ -651,6 +651,16 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
         circuit = _simplify_runs(circuit, remove_id_gates, atol, simplify if isinstance(simplify, dict) else {})
         if not kwargs.get('qubits') and all_qubits(circuit) != qubits:
             raise ValueError("Active qubits have changed after simplification. Forcing stop.")
+    if not isinstance(initial_state, str):  # simulation.py:270-281 (a flat vector of 2^n amplitudes is accepted as well)
+        shape = np.shape(initial_state)
+        if len(shape) > 1 and any(x != 2 for x in shape):
+            raise ValueError("Only qubits of dimension 2 are supported.")
+        if len(shape) > 1 and len(shape) != n:
+            raise ValueError("Wrong number of qubits for initial/final state.")
+    elif len(initial_state) not in (1, n):  # simulation.py:264-268
+        raise ValueError("Wrong number of qubits for initial/final state.")
+    if 2**n > kwargs['max_largest_intermediate']:  # simulation.py:409-412, before any planning work
+        raise MemoryError("Memory for the given number of qubits exceeds the 'max_largest_intermediate'.")
     ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
     # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519)
     schedule_info = None
@@ -658,9 +668,6 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
         gates, schedule_info = choose_schedule(circuit, qubits, n, ctype)
     else:
         gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
-    if 2**n > kwargs['max_largest_intermediate']:  # simulation.py:409-412
-        raise MemoryError("Memory for the given number of qubits exceeds the 'max_largest_intermediate'.")
-
     torch = _torch()
     if _wants_shards(kwargs):
         return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule)

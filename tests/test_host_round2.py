@@ -242,3 +242,24 @@ def test_flatten_container_gates():
     flat = flatten([gs[0], Tup([gs[1], Tup([gs[2], gs[3]])]), Tup([]), [gs[4][0], gs[4][1]], Tup([gs[5]])])
     assert [g[1] for g in flat] == [(i,) for i in range(6)] and all(np.array_equal(a[0], b[0]) for a, b in zip(flat, gs))
     assert all_qubits(flat) == list(range(6))
+
+
+def test_simulate_argument_errors_precede_device_work():
+    """The reference's argument checks (simulation.py:264-281, :409-423), raised before planning or touching a device:
+    these run on a box without a GPU."""
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    gates = rqc_1q2q(12, depth=4, seed=1)
+    q = list(range(12))
+    with pytest.raises(ValueError, match="must be specified"):
+        simulate(gates, qubits=q)
+    with pytest.raises(ValueError, match="Wrong number of qubits"):
+        simulate(gates, initial_state='0' * 11, qubits=q)
+    with pytest.raises(ValueError, match="Only qubits of dimension 2"):
+        simulate(gates, initial_state=np.zeros((4,) * 6), qubits=q)
+    with pytest.raises(ValueError, match="Wrong number of qubits"):
+        simulate(gates, initial_state=np.zeros((2,) * 11), qubits=q)
+    with pytest.raises(MemoryError):
+        simulate(gates, initial_state='0', qubits=q, max_largest_intermediate=2**11)
+    with pytest.raises(ValueError, match="only implements optimize='evolution'"):
+        simulate(gates, initial_state='0', optimize='tn')
