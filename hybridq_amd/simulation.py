@@ -345,16 +345,29 @@ class EvolutionState:
                 new_psi = torch.as_tensor(new_psi, device=self.planes.device).to(self.planes.dtype)
                 self.planes.copy_(new_psi.reshape(2, -1))
             return
-        core.sync()
-        host = np.empty((2, 1 << self.n), dtype=self.float_type)
-        for p in (0, 1):  # chunked, threaded copies for large states (see _to_host)
-            _to_host(self.planes[p], out=host[p])
-        new_psi, new_order = gate.apply(psi=host.reshape((2,) + (2,) * self.n), order=order)
+        new_psi, new_order = gate.apply(psi=self.to_split_array(), order=order)
         if any(x != y for x, y in zip(order, new_order)):  # :552-554
             raise RuntimeError("'order' has changed.")
         new_psi = np.ascontiguousarray(new_psi, dtype=self.float_type).reshape(2, -1)
         for p in (0, 1):
             _from_host(new_psi[p], self.planes[p])
+
+    def to_split_array(self):
+        """The state on the host in the reference's own working layout: a real array of shape (2,) + (2,)*n, [0] = real
+        parts, [1] = imaginary parts (simulation.py:490-497) -- what FunctionalGates receive and what the reference's
+        ``simulate(..., return_numpy_array=False)`` returns."""
+        core.use_torch_stream()
+        core.sync()
+        host = np.empty((2, 1 << self.n), dtype=self.float_type)
+        for p in (0, 1):  # chunked, threaded copies for large states (see _to_host)
+            _to_host(self.planes[p], out=host[p])
+        return host.reshape((2,) + (2,) * self.n)
+
+    def __array__(self, dtype=None, copy=None):
+        """``np.asarray(state)``: the split array above, so that code written against the reference's
+        ``return_numpy_array=False`` result (a (2,) + (2,)*n real array) keeps working on the device-resident state."""
+        a = self.to_split_array()
+        return a if dtype is None else a.astype(dtype, copy=False)
 
     def compile(self, circuit, compress=4, blocked=False):
         """Record `circuit` (matrix gates only) against THIS state's planes into a
@@ -596,7 +609,8 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     ``compress=5``, as defaults); everything the reference routes elsewhere (einsum, tensor
     networks, Clifford) is out of scope.
     Supported kwargs: ``allow_sampling`` / ``sampling_seed`` (stochastic gates = objects with ``.sample()``, as
-    at simulation.py:241-256), ``return_info``, ``return_numpy_array`` (default True),
+    at simulation.py:241-256), ``return_info``, ``return_numpy_array`` (default True; False returns the device-resident
+    :class:`EvolutionState`, whose ``np.asarray()`` is the reference's (2,) + (2,)*n split array),
     ``max_largest_intermediate`` (default 2**36 amplitudes: one MI355X holds n=34 in
     complex64), ``compress`` (max qubits of a fused gate, default 4 like simulation.py:314;
     0 applies the gates as given; a dict may carry ``max_n_qubits`` plus the keyword

@@ -224,3 +224,19 @@ def test_dm_1__simulation_1(torch_cuda):
     sv = dm.to_statevector_circuit(circuit)
     # rho's own rounding (400 one-sided gates) against psi (x) psi*, which carries psi's rounding twice
     assert np.abs(expected - rho_1.ravel()).max() / np.abs(expected).max() < 2 * circuit_tol(sv, circuit)
+
+
+def test_return_numpy_array_false_is_the_split_state(torch_cuda):
+    """simulation.py:669-675: without `return_numpy_array` the reference hands back its working array, real and imaginary
+    parts as a (2,) + (2,)*n real array; here that is np.asarray() of the device-resident state."""
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import EvolutionState, simulate
+    n = 14
+    gates = rqc_1q2q(n, depth=6, seed=5)
+    psi = simulate(gates, initial_state='+' * n, qubits=list(range(n)))
+    state = simulate(gates, initial_state='+' * n, qubits=list(range(n)), return_numpy_array=False)
+    assert isinstance(state, EvolutionState)
+    split = np.asarray(state)
+    assert split.shape == (2,) + (2,) * n and split.dtype == np.float32
+    assert np.array_equal(split[0], psi.real) and np.array_equal(split[1], psi.imag)
+    assert np.asarray(state, dtype=np.float64).dtype == np.float64
