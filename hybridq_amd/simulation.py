@@ -530,6 +530,8 @@ TUNED_PLACEMENT_SEARCH_MS = 2500.0  # what alloc_planes' draw-and-probe search c
 #: host time of planning one candidate schedule, per matrix gate of the circuit (measured on the benchmark circuits,
 #: n = 16..30: fusion to 4 ~0.04 ms / gate, to 5 ~0.07, the blocked planner ~0.13)
 PLAN_HOST_MS_PER_GATE = {'per_gate': 0.0, 'fused_4': 0.045, 'fused_5': 0.075, 'blocked': 0.13}
+BLOCKED_VS_FUSED5 = 0.55  # modelled time of the cache-blocked plan over the fused-5 plan (0.45 benchmark circuit, 0.63 dense 3q/4q gates)
+PREDICTION_SLACK = 0.85  # a plan may come out this much better than predicted (commuting gates fuse further)
 LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)
 
 
@@ -552,30 +554,61 @@ def estimate_ms(ops, n, ctype):
     return t
 
 
+def _predict_fused_ms(circuit, n, ctype, kmax):
+    """What fusion to `kmax` qubits will cost, from the qubit sets alone (blocking._dry_layers: the grouping of fusion.fuse
+    without matrix commutation, ~2 ms for 900 gates instead of 40-70): a prediction to decide what is worth planning."""
+    from .blocking import _dry_layers
+    scale = 2.0 ** (n - 30) * (2.0 if np.dtype(ctype) == np.dtype('complex128') else 1.0)
+    t, run = 0.0, []
+
+    def flush():
+        nonlocal t
+        for layer in _dry_layers(run, kmax):
+            t += max(PASS_MS[min(len(layer), 10)] * scale, LAUNCH_FLOOR_MS)
+        run.clear()
+
+    for g in circuit:
+        if _is_functional(g):
+            flush()
+        else:
+            run.append(frozenset(_gate_qubits_matrix(g)[0]))
+    flush()
+    return t
+
+
 def choose_schedule(circuit, qubits, n, ctype):
-    """Plan the circuit every way this driver knows -- gate by gate, fused to 4 qubits (the reference's
-    default, simulation.py:314), fused to 5, cache-blocked -- and keep the plan with the smallest
-    modelled time.  Host work only, outside the timed loop like the reference's own compression
-    (simulation.py:436-454 precede :519).  Returns (ops, info)."""
+    """Plan the circuit the ways this driver knows -- gate by gate, fused to 4 qubits (the reference's default,
+    simulation.py:314), fused to 5, cache-blocked -- and keep the plan with the smallest modelled time.  Host work only,
+    outside the timed loop like the reference's own compression (simulation.py:436-454 precede :519), but the caller
+    waits for it all the same (at n = 30 planning all four takes 210 ms against a 137 ms loop), so a schedule is only
+    planned when its PREDICTED device time plus its planning time beats the best plan in hand: the gate-by-gate plan is
+    free, the fused ones are predicted from the qubit sets (exact unless gates commute), the cache-blocked one as
+    BLOCKED_VS_FUSED5 of the fused-5 prediction.  Short loops (n <~ 24 of the benchmark circuit) therefore run gate by
+    gate at once, n = 26-28 plans fusion to 4 only, n >= 29 the cache-blocked schedule only.  Returns (ops, info)."""
     cands = {'per_gate': dict(compress=0, blocked=False), 'fused_4': dict(compress=4, blocked=False),
              'fused_5': dict(compress=5, blocked=False)}
     if n >= 14:
         cands['blocked'] = dict(compress=5, blocked=True)
-    plans, est, skipped = {}, {}, []
     n_matrix = sum(1 for g in circuit if not _is_functional(g))
-    for name, kw in cands.items():
-        # Planning is host time the caller waits for as well: a candidate is only planned when the best plan so far
-        # still costs more device time than planning it would cost on the host -- no schedule can save more than
-        # that.  Small states (n <~ 24 for the benchmark circuit) therefore run gate by gate straight away.
-        if est and min(est.values()) < PLAN_HOST_MS_PER_GATE[name] * n_matrix:
-            skipped.append(name)
-            continue
-        plans[name] = _plan_ops(circuit, qubits, n, ctype, kw['compress'], kw['blocked'])
-        est[name] = estimate_ms(plans[name], n, ctype)
+    cost = {name: PLAN_HOST_MS_PER_GATE[name] * n_matrix for name in cands}
+    plans = {'per_gate': _plan_ops(circuit, qubits, n, ctype, 0, False)}
+    est = {'per_gate': estimate_ms(plans['per_gate'], n, ctype)}
+    pred = {}
+    if est['per_gate'] > min(c for name, c in cost.items() if name != 'per_gate'):  # else nothing can pay its planning back
+        pred['fused_4'] = _predict_fused_ms(circuit, n, ctype, 4)
+        pred['fused_5'] = _predict_fused_ms(circuit, n, ctype, 5)
+        if 'blocked' in cands:
+            pred['blocked'] = BLOCKED_VS_FUSED5 * pred['fused_5']
+    for name in sorted(pred, key=lambda k: pred[k] + cost[k]):
+        if cost[name] + PREDICTION_SLACK * pred[name] < min(est.values()):
+            kw = cands[name]
+            plans[name] = _plan_ops(circuit, qubits, n, ctype, kw['compress'], kw['blocked'])
+            est[name] = estimate_ms(plans[name], n, ctype)
     best = min(est, key=est.get)
     return plans[best], {'chosen': best, 'modelled_ms': {k: round(v, 4) for k, v in est.items()},
                          'passes': {k: sum(1 for g in v if not _is_functional(g)) for k, v in plans.items()},
-                         'not_planned': skipped}
+                         'predicted_ms': {k: round(v, 4) for k, v in pred.items()},
+                         'not_planned': [k for k in cands if k not in plans]}
 
 
 def _execute_ops(state, gates):

@@ -322,11 +322,11 @@ def test_evolution_hip_chooses_a_schedule(torch_cuda, monkeypatch):
     psi_h, info_h = simulate(g20, initial_state='0' * 20, optimize='evolution-hybridq', return_info=True, qubits=list(range(20)))
     assert info_a['schedule']['chosen'] == 'per_gate' and 'schedule' not in info_h  # short loop: nothing to win back
     assert np.abs(psi_a - psi_h).max() / np.abs(psi_h).max() < 2 * circuit_tol(g20)
-    # with planning priced at nothing every candidate is planned and the cache-blocked schedule wins, as at n = 30
+    # with planning priced at nothing the schedule predicted to be fastest is planned first: the cache-blocked one, as at n = 30
     from hybridq_amd import simulation
     monkeypatch.setattr(simulation, 'PLAN_HOST_MS_PER_GATE', dict.fromkeys(simulation.PLAN_HOST_MS_PER_GATE, 0.0))
     psi_b, info_b = simulate(g20, initial_state='0' * 20, optimize='evolution', return_info=True, qubits=list(range(20)))
-    assert info_b['schedule']['chosen'] == 'blocked' and info_b['schedule']['not_planned'] == []
+    assert info_b['schedule']['chosen'] == 'blocked'
     assert np.abs(psi_b - psi_h).max() / np.abs(psi_h).max() < 2 * circuit_tol(g20)
 
 

@@ -13,14 +13,19 @@ if ROOT not in sys.path:
 
 def test_choose_schedule_cost_model():
     from hybridq_amd.circuits import random_dense, rqc_1q2q
-    from hybridq_amd.simulation import PASS_MS, choose_schedule, estimate_ms
+    from hybridq_amd.simulation import PASS_MS, _plan_ops, choose_schedule, estimate_ms
     n = 30
     gates = rqc_1q2q(n, depth=40, seed=n)
     ops, info = choose_schedule(gates, list(range(n)), n, np.dtype('complex64'))
-    est = info['modelled_ms']
+    est = dict(info['modelled_ms'])
     # measured on MI355X (profiles/r02_v7_bench.json): 2415-2509 / 399-408 / 307-311 / 135-148 ms
-    assert abs(est['per_gate'] - 2431) < 50 and abs(est['fused_4'] - 400) < 25 and abs(est['fused_5'] - 307) < 15
-    assert abs(est['blocked'] - 137) < 10 and info['chosen'] == 'blocked'
+    assert abs(est['per_gate'] - 2431) < 50 and abs(est['blocked'] - 137) < 10 and info['chosen'] == 'blocked'
+    # the fused schedules are only PREDICTED here (from the qubit sets), not planned: they cannot beat the blocked one
+    assert info['not_planned'] == ['fused_4', 'fused_5']
+    for name, k, ms, tol in (('fused_4', 4, 400, 25), ('fused_5', 5, 307, 15)):
+        est[name] = estimate_ms(_plan_ops(gates, list(range(n)), n, np.dtype('complex64'), k, False), n, np.dtype('complex64'))
+        assert abs(est[name] - ms) < tol and info['predicted_ms'][name] == pytest.approx(est[name], rel=0.02)
+    assert 0.4 < est['blocked'] / est['fused_5'] < 0.7  # BLOCKED_VS_FUSED5 predicts 0.55
     assert est['per_gate'] == pytest.approx(900 * PASS_MS[1], rel=1e-6)
     # complex128 costs twice the bytes, one qubit less halves them
     # complex128: twice the bytes
@@ -30,14 +35,23 @@ def test_choose_schedule_cost_model():
     # tiny states: the launch floor decides, i.e. the fewest calls win; blocking needs n >= 14
     _, small = choose_schedule(rqc_1q2q(10, depth=8, seed=1), list(range(10)), 10, np.dtype('complex64'))
     assert 'blocked' not in small['modelled_ms'] and 'blocked' not in small['not_planned']
-    # ... and planning is host time too: a candidate is planned only while the best plan so far costs more device
-    # time than planning it costs on the host, so short loops run gate by gate at once and n = 30 plans everything
+    # ... and planning is host time too: a schedule is planned only when its predicted device time plus its planning time
+    # beats the best plan in hand, so short loops run gate by gate at once, n = 26..28 plans fusion to 4 only and
+    # n >= 29 the cache-blocked schedule only
     assert small['chosen'] == 'per_gate' and small['not_planned'] == ['fused_4', 'fused_5']
-    assert info['not_planned'] == []
     _, mid = choose_schedule(rqc_1q2q(20, depth=40, seed=20), list(range(20)), 20, np.dtype('complex64'))
     assert mid['chosen'] == 'per_gate' and mid['not_planned'] == ['fused_4', 'fused_5', 'blocked']
     _, m28 = choose_schedule(rqc_1q2q(28, depth=40, seed=28), list(range(28)), 28, np.dtype('complex64'))
-    assert m28['chosen'] == 'fused_5' and m28['not_planned'] == ['blocked']  # 117 ms of planning to save ~40 ms
+    assert m28['chosen'] == 'fused_4' and m28['not_planned'] == ['fused_5', 'blocked']
+    _, m29 = choose_schedule(rqc_1q2q(29, depth=40, seed=29), list(range(29)), 29, np.dtype('complex64'))
+    assert m29['chosen'] == 'blocked' and m29['not_planned'] == ['fused_4', 'fused_5']
+    # FunctionalGates cut the prediction's runs like they cut the plans
+    from hybridq_amd.simulation import FunctionalGate, _predict_fused_ms
+    g29 = rqc_1q2q(29, depth=40, seed=29)
+    cut = g29[:400] + [FunctionalGate((0,), lambda psi, order: (psi, order))] + g29[400:]
+    p_cut = _predict_fused_ms(cut, 29, np.dtype('complex64'), 4)
+    assert p_cut == pytest.approx(estimate_ms(_plan_ops(cut, list(range(29)), 29, np.dtype('complex64'), 4, False), 29, np.dtype('complex64')), rel=0.02)
+    assert p_cut >= _predict_fused_ms(g29, 29, np.dtype('complex64'), 4)
     # wide gates are priced by their own width
     wide = [g for g in random_dense(20, 40, kmax=7, seed=3) if len(g[1]) >= 6][:3]
     _, w = choose_schedule(wide, list(range(20)), 20, np.dtype('complex64'))
