@@ -21,6 +21,24 @@ import numpy as np
 
 
 _EMBED_INDEX = {}  # (k, gate axes) -> (rows, cols) of the embedded matrix, cached
+_BLAS = []
+
+
+def single_thread_blas():
+    """Context manager: numpy's BLAS on ONE thread while a planner runs.  The planners multiply thousands of 4x4 ... 64x64
+    matrices with Python in between; a threaded BLAS wakes its pool for each of them (measured here: 0.7 ms per call once
+    the workers have gone to sleep, planning the n = 30 benchmark circuit 0.7-1.3 s instead of 0.05 s; worse on a GPU
+    box with 256 hardware threads).  Needs threadpoolctl; without it nothing changes."""
+    if not _BLAS:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _BLAS.append(ThreadpoolController())
+        except Exception:  # noqa: BLE001 -- not installed, or a BLAS it cannot introspect
+            _BLAS.append(None)
+    if _BLAS[0] is None:
+        import contextlib
+        return contextlib.nullcontext()
+    return _BLAS[0].limit(limits=1, user_api='blas')
 
 
 def _embed(U, qs, Q):
@@ -69,6 +87,12 @@ def commute(U1, q1, U2, q2, atol=1e-7):
         return True
     Q = _sorted_union(q1, q2)
     A, B = _embed(U1, q1, Q), _embed(U2, q2, Q)
+    # one row of the commutator first: generic gates that share a qubit fail right here (the verdict is the full
+    # test's: it needs EVERY entry to pass), for O(D^2) instead of two D^3 products -- which the planners otherwise pay
+    # a thousand times per circuit, each a threaded BLAS call on a matrix too small for it
+    r_ab, r_ba = A[0] @ B, B[0] @ A
+    if not (np.abs(r_ab - r_ba) <= atol + 1e-5 * np.abs(r_ba)).all():
+        return False
     AB, BA = A @ B, B @ A
     return bool((np.abs(AB - BA) <= atol + 1e-5 * np.abs(BA)).all())  # np.allclose's test without its bookkeeping
 

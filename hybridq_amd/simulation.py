@@ -528,8 +528,9 @@ BLOCKED_OVERLAP_MS = 1.3  # ... what of the stream does NOT hide behind the gate
 BLOCKED_INNER_MS = {1: 0.38, 2: 0.63, 3: 0.63, 4: 1.20}
 TUNED_PLACEMENT_SEARCH_MS = 2500.0  # what alloc_planes' draw-and-probe search costs (n = 30; measured 2.5 s)
 #: host time of planning one candidate schedule, per matrix gate of the circuit (measured on the benchmark circuits,
-#: n = 16..30: fusion to 4 ~0.04 ms / gate, to 5 ~0.07, the blocked planner ~0.13)
-PLAN_HOST_MS_PER_GATE = {'per_gate': 0.0, 'fused_4': 0.045, 'fused_5': 0.075, 'blocked': 0.13}
+#: n = 16..30: fusion to 4 ~0.04 ms / gate, to 5 ~0.07, the blocked planner ~0.13 at full search effort, ~0.055 with
+#: tries=8 / fusion_orders=1)
+PLAN_HOST_MS_PER_GATE = {'per_gate': 0.0, 'fused_4': 0.045, 'fused_5': 0.075, 'blocked': 0.13, 'blocked_quick': 0.055}
 BLOCKED_VS_FUSED5 = 0.55  # modelled time of the cache-blocked plan over the fused-5 plan (0.45 benchmark circuit, 0.63 dense 3q/4q gates)
 PREDICTION_SLACK = 0.85  # a plan may come out this much better than predicted (commuting gates fuse further)
 LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)
@@ -584,13 +585,18 @@ def choose_schedule(circuit, qubits, n, ctype):
     planned when its PREDICTED device time plus its planning time beats the best plan in hand: the gate-by-gate plan is
     free, the fused ones are predicted from the qubit sets (exact unless gates commute), the cache-blocked one as
     BLOCKED_VS_FUSED5 of the fused-5 prediction.  Short loops (n <~ 24 of the benchmark circuit) therefore run gate by
-    gate at once, n = 26-28 plans fusion to 4 only, n >= 29 the cache-blocked schedule only.  Returns (ops, info)."""
+    gate at once, n = 25 plans fusion to 4 only, n >= 26 the cache-blocked schedule only.  Returns (ops, info)."""
     cands = {'per_gate': dict(compress=0, blocked=False), 'fused_4': dict(compress=4, blocked=False),
              'fused_5': dict(compress=5, blocked=False)}
-    if n >= 14:
-        cands['blocked'] = dict(compress=5, blocked=True)
     n_matrix = sum(1 for g in circuit if not _is_functional(g))
     cost = {name: PLAN_HOST_MS_PER_GATE[name] * n_matrix for name in cands}
+    if n >= 14:
+        # the blocked planner's search effort (visiting orders per pass, fusion orders per pass) buys ~9 % of device time
+        # (n = 30: 139 instead of 151 ms) for 65 ms more host time: worth it from n = 33 on, or when the plan is reused
+        # (an explicit blocked=True, EvolutionState.compile)
+        full = n >= 33
+        cands['blocked'] = dict(compress=5, blocked=True if full else dict(tries=8, fusion_orders=1))
+        cost['blocked'] = (PLAN_HOST_MS_PER_GATE['blocked'] if full else PLAN_HOST_MS_PER_GATE['blocked_quick']) * n_matrix
     plans = {'per_gate': _plan_ops(circuit, qubits, n, ctype, 0, False)}
     est = {'per_gate': estimate_ms(plans['per_gate'], n, ctype)}
     pred = {}
@@ -695,7 +701,9 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     if remove_id_gates:  # simulation.py:289-291 (named identity gates; matrix identities go in simplify)
         circuit = [g for g in circuit if getattr(g, 'name', None) != 'I']
     if simplify:  # simulation.py:293-305
-        circuit = _simplify_runs(circuit, remove_id_gates, atol, simplify if isinstance(simplify, dict) else {})
+        from .fusion import single_thread_blas
+        with single_thread_blas():
+            circuit = _simplify_runs(circuit, remove_id_gates, atol, simplify if isinstance(simplify, dict) else {})
         if not kwargs.get('qubits') and all_qubits(circuit) != qubits:
             raise ValueError("Active qubits have changed after simplification. Forcing stop.")
     if not isinstance(initial_state, str):  # simulation.py:270-281 (a flat vector of 2^n amplitudes is accepted as well)
@@ -711,10 +719,12 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     ctype = np.dtype(complex_type) if np.dtype(complex_type) in _FLOAT_OF else np.dtype('complex64')
     # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519)
     schedule_info = None
-    if auto_schedule:
-        gates, schedule_info = choose_schedule(circuit, qubits, n, ctype)
-    else:
-        gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
+    from .fusion import single_thread_blas
+    with single_thread_blas():  # thousands of tiny matrix products: a threaded BLAS only adds wake-ups
+        if auto_schedule:
+            gates, schedule_info = choose_schedule(circuit, qubits, n, ctype)
+        else:
+            gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
     torch = _torch()
     if _wants_shards(kwargs):
         return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule)
