@@ -217,26 +217,34 @@ def simplify(gates, atol=1e-8, use_matrix_commutation=True, max_n_qubits_matrix=
     list the fusion sees (the reference's ``simulate`` runs this by default, simulation.py:304)."""
     gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
     if remove_id_gates:  # utils.py:841-845
-        gates = [(U, qs) for U, qs in gates
-                 if len(qs) > max_n_qubits_matrix or not np.allclose(U, np.eye(U.shape[0]), atol=atol)]
-    new = []  # in circuit order; gates are inserted from the left
+        eyes = {}
+
+        def is_identity(U):  # np.allclose(U, eye, atol=atol) without its bookkeeping (900 tiny calls per circuit)
+            eye = eyes.get(U.shape[0])
+            if eye is None:
+                eye = eyes[U.shape[0]] = np.eye(U.shape[0])
+            return U.shape == eye.shape and bool((np.abs(U - eye) <= atol + 1e-5 * eye).all())
+
+        gates = [(U, qs) for U, qs in gates if len(qs) > max_n_qubits_matrix or not is_identity(U)]
+    new = []  # in circuit order; gates are inserted from the left.  Entries carry their qubit set: most of the time goes
+    #           into sliding past gates on other qubits, which needs nothing else
     for U, qs in reversed(gates):
-        q = set(qs)
+        q = frozenset(qs)
         placed = False
-        for p, (V, vs) in enumerate(new):
-            if _inverse_of(U, qs, V, vs, atol):  # :182-184
+        for p, (V, vs, vset) in enumerate(new):
+            if vset == q and _inverse_of(U, qs, V, vs, atol):  # :182-184 (an inverse acts on the same qubits)
                 del new[p]
                 placed = True
                 break
             ok = False
             if len(vs) <= max_n_qubits_matrix:  # :192-195
-                ok = not (q & set(vs))
+                ok = not (q & vset)
                 if not ok and use_matrix_commutation:
                     ok = commute(U, qs, V, vs, atol)
             if not ok:  # :199-201
-                new.insert(p, (U, qs))
+                new.insert(p, (U, qs, q))
                 placed = True
                 break
         if not placed:
-            new.append((U, qs))
-    return new
+            new.append((U, qs, q))
+    return [(U, qs) for U, qs, _ in new]
