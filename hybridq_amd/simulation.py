@@ -470,20 +470,25 @@ def _simplify_runs(circuit, remove_id_gates, atol, opts):
     return out
 
 
-def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
-    """Turn a circuit into the op list the gate loop executes: fused ``(qubits, U)`` gates
-    (simulation.py:436-454), or the 'B'/'G' ops of the cache-blocked planner; FunctionalGates are
-    never fused (skip_compression=[FunctionalGate], :441) -- the circuit is cut at them."""
+def _compress_args(compress):
+    """(max_n_qubits, keyword arguments for fusion.fuse) of a `compress` argument, validated: the core applies gates of
+    up to MAX_GATE_QUBITS qubits, and only these keys of the reference's utils.compress have a counterpart in fusion.fuse."""
     comp_kw = {k: v for k, v in compress.items() if k != 'max_n_qubits'} if isinstance(compress, dict) else {}
     comp_n = compress.get('max_n_qubits', 4) if isinstance(compress, dict) else compress
-    # checked BEFORE any planning work: the core applies gates of up to MAX_GATE_QUBITS qubits, and only
-    # these keys of the reference's utils.compress have a counterpart in fusion.fuse
     if comp_n and comp_n > MAX_GATE_QUBITS:
         raise ValueError(f"compress={comp_n}: fused gates are limited to {MAX_GATE_QUBITS} qubits by the HIP core")
     unknown = set(comp_kw) - {'use_matrix_commutation', 'max_n_qubits_matrix', 'atol', 'exclude_qubits'}
     if unknown:
         raise ValueError(f"unsupported 'compress' option(s) {sorted(unknown)}: FunctionalGates are never compressed "
                          "here (the reference's skip_compression default), other skip lists have no counterpart")
+    return comp_n, comp_kw
+
+
+def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
+    """Turn a circuit into the op list the gate loop executes: fused ``(qubits, U)`` gates
+    (simulation.py:436-454), or the 'B'/'G' ops of the cache-blocked planner; FunctionalGates are
+    never fused (skip_compression=[FunctionalGate], :441) -- the circuit is cut at them."""
+    comp_n, comp_kw = _compress_args(compress)
     use_blocked = bool(blocked) and n >= 14
     pos_of = {q: n - x - 1 for x, q in enumerate(qubits)}  # simulation.py:512 (never permuted here)
     gates, run = [], []
@@ -720,14 +725,16 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     # Compress circuit (simulation.py:436-454); untimed, like in the reference (:519)
     schedule_info = None
     from .fusion import single_thread_blas
+    _compress_args(kwargs['compress'])  # argument checks, before anything else
+    if _wants_shards(kwargs):  # the sharded driver plans for its own local qubit count
+        _torch()
+        return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule)
     with single_thread_blas():  # thousands of tiny matrix products: a threaded BLAS only adds wake-ups
         if auto_schedule:
             gates, schedule_info = choose_schedule(circuit, qubits, n, ctype)
         else:
             gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
-    torch = _torch()
-    if _wants_shards(kwargs):
-        return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule)
+    _torch()
     # Placement of the state: the tuned (VMM draw-and-probe) placement speeds the streaming kernels up by ~10 % but
     # the search itself costs ~2.5 s at n = 30 (8 draws): only worth it when the modelled loop is long enough to
     # win that back; the cache-blocked passes prefer the plain allocator anyway (prepare_state_planes).
@@ -796,7 +803,9 @@ def _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_sch
                           backend=HipBackend(_FLOAT_OF[np.dtype(ctype)], placement='plain'))
     # auto schedule: cache-blocked local passes between the exchanges (2.7x the fused stream on one GPU)
     blocked = kwargs.get('blocked', bool(auto_schedule) and sh.m >= 14)
-    sched = sh.plan(gates, compress=comp_n or 0, blocked=blocked)
+    from .fusion import single_thread_blas
+    with single_thread_blas():
+        sched = sh.plan(gates, compress=comp_n or 0, blocked=blocked)
     info = {}
     if auto_schedule:
         info['schedule'] = {'chosen': 'blocked' if blocked else f'fused_{comp_n or 0}', 'local_qubits': sh.m}

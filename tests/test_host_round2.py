@@ -282,3 +282,13 @@ def test_simulate_argument_errors_precede_device_work():
         simulate(gates, initial_state='0', qubits=q, max_largest_intermediate=2**11)
     with pytest.raises(ValueError, match="only implements optimize='evolution'"):
         simulate(gates, initial_state='0', optimize='tn')
+
+
+def test_simulate_checks_compress_before_the_device():
+    from hybridq_amd.circuits import rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    g = rqc_1q2q(12, depth=2, seed=1)
+    with pytest.raises(ValueError, match='limited to 10 qubits'):
+        simulate(g, initial_state='0', qubits=list(range(12)), compress=11)
+    with pytest.raises(ValueError, match='skip_compression'):
+        simulate(g, initial_state='0', qubits=list(range(12)), compress={'max_n_qubits': 4, 'skip_compression': ['X']})
