@@ -308,17 +308,28 @@ class EvolutionState:
             self.planes = prepare_state_planes(initial_state, self.n, self.float_type, self.device, placement)
 
     @property
+    def planes(self):
+        return self._planes
+
+    @planes.setter
+    def planes(self, value):
+        # the two plane views are made once: indexing the (2, 2^n) tensor anew for every gate costs ~5 us of the ~11 us a
+        # Python-level apply_U call takes, which is what bounds the loop below n ~ 22
+        self._planes = value
+        self._re, self._im = value[0], value[1]
+
+    @property
     def re(self):
-        return self.planes[0]
+        return self._re
 
     @property
     def im(self):
-        return self.planes[1]
+        return self._im
 
     def apply(self, U, qubits):
         core.use_torch_stream()
         pos = [self.map[q] for q in reversed(qubits)]  # simulation.py:633
-        core.apply_U(self.planes[0], self.planes[1], U, pos, self.n)
+        core.apply_U(self._re, self._im, U, pos, self.n)
 
     def apply_functional(self, gate):
         """FunctionalGate branch of the loop (simulation.py:525-554): the gate receives the raw
@@ -633,9 +644,9 @@ def _execute_ops(state, gates):
         elif isinstance(g[0], str):  # ops of the blocked planner, positions already physical
             n_passes += 1
             if g[0] == 'B':
-                core.apply_blocked(state.planes[0], state.planes[1], g[1], g[2], n)
+                core.apply_blocked(state.re, state.im, g[1], g[2], n)
             else:
-                core.apply_U(state.planes[0], state.planes[1], g[1], g[2], n)
+                core.apply_U(state.re, state.im, g[1], g[2], n)
         else:
             n_passes += 1
             state.apply(g[1], g[0])
