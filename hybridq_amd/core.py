@@ -270,9 +270,15 @@ def _ptr(x):
     raise TypeError(f'cannot take the address of {type(x)}')
 
 
+_TORCH_DTYPES = {}
+
+
 def _float_dtype(x):
     if hasattr(x, 'data_ptr'):  # torch tensor
-        return np.dtype(str(x.dtype).replace('torch.', ''))
+        dt = _TORCH_DTYPES.get(x.dtype)
+        if dt is None:
+            dt = _TORCH_DTYPES[x.dtype] = np.dtype(str(x.dtype).replace('torch.', ''))
+        return dt
     return np.dtype(x.dtype)
 
 
@@ -291,12 +297,12 @@ def apply_U(psi_re, psi_im, U, pos, n_qubits=None):
     ft = _float_dtype(psi_re)
     ctype = np.dtype('complex64') if ft == np.dtype('float32') else np.dtype('complex128')
     U = np.ascontiguousarray(U, dtype=ctype)
-    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    k = len(pos)
     n = _n_qubits(psi_re) if n_qubits is None else int(n_qubits)
-    if U.size != 4**len(pos):
+    if U.size != 4**k:
         raise ValueError("'U' and 'pos' are incompatible")
-    rc = _dot_core[ft](_ptr(psi_re), _ptr(psi_im), U.ctypes.data,
-                       pos.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n, len(pos))
+    # a ctypes array built from the k integers: 0.25 us against 2 us for a numpy array plus .ctypes.data_as()
+    rc = _dot_core[ft](_ptr(psi_re), _ptr(psi_im), U.ctypes.data, (ctypes.c_uint32 * k)(*pos), n, k)
     _check(rc, 'apply_U')
 
 

@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -70,3 +71,25 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt, f
                 assert 'libhq_oracle' not in txt and '_ref/' not in txt, f
+
+
+def test_apply_U_argument_marshalling_without_a_device():
+    """core.apply_U hands `pos` over as a ctypes array built from the integers; the library validates the positions before
+    it touches a device, so the marshalling can be checked on a box without a GPU: bad positions are named as such, good
+    ones get past that check (and then fail on something else here -- alignment or the missing device)."""
+    import numpy as np
+    from hybridq_amd import core
+    U = np.eye(4, dtype=np.complex64)
+    pre, pim = np.zeros(1024, np.float32), np.zeros(1024, np.float32)
+    for pos in ([3, 50], [3, 3], np.array([10, 2]), (np.uint32(1), np.int64(99))):
+        with pytest.raises(core.HQError, match='invalid positions'):
+            core.apply_U(pre, pim, U, pos, 10)
+    for pos in ([3, 5], np.array([0, 9], dtype=np.uint32), (np.int64(4), 7)):
+        try:
+            core.apply_U(pre, pim, U, pos, 10)
+        except core.HQError as e:
+            assert 'invalid positions' not in str(e)
+    with pytest.raises(ValueError, match='incompatible'):
+        core.apply_U(pre, pim, U, [1, 2, 3], 10)
+    with pytest.raises(TypeError):
+        core.apply_U(pre, pim, U, [1.5, 2], 10)
