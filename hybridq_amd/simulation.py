@@ -637,19 +637,21 @@ def _execute_ops(state, gates):
     """The gate loop (simulation.py:522-646); returns the number of passes over the state."""
     n = state.n
     n_passes = 0
-    core.use_torch_stream()
+    core.use_torch_stream()  # once: nothing in the loop but a FunctionalGate (user code) can change torch's current stream
+    re, im, qmap, apply_U = state.re, state.im, state.map, core.apply_U
     for g in gates:
         if _is_functional(g):
             state.apply_functional(g)
+            core.use_torch_stream()
         elif isinstance(g[0], str):  # ops of the blocked planner, positions already physical
             n_passes += 1
             if g[0] == 'B':
-                core.apply_blocked(state.re, state.im, g[1], g[2], n)
+                core.apply_blocked(re, im, g[1], g[2], n)
             else:
-                core.apply_U(state.re, state.im, g[1], g[2], n)
+                apply_U(re, im, g[1], g[2], n)
         else:
             n_passes += 1
-            state.apply(g[1], g[0])
+            apply_U(re, im, g[1], [qmap[q] for q in reversed(g[0])], n)  # simulation.py:633
     return n_passes
 
 

@@ -292,3 +292,29 @@ def test_simulate_checks_compress_before_the_device():
         simulate(g, initial_state='0', qubits=list(range(12)), compress=11)
     with pytest.raises(ValueError, match='skip_compression'):
         simulate(g, initial_state='0', qubits=list(range(12)), compress={'max_n_qubits': 4, 'skip_compression': ['X']})
+
+
+def test_gate_loop_positions_and_stream_binding(monkeypatch):
+    """_execute_ops: matrix gates go to apply_U with pos = reversed(gate qubits) mapped to physical positions
+    (reference simulation.py:633), planner ops with their positions as they are; torch's stream is bound once, and again
+    after every FunctionalGate (user code)."""
+    import hybridq_amd.simulation as sim
+    calls, binds = [], []
+    monkeypatch.setattr(sim.core, 'apply_U', lambda re, im, U, pos, n: calls.append(('U', re, im, U, list(pos), n)))
+    monkeypatch.setattr(sim.core, 'apply_blocked', lambda re, im, tile, inner, n: calls.append(('B', re, im, list(tile), n)))
+    monkeypatch.setattr(sim.core, 'use_torch_stream', lambda: binds.append(len(calls)))
+
+    class State:
+        n = 5
+        re, im = 're', 'im'
+        map = {q: 4 - x for x, q in enumerate('abcde')}
+
+        def apply_functional(self, g):
+            calls.append(('F', g.name))
+
+    fn = sim.FunctionalGate(('a',), lambda psi, order: (psi, order), name='probe')
+    ops = [(('a', 'c'), 'U0'), fn, (('e',), 'U1'), ('B', [0, 1, 2], [('V', [1])]), ('G', 'U2', [3, 0])]
+    assert sim._execute_ops(State(), ops) == 4
+    assert calls == [('U', 're', 'im', 'U0', [2, 4], 5), ('F', 'probe'), ('U', 're', 'im', 'U1', [0], 5),
+                     ('B', 're', 'im', [0, 1, 2], 5), ('U', 're', 'im', 'U2', [3, 0], 5)]
+    assert binds == [0, 2]
