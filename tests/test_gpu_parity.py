@@ -452,7 +452,7 @@ def test_simulate_functional_gate_branch(torch_cuda, oracle_port):
 
     g1, g2 = random_dense(n, 30, kmax=3, seed=1, unitary=True), random_dense(n, 30, kmax=3, seed=2, unitary=True)
     circuit = list(g1) + [FunctionalGate((3,), project_q3_to_1)] + list(g2)
-    psi, info = simulate(circuit, initial_state='+' * n, complex_type='complex128', return_info=True)
+    psi, info = simulate(circuit, initial_state='+' * n, complex_type='complex128', return_info=True, compress=4)
     assert seen['shape'] == (2,) + (2,) * n and seen['order'] == tuple(range(n))
     a = oracle.evolve_tensordot(g1, n, initial_state=np.full(1 << n, 2.0**(-n / 2)), qubits=list(range(n)))
     a = a.reshape((2,) * n).copy()
@@ -663,7 +663,7 @@ def test_apply_blocked_matches_gate_by_gate(torch_cuda, oracle_port, ft):
         core.apply_blocked(dre, dim_, np.arange(12), [(np.eye(2), [15])])  # target outside the tile
 
 
-def test_simulate_blocked_matches_oracle(torch_cuda, oracle_port):
+def test_simulate_blocked_matches_oracle(torch_cuda, oracle_port, monkeypatch):
     """simulate(blocked=True): the cache-blocked schedule (many gates per LDS-tile pass, inner
     fusion) gives the same state as gate-by-gate evolution; far fewer passes than gates."""
     import oracle
@@ -685,7 +685,10 @@ def test_simulate_blocked_matches_oracle(torch_cuda, oracle_port):
             err = np.abs(psi.reshape(-1) - exp).max() / np.abs(exp).max()
             assert err < circuit_tol(gates), (n, opts, err)
             assert info['n_passes'] < len(gates) / 2.5
-    # optimize='evolution-hip' = the same path with blocked=True / compress=5 as defaults
+    # optimize='evolution-hip' = the cost model's own choice; with planning priced at nothing (a loop this short would not
+    # win any planning time back and run gate by gate) it takes the fused / cache-blocked schedules
+    from hybridq_amd import simulation
+    monkeypatch.setattr(simulation, 'PLAN_HOST_MS_PER_GATE', dict.fromkeys(simulation.PLAN_HOST_MS_PER_GATE, 0.0))
     for n in (12, 18):
         g = rqc_1q2q(n, depth=10, seed=11) + random_dense(n, 6, kmax=5, seed=12)
         psi, info = simulate(g, initial_state='0' * n, optimize='evolution-hip', return_info=True, qubits=list(range(n)))
