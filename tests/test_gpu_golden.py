@@ -69,8 +69,11 @@ def test_simple_qasm_trace_and_circuit(torch_cuda):
     assert np.abs(psi[::stride] - z['psi_sample']).max() / scale < tol
     assert np.abs(psi[:8] - z['psi_head']).max() / scale < tol
     gates = gu.simple_qasm_gates(z)
-    psi2 = simulate(gates, initial_state='0' * n, complex_type='complex64').reshape(-1)
+    psi2 = simulate(gates, initial_state='0' * n, complex_type='complex64', compress=4).reshape(-1)  # the reference's schedule
     assert np.abs(psi2[::stride] - z['psi_sample']).max() / scale < tol
+    # the schedule simulate() picks by itself (99 gates at n = 24: gate by gate) against the reference's 13 fused calls
+    psi3 = simulate(gates, initial_state='0' * n, complex_type='complex64').reshape(-1)
+    assert np.abs(psi3[::stride] - z['psi_sample']).max() / scale < circuit_tol(gates, calls, c=C_STRUCTURED)
     # |<psi|psi> - 1| <= 2 x the state's own rounding bound (first order in the error)
     assert abs(float(np.vdot(psi2.astype(np.complex128), psi2.astype(np.complex128)).real) - 1.0) < 2 * circuit_tol(calls)
 
