@@ -1,0 +1,146 @@
+"""The host side of ``simulate()`` end to end on a box without a GPU: argument handling, container / stochastic gates,
+simplification, schedule choice, fusion, the cache-blocked planner and the gate loop's position arithmetic run for real;
+only the device is replaced -- by a TEST DOUBLE that keeps the state in numpy and applies every ``apply_U`` /
+``apply_blocked`` call with the oracle's index arithmetic (oracle.evolution.apply_gate_numpy).  What is checked is that
+the calls the driver ISSUES evolve the state like an independent float64 evolution of the circuit as given.  The product
+itself has no such path: without the HIP library's device ``simulate()`` raises (tests/test_abi.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class _Planes:
+    """Stands for one plane tensor; both planes of a state share the owner."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+
+@pytest.fixture
+def numpy_device(monkeypatch):
+    import oracle
+    from oracle.evolution import _initial, apply_gate_numpy
+    import hybridq_amd.simulation as sim
+    log = {'apply_U': 0, 'apply_blocked': 0, 'states': 0}
+
+    class State:
+        def __init__(self, qubits, complex_type='complex64', initial_state=None, device=None, placement='plain'):
+            self.qubits, self.n = list(qubits), len(qubits)
+            self.complex_type = np.dtype(complex_type)
+            self.map = {q: self.n - x - 1 for x, q in enumerate(self.qubits)}
+            self.psi = _initial(initial_state, self.n, np.complex128)  # the double keeps float64: only the calls are on trial
+            self.re = self.im = _Planes(self)
+            log['states'] += 1
+
+        def apply_functional(self, gate):
+            order = tuple(self.qubits)
+            host = np.stack([self.psi.real, self.psi.imag]).reshape((2,) + (2,) * self.n)
+            new_psi, new_order = gate.apply(psi=host, order=order)
+            assert tuple(new_order) == order
+            new_psi = np.asarray(new_psi).reshape(2, -1)
+            self.psi = new_psi[0] + 1j * new_psi[1]
+
+        def to_numpy(self):
+            return self.psi.astype(self.complex_type)
+
+    def apply_U(re, im, U, pos, n):
+        st = re.owner
+        assert im.owner is st and n == st.n and len(set(int(p) for p in pos)) == len(pos) and all(0 <= int(p) < n for p in pos)
+        st.psi = apply_gate_numpy(st.psi, np.asarray(U, dtype=np.complex128), [int(p) for p in pos])
+        log['apply_U'] += 1
+
+    def apply_blocked(re, im, tile_pos, gates, n):
+        tile = set(int(p) for p in tile_pos)
+        assert len(tile) == len(tile_pos) and list(tile_pos) == sorted(tile)
+        for U, pos in gates:
+            assert set(int(p) for p in pos) <= tile and 1 <= len(pos) <= 4  # what hq_apply_blocked_* demands
+            apply_U(re, im, U, pos, n)
+            log['apply_U'] -= 1
+        log['apply_blocked'] += 1
+
+    monkeypatch.setattr(sim, 'EvolutionState', State)
+    monkeypatch.setattr(sim, '_torch', lambda: None)
+    monkeypatch.setattr(sim.core, 'apply_U', apply_U)
+    monkeypatch.setattr(sim.core, 'apply_blocked', apply_blocked)
+    monkeypatch.setattr(sim.core, 'use_torch_stream', lambda: None)
+    monkeypatch.setattr(sim.core, 'sync', lambda: None)
+    return log, oracle
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize('kw', [dict(compress=0), dict(compress=4), dict(compress=6), dict(blocked=True),
+                                dict(blocked={'tile_bits': 12, 'low_bits': 4, 'inner_max': 4}), dict(optimize='evolution-hip'),
+                                dict(optimize='evolution-hybridq'), dict(compress={'max_n_qubits': 3, 'exclude_qubits': [0, 5]})],
+                         ids=lambda kw: '-'.join(f'{k}={v}' for k, v in kw.items())[:40])
+def test_issued_calls_evolve_the_state(numpy_device, kw):
+    log, oracle = numpy_device
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    from hybridq_amd.simulation import simulate
+    n = 16
+    for gates, init in ((rqc_1q2q(n, depth=12, seed=3), '0' * n), (random_dense(n, 60, kmax=4, seed=4, unitary=True), '01+-' * 4)):
+        psi, info = simulate(gates, initial_state=init, complex_type='complex128', qubits=list(range(n)), return_info=True, **kw)
+        exp = oracle.evolve_tensordot(gates, n, initial_state=init, qubits=list(range(n)))
+        assert psi.shape == (2,) * n and _rel(psi.reshape(-1), exp) < 1e-12, kw
+        assert info['n_gates_given'] == len(gates) and info['n_qubits'] == n and info['n_passes'] <= len(gates)
+        if kw.get('blocked'):
+            assert log['apply_blocked'] > 0 and info['n_passes'] < len(gates) / 2
+        if kw.get('compress') == 0:
+            assert info['n_passes'] == len(gates)
+
+
+def test_labels_functional_and_container_gates(numpy_device):
+    """Heterogeneous qubit labels (sorted like Circuit.all_qubits), a FunctionalGate between fused runs, container gates,
+    an array as initial state."""
+    log, oracle = numpy_device
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.simulation import FunctionalGate, simulate
+    n = 10
+    labels = ['q%d' % i for i in range(5)] + [(0, i) for i in range(5)]
+    base = random_dense(n, 50, kmax=3, seed=9, unitary=True)
+    gates = [(U, tuple(labels[q] for q in qs)) for U, qs in base]
+    from hybridq_amd.simulation import all_qubits
+    order = all_qubits(gates)
+    assert sorted(map(str, order)) == sorted(map(str, labels))
+    index = {q: i for i, q in enumerate(order)}
+    as_int = [(U, tuple(index[q] for q in qs)) for U, qs in gates]
+    rng = np.random.default_rng(1)
+    psi0 = rng.standard_normal((2,) * n) + 1j * rng.standard_normal((2,) * n)
+    psi0 /= np.linalg.norm(psi0.ravel())
+    seen = []
+
+    def negate_where_first_is_one(psi, order):
+        seen.append(order)
+        out = psi.copy()
+        ax = order.index(order[0]) + 1
+        idx = [slice(None)] * psi.ndim
+        idx[ax] = 1
+        out[tuple(idx)] *= -1
+        return out, order
+
+    class Tup:  # the reference's TupleGate duck-typed (a list subclass would read as a (U, qubits) pair)
+        def __init__(self, gates):
+            self.gates = list(gates)
+
+        def __iter__(self):
+            return iter(self.gates)
+
+        def flatten(self):
+            return self
+
+    fn = FunctionalGate((order[0],), negate_where_first_is_one)
+    circuit = [Tup(gates[:10]), Tup([Tup(gates[10:20]), gates[20]])] + gates[21:30] + [fn] + gates[30:]
+    psi = simulate(circuit, initial_state=psi0, complex_type='complex128', compress=4)
+    assert seen == [tuple(order)]
+    a = oracle.evolve_tensordot(as_int[:30], n, initial_state=psi0.reshape(-1), qubits=list(range(n))).reshape((2,) * n).copy()
+    a[1] *= -1
+    exp = oracle.evolve_tensordot(as_int[30:], n, initial_state=a.reshape(-1), qubits=list(range(n)))
+    assert _rel(psi.reshape(-1), exp) < 1e-12
