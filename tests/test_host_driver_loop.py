@@ -36,6 +36,8 @@ def numpy_device(monkeypatch):
             self.map = {q: self.n - x - 1 for x, q in enumerate(self.qubits)}
             self.psi = _initial(initial_state, self.n, np.complex128)  # the double keeps float64: only the calls are on trial
             self.re = self.im = _Planes(self)
+            self.planes = [self.re, self.im]
+            self.device = None
             log['states'] += 1
 
         def apply_functional(self, gate):
@@ -70,6 +72,7 @@ def numpy_device(monkeypatch):
     monkeypatch.setattr(sim.core, 'apply_blocked', apply_blocked)
     monkeypatch.setattr(sim.core, 'use_torch_stream', lambda: None)
     monkeypatch.setattr(sim.core, 'sync', lambda: None)
+    monkeypatch.setattr(sim.core, 'vdot', lambda are, aim, bre, bim: complex(np.vdot(are.owner.psi, bre.owner.psi)))
     return log, oracle
 
 
@@ -144,3 +147,69 @@ def test_labels_functional_and_container_gates(numpy_device):
     a[1] *= -1
     exp = oracle.evolve_tensordot(as_int[30:], n, initial_state=a.reshape(-1), qubits=list(range(n)))
     assert _rel(psi.reshape(-1), exp) < 1e-12
+
+
+def test_density_matrix_front_end(numpy_device):
+    """dm.simulate: unitary gates act as U (x) conj(U) on the (0, q) / (1, q) copies, channels as one superoperator gate;
+    against rho -> sum_i s_i K_i rho K_i^dagger carried out on the 2^n x 2^n matrix in numpy."""
+    log, oracle = numpy_device
+    from hybridq_amd import dm
+    from hybridq_amd.circuits import random_dense
+    n = 5
+    rng = np.random.default_rng(2)
+    gates = random_dense(n, 24, kmax=2, seed=21, unitary=True)
+    circuit, rho_ops = [], []
+    for i, (U, qs) in enumerate(gates):
+        circuit.append((U, qs))
+        rho_ops.append(('U', U, qs))
+        if i % 6 == 5:
+            qs2 = tuple(int(q) for q in rng.permutation(n)[:2])
+            ch = dm.depolarizing(qs2, 0.1 + 0.05 * (i // 6))
+            circuit.append(ch)
+            rho_ops.append(('K', ch, qs2))
+    init = '01+-0'
+
+    psi0 = oracle.evolution._initial(init, n, np.complex128)
+    rho = np.outer(psi0, psi0.conj())
+    for kind, op, qs in rho_ops:
+        if kind == 'U':
+            F = _full(op, qs, n)
+            rho = F @ rho @ F.conj().T
+        else:
+            rho = sum(s * (_full(L, qs, n) @ rho @ _full(L, qs, n).conj().T) for s, L in zip(op.s, op.left))
+    for kw in (dict(compress=4), dict(compress=0), dict(blocked=True), {}):
+        got = dm.simulate(circuit, initial_state=init, complex_type='complex128', **kw)
+        assert got.shape == (2,) * (2 * n)
+        assert _rel(got.reshape(1 << n, 1 << n), rho) < 1e-12, kw
+    assert abs(np.trace(rho) - 1) < 1e-12
+
+
+def _full(M, qs, n):
+    """Dense 2^n x 2^n matrix of gate (M, qs): columns = images of the basis states under an independent evolution."""
+    k = len(qs)
+    Mt = np.asarray(M, dtype=np.complex128).reshape((2,) * (2 * k))
+    eye = np.eye(1 << n, dtype=np.complex128).reshape((2,) * n + (1 << n,))
+    out = np.moveaxis(np.tensordot(Mt, eye, axes=(list(range(k, 2 * k)), list(qs))), list(range(k)), list(qs))
+    return out.reshape(1 << n, 1 << n)
+
+
+def test_expectation_value(numpy_device):
+    """expectation_value(state, op) = <state| op |state> with the qubits mapped to the axes of `state` in sorted order."""
+    log, oracle = numpy_device
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.simulation import expectation_value
+    n = 8
+    rng = np.random.default_rng(5)
+    state = rng.standard_normal((2,) * n) + 1j * rng.standard_normal((2,) * n)
+    state /= np.linalg.norm(state.ravel())
+    op = random_dense(n, 6, kmax=2, seed=6)  # non-unitary: the value is complex
+    exp = np.vdot(state.reshape(-1), oracle.evolve_tensordot(op, n, initial_state=state.reshape(-1), qubits=list(range(n))))
+    got = expectation_value(state, op, qubits_order=list(range(n)), complex_type='complex128')
+    assert abs(got - exp) < 1e-12
+    herm = [(np.diag([1.0, -1.0]), (3,))]
+    val = expectation_value(state, herm, qubits_order=list(range(n)), complex_type='complex128')
+    assert isinstance(val, float) or abs(complex(val).imag) == 0
+    z = state.reshape((2,) * n)
+    assert abs(val - (np.sum(np.abs(np.take(z, 0, axis=3))**2) - np.sum(np.abs(np.take(z, 1, axis=3))**2))) < 1e-12
+    with pytest.raises(ValueError):
+        expectation_value(state, [(np.eye(2), (n + 3,))], qubits_order=list(range(n)))
