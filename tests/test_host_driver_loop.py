@@ -41,6 +41,9 @@ def numpy_device(monkeypatch):
             log['states'] += 1
 
         def apply_functional(self, gate):
+            if callable(getattr(gate, 'apply_device', None)):  # as EvolutionState.apply_functional does
+                gate.apply_device(self)
+                return
             order = tuple(self.qubits)
             host = np.stack([self.psi.real, self.psi.imag]).reshape((2,) + (2,) * self.n)
             new_psi, new_order = gate.apply(psi=host, order=order)
@@ -73,6 +76,26 @@ def numpy_device(monkeypatch):
     monkeypatch.setattr(sim.core, 'use_torch_stream', lambda: None)
     monkeypatch.setattr(sim.core, 'sync', lambda: None)
     monkeypatch.setattr(sim.core, 'vdot', lambda are, aim, bre, bim: complex(np.vdot(are.owner.psi, bre.owner.psi)))
+
+    def _outcome_index(st, pos):  # outcome bit j <-> index bit pos[j]
+        idx = np.arange(1 << st.n)
+        out = np.zeros_like(idx)
+        for j, p in enumerate(pos):
+            out |= ((idx >> int(p)) & 1) << j
+        return out
+
+    def probabilities(re, im, pos, n):
+        st = re.owner
+        assert len(pos) <= 10  # the marginal kernel's limit
+        return np.bincount(_outcome_index(st, pos), weights=np.abs(st.psi)**2, minlength=1 << len(pos))
+
+    def project(re, im, pos, state, scale=1.0, n=None):
+        st = re.owner
+        st.psi = np.where(_outcome_index(st, pos) == int(state), st.psi * scale, 0)
+
+    monkeypatch.setattr(sim.core, 'probabilities', probabilities)
+    monkeypatch.setattr(sim.core, 'project', project)
+    monkeypatch.setattr(sim.core, 'norm2', lambda re, im: float(np.sum(np.abs(re.owner.psi)**2)))
     return log, oracle
 
 
@@ -213,3 +236,51 @@ def test_expectation_value(numpy_device):
     assert abs(val - (np.sum(np.abs(np.take(z, 0, axis=3))**2) - np.sum(np.abs(np.take(z, 1, axis=3))**2))) < 1e-12
     with pytest.raises(ValueError):
         expectation_value(state, [(np.eye(2), (n + 3,))], qubits_order=list(range(n)))
+
+
+def test_device_functional_gates_in_the_loop(numpy_device):
+    """functional.Projection / Measure inside simulate(): bit conventions (qubits[0] = most significant outcome bit),
+    renormalisation, the "nothing survives" case, and a measurement of more qubits than the marginal kernel tabulates
+    (chunk by chunk: the joint law of one draw)."""
+    log, oracle = numpy_device
+    from hybridq_amd.circuits import random_dense
+    from hybridq_amd.functional import Measure, Projection
+    from hybridq_amd.simulation import simulate
+    n = 14
+    g1, g2 = random_dense(n, 40, kmax=2, seed=31, unitary=True), random_dense(n, 20, kmax=2, seed=32, unitary=True)
+    q = list(range(n))
+    mid = oracle.evolve_tensordot(g1, n, qubits=q).reshape((2,) * n)
+
+    def collapse(psi, qubits, bits, renorm=True):
+        out = np.zeros_like(psi)
+        idx = [slice(None)] * n
+        for qq, b in zip(qubits, bits):
+            idx[qq] = int(b)
+        out[tuple(idx)] = psi[tuple(idx)]
+        return out / np.linalg.norm(out.ravel()) if renorm else out
+
+    for qs, bits, renorm in (((3, 0, 9), '101', True), ((5,), '0', False), (tuple(range(12)), '011010011101', True)):
+        psi = simulate(g1 + [Projection(bits, qs, renormalize=renorm)] + g2, initial_state='0' * n, complex_type='complex128',
+                       qubits=q, compress=4)
+        exp = oracle.evolve_tensordot(g2, n, initial_state=collapse(mid, qs, bits, renorm).reshape(-1), qubits=q)
+        assert _rel(psi.reshape(-1), exp) < 1e-12, (qs, bits)
+    # nothing survives: '1' on a qubit that is still |0>
+    only_q0 = [(U, qs) for U, qs in g1 if 7 not in qs][:10]
+    psi = simulate(only_q0 + [Projection('1', (7,))], initial_state='0' * n, complex_type='complex128', qubits=q, compress=0)
+    assert not psi.any()
+    for qs in ((2, 11, 4), tuple(range(1, 13))):  # 3 qubits: one draw; 12 qubits: two chunks
+        m = Measure(qs, rng=np.random.default_rng(len(qs)))
+        psi = simulate(g1 + [m] + g2, initial_state='0' * n, complex_type='complex128', qubits=q, compress=4)
+        bits = format(m.outcome, '0%db' % len(qs))  # qubits[0] = most significant bit of the outcome
+        exp = oracle.evolve_tensordot(g2, n, initial_state=collapse(mid, qs, bits).reshape(-1), qubits=q)
+        assert _rel(psi.reshape(-1), exp) < 1e-12, qs
+        assert abs(np.linalg.norm(psi.ravel()) - 1) < 1e-12
+    # the sampled law: outcome frequencies of a 2-qubit measurement follow the marginal
+    counts = np.zeros(4)
+    rng = np.random.default_rng(0)
+    marg = np.array([np.sum(np.abs(np.take(np.take(mid, a, axis=6), b, axis=1))**2) for a in (0, 1) for b in (0, 1)])  # qubits (6, 1)
+    for _ in range(300):
+        m = Measure((6, 1), rng=rng)
+        simulate(g1 + [m], initial_state='0' * n, complex_type='complex128', qubits=q, compress=0, return_numpy_array=False)
+        counts[m.outcome] += 1
+    assert np.abs(counts / 300 - marg).max() < 0.1
