@@ -113,6 +113,11 @@ def numpy_device(monkeypatch):
         def to_numpy(self):
             return self.psi.astype(self.complex_type)
 
+        def to_complex(self):  # EvolutionState.to_complex returns a device tensor: .cpu().numpy() gives the amplitudes
+            arr = self.psi.astype(self.complex_type)
+            from types import SimpleNamespace
+            return SimpleNamespace(cpu=lambda: SimpleNamespace(numpy=lambda: arr))
+
     def apply_U(re, im, U, pos, n):
         st = re.owner
         assert im.owner is st and n == st.n and len(set(int(p) for p in pos)) == len(pos) and all(0 <= int(p) < n for p in pos)
