@@ -29,6 +29,8 @@ What is recorded
   e2e_api.npz         host-level API around the path (python make_golden.py api): prepare_state,
                       simulate() with mixed initial states / compress 4 and 8, Projection and
                       Measure gates, expectation_value(), utils.dot(), utils.transpose().
+  e2e_containers.npz  TupleGate / StochasticGate (allow_sampling, sampling_seed) / zero-qubit MessageGate circuits through
+                      the reference's simulate() (python make_golden.py containers).
   e2e_matrix.npz      utils.matrix / compress / to_matrix_gate on small circuits (python make_golden.py matrix).
 The import of the reference Python needs stand-ins for three absent third-party modules
 (opt_einsum, more_itertools, numba); none of them is on the evolution-hybridq path except
@@ -498,6 +500,68 @@ def matrix_vectors():
     print('e2e_matrix.npz:', {k: v.shape for k, v in out.items() if k.endswith('matrix')})
 
 
+def container_vectors():
+    """e2e_containers.npz (python make_golden.py containers): the reference's simulate() on circuits holding container
+    gates -- TupleGate chunks (tests.py:1942-1977), a StochasticGate drawn with allow_sampling / sampling_seed
+    (tests.py:2111-2197, simulation.py:241-256) and zero-qubit MessageGates (tests.py:1980-2034) -- as data: every
+    gate's matrix and qubits, the probabilities, the seeds, and the final states the reference returned."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    import io
+    import hybridq.circuit.simulation.simulation as sim
+    from hybridq.circuit import Circuit
+    from hybridq.circuit.simulation import simulate
+    from hybridq.extras.gate import Gate as ExtraGate
+    from hybridq.extras.random import get_rqc
+    from hybridq.gate import Gate
+    assert sim._log2_pack_size == 3, 'reference core not found: set LD_LIBRARY_PATH=oracle/_ref'
+    out = {}
+    np.random.seed(77)
+    n = 12
+
+    def dump(c, tag):
+        out[f'{tag}_n_gates'] = len(c)
+        for i, g in enumerate(c):
+            out[f'{tag}_U{i}'] = np.asarray(g.matrix(), dtype=np.complex128)
+            out[f'{tag}_q{i}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+
+    c = get_rqc(n, 80, use_random_indexes=False, use_unitary_only=False)
+    assert c.all_qubits() == list(range(n))
+    init = ''.join(np.random.choice(list('01+-'), size=n))
+    out['init'] = np.array(init)
+    dump(c, 'tup')
+    gs = list(c)
+    chunks = Circuit(Gate('TUPLE', gates=gs[i:i + 4]) for i in range(0, len(gs), 4))
+    whole = Circuit([Gate('TUPLE', gates=gs)])
+    psi = simulate(c, initial_state=init, optimize='evolution', complex_type='complex128', compress=0, simplify=False)
+    psi_chunks = simulate(chunks, initial_state=init, optimize='evolution', complex_type='complex128', compress=0, simplify=False)
+    psi_whole = simulate(whole, initial_state=init, optimize='evolution', complex_type='complex128', compress=0, simplify=False)
+    assert np.array_equal(psi, psi_chunks) and np.array_equal(psi, psi_whole)
+    out['tup_psi'] = np.asarray(psi).reshape(-1)
+    # stochastic gate between the two halves of the circuit
+    cand = get_rqc(n, 8, use_random_indexes=False, use_unitary_only=False)
+    prob = np.random.random(len(cand))
+    prob /= prob.sum()
+    dump(cand, 'stoc')
+    out['stoc_p'] = prob
+    stoc = Gate('STOC', gates=list(cand), p=prob)
+    seeds = [3, 11, 12345]
+    out['stoc_seeds'] = np.asarray(seeds)
+    for s_ in seeds:
+        r = simulate(Circuit(gs[:40]) + [stoc] + Circuit(gs[40:]), initial_state=init, optimize='evolution', complex_type='complex128',
+                     compress=0, simplify=False, allow_sampling=True, sampling_seed=s_)
+        out[f'stoc_psi_{s_}'] = np.asarray(r).reshape(-1)
+    # zero-qubit MessageGates after every gate
+    buf = io.StringIO()
+    msg = Circuit(x for i, g in enumerate(gs) for x in (g, ExtraGate('MESSAGE', qubits=tuple(), message=f'{i}', file=buf)))
+    r = simulate(msg, initial_state=init, optimize='evolution', complex_type='complex128')
+    out['msg_psi'] = np.asarray(r).reshape(-1)
+    buf.seek(0)
+    out['msg_lines'] = np.asarray([int(x.strip()) for x in buf.readlines()])
+    np.savez_compressed(os.path.join(HERE, 'e2e_containers.npz'), **out)
+    print('tuple / stochastic / message vectors written;', len(out['msg_lines']), 'messages')
+
+
 def qasm_vectors():
     """e2e_qasm_ext.npz: a circuit with string / tuple-free labels, powers, conj / T and a MATRIX gate written
     by the reference's to_qasm (hybridq/extras/io/qasm.py:160) -- the text it produced (output data) and every
@@ -533,6 +597,9 @@ def qasm_vectors():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'qasm':
         qasm_vectors()
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'containers':
+        container_vectors()
         raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'matrix':
         matrix_vectors()

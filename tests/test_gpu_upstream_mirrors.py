@@ -240,3 +240,38 @@ def test_return_numpy_array_false_is_the_split_state(torch_cuda):
     assert split.shape == (2,) + (2,) * n and split.dtype == np.float32
     assert np.array_equal(split[0], psi.real) and np.array_equal(split[1], psi.imag)
     assert np.asarray(state, dtype=np.float64).dtype == np.float64
+
+
+def test_container_gates_against_the_reference_itself(torch_cuda):
+    """tests/golden/e2e_containers.npz: final states the REFERENCE returned (make_golden.py containers) for a circuit cut
+    into TupleGates, for a StochasticGate drawn under `sampling_seed` (the draw is numpy's global generator seeded the way
+    simulation.py:241-256 does it: same seed, same gate) and for zero-qubit MessageGates after every gate."""
+    import golden_util as gu
+    from hybridq_amd.simulation import simulate
+    z = gu.load('e2e_containers.npz')
+    gs = gu.rqc_gates(z, 'tup')
+    n = 12
+    init = str(z['init'])
+    q = list(range(n))
+    kw = dict(initial_state=init, complex_type='complex128', compress=0, simplify=False, qubits=q)
+    exp = z['tup_psi']
+    scale = np.abs(exp).max()
+    for circuit in (gs, [TupleGate(gs[i:i + 4]) for i in range(0, len(gs), 4)], [TupleGate(gs)]):
+        assert np.abs(simulate(circuit, **kw).reshape(-1) - exp).max() / scale < 1e-12
+    stoc = StochasticGate(gu.rqc_gates(z, 'stoc'), z['stoc_p'])
+    picked = set()
+    for seed in z['stoc_seeds']:
+        psi = simulate(gs[:40] + [stoc] + gs[40:], allow_sampling=True, sampling_seed=int(seed), **kw).reshape(-1)
+        ref = z[f'stoc_psi_{int(seed)}']
+        assert np.abs(psi - ref).max() / np.abs(ref).max() < 1e-12, int(seed)
+        picked.add(ref.tobytes())
+    assert len(picked) > 1  # the seeds do select different gates
+    file = io.StringIO()
+    msg = [x for i, g in enumerate(gs) for x in (g, MessageGate(f'{i}', file))]
+    psi = simulate(msg, initial_state=init, complex_type='complex128', qubits=q).reshape(-1)
+    assert np.abs(psi - z['msg_psi']).max() / np.abs(z['msg_psi']).max() < 1e-12
+    file.seek(0)
+    # every message exactly once; the reference prints them in the order its simplify / compress passes left the zero-qubit
+    # gates in (they commute with everything: 79, 78, ... here), this driver in circuit order -- tests.py:2030-2034 sorts too
+    ours = [int(x.strip()) for x in file.readlines()]
+    assert ours == list(range(len(gs))) and sorted(int(x) for x in z['msg_lines']) == ours

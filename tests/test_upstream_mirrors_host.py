@@ -46,3 +46,7 @@ def test_simulation_2__message(host):
 
 def test_simulation_2__stochastic(host):
     mirrors.test_simulation_2__stochastic(None)
+
+
+def test_container_gates_against_the_reference_itself(host):
+    mirrors.test_container_gates_against_the_reference_itself(None)
