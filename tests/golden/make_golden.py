@@ -562,6 +562,42 @@ def container_vectors():
     print('tuple / stochastic / message vectors written;', len(out['msg_lines']), 'messages')
 
 
+def live_cases(path, seed):
+    """python make_golden.py live OUT.npz SEED: random circuits through the reference's simulate() under random options,
+    for the live differential test (tests/test_reference_live_host.py runs this in a subprocess when /root/reference is
+    there and compares this package's host side, on the numpy test double, case by case)."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    import hybridq.circuit.simulation.simulation as sim
+    from hybridq.circuit.simulation import simulate
+    from hybridq.extras.random import get_rqc
+    assert sim._log2_pack_size == 3, 'reference core not found: set LD_LIBRARY_PATH=oracle/_ref'
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed)
+    out = {'n_cases': 0}
+    for i in range(10):
+        n = int(rng.integers(11, 14))
+        c = get_rqc(n, int(rng.integers(40, 120)), use_random_indexes=False, use_unitary_only=bool(rng.integers(0, 2)))
+        qubits = c.all_qubits()
+        init = ''.join(rng.choice(list('01+-'), size=len(qubits)))
+        compress = int(rng.choice([0, 2, 4, 6]))
+        simplify = bool(rng.integers(0, 2))
+        ctype = 'complex128' if i % 3 else 'complex64'
+        psi = simulate(c, initial_state=init, optimize='evolution-hybridq', complex_type=ctype, compress=compress, simplify=simplify)
+        out[f'c{i}_n_gates'] = len(c)
+        for j, g in enumerate(c):
+            out[f'c{i}_U{j}'] = np.asarray(g.matrix(), dtype=np.complex128)
+            out[f'c{i}_q{j}'] = np.asarray([qubits.index(q) for q in g.qubits], dtype=np.int32)
+        out[f'c{i}_n'] = len(qubits)
+        out[f'c{i}_init'] = np.array(init)
+        out[f'c{i}_compress'] = compress
+        out[f'c{i}_simplify'] = simplify
+        out[f'c{i}_ctype'] = np.array(ctype)
+        out[f'c{i}_psi'] = np.asarray(psi).reshape(-1)
+        out['n_cases'] = i + 1
+    np.savez_compressed(path, **out)
+
+
 def qasm_vectors():
     """e2e_qasm_ext.npz: a circuit with string / tuple-free labels, powers, conj / T and a MATRIX gate written
     by the reference's to_qasm (hybridq/extras/io/qasm.py:160) -- the text it produced (output data) and every
@@ -597,6 +633,9 @@ def qasm_vectors():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'qasm':
         qasm_vectors()
+        raise SystemExit(0)
+    if len(sys.argv) > 3 and sys.argv[1] == 'live':
+        live_cases(sys.argv[2], int(sys.argv[3]))
         raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'containers':
         container_vectors()

@@ -1,0 +1,41 @@
+"""Live differential test against the REFERENCE ITSELF, in the build container only: when /root/reference and the compiled
+reference core (oracle/_ref) are present, the reference's own ``simulate(optimize='evolution-hybridq')`` runs random
+circuits under random options in a subprocess (tests/golden/make_golden.py live), and this package's host side -- on the
+numpy test double of the device -- must return the same states.  Skipped anywhere else (the GPU boxes have no reference;
+the committed fixtures under tests/golden/ are what travels)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+REF_CORE = os.path.join(ROOT, 'oracle', '_ref')
+
+
+@pytest.mark.skipif(not (os.path.isdir('/root/reference/hybridq') and os.path.exists(os.path.join(REF_CORE, 'hybridq.so'))),
+                    reason='needs /root/reference and oracle/_ref (build container only)')
+@pytest.mark.parametrize('seed', [1, 2])
+def test_random_circuits_and_options_against_the_reference(numpy_device, tmp_path, seed):
+    from hybridq_amd.simulation import simulate
+    out = str(tmp_path / 'live.npz')
+    env = dict(os.environ, LD_LIBRARY_PATH=REF_CORE + ':' + os.environ.get('LD_LIBRARY_PATH', ''), PYTHONDONTWRITEBYTECODE='1')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'golden', 'make_golden.py'), 'live', out, str(seed)],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    z = np.load(out, allow_pickle=False)
+    assert int(z['n_cases']) == 10
+    for i in range(int(z['n_cases'])):
+        gates = [(z[f'c{i}_U{j}'], tuple(int(q) for q in z[f'c{i}_q{j}'])) for j in range(int(z[f'c{i}_n_gates']))]
+        n, ctype = int(z[f'c{i}_n']), str(z[f'c{i}_ctype'])
+        psi = simulate(gates, initial_state=str(z[f'c{i}_init']), optimize='evolution-hybridq', complex_type=ctype,
+                       compress=int(z[f'c{i}_compress']), simplify=bool(z[f'c{i}_simplify']), qubits=list(range(n)))
+        ref = z[f'c{i}_psi']
+        assert psi.dtype == ref.dtype and psi.shape == (2,) * n
+        # the double computes in float64: against the reference's complex128 run that is rounding only, against its
+        # complex64 run the reference's own single-precision error (<= 1e-5 over ~100 non-unitary gates)
+        tol = 1e-11 if ctype == 'complex128' else 2e-5
+        assert np.abs(psi.reshape(-1) - ref).max() / np.abs(ref).max() < tol, (seed, i, ctype)
