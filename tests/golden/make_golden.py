@@ -589,11 +589,24 @@ def live_cases(path, seed):
             out[f'c{i}_U{j}'] = np.asarray(g.matrix(), dtype=np.complex128)
             out[f'c{i}_q{j}'] = np.asarray([qubits.index(q) for q in g.qubits], dtype=np.int32)
         out[f'c{i}_n'] = len(qubits)
+        out[f'c{i}_names'] = np.array([g.name for g in c])
         out[f'c{i}_init'] = np.array(init)
         out[f'c{i}_compress'] = compress
         out[f'c{i}_simplify'] = simplify
         out[f'c{i}_ctype'] = np.array(ctype)
         out[f'c{i}_psi'] = np.asarray(psi).reshape(-1)
+        # the gate stream the reference's driver hands to its core for this call (simulation.py:289-305, :436-454)
+        from hybridq.circuit import Circuit, utils
+        from hybridq.gate import property as pr
+        cc = Circuit(g for g in c if g.name != 'I')
+        if simplify:
+            cc = utils.simplify(cc, remove_id_gates=True, atol=1e-8, verbose=False)
+        layers = utils.compress(cc, compress, verbose=False, skip_compression=[pr.FunctionalGate])
+        fused = [utils.to_matrix_gate(layer, complex_type=ctype) for layer in layers]
+        out[f'c{i}_f_n'] = len(fused)
+        for j, g in enumerate(fused):
+            out[f'c{i}_fU{j}'] = np.asarray(g.matrix())
+            out[f'c{i}_fq{j}'] = np.asarray([qubits.index(q) for q in g.qubits], dtype=np.int32)
         out['n_cases'] = i + 1
     np.savez_compressed(path, **out)
 

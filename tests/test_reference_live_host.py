@@ -33,6 +33,24 @@ def test_random_circuits_and_options_against_the_reference(numpy_device, tmp_pat
         n, ctype = int(z[f'c{i}_n']), str(z[f'c{i}_ctype'])
         psi = simulate(gates, initial_state=str(z[f'c{i}_init']), optimize='evolution-hybridq', complex_type=ctype,
                        compress=int(z[f'c{i}_compress']), simplify=bool(z[f'c{i}_simplify']), qubits=list(range(n)))
+        # the same gate stream as the reference's driver builds (simplify, compress, to_matrix_gate), one for one
+        from hybridq_amd.simulation import _plan_ops, _simplify_runs
+        named = [g for g, name in zip(gates, z[f'c{i}_names']) if str(name) != 'I']  # Gate('I') is stripped by name (:289-291)
+        circ = _simplify_runs(named, True, 1e-8, {}) if bool(z[f'c{i}_simplify']) else named
+        ours = _plan_ops(circ, list(range(n)), n, np.dtype(ctype), int(z[f'c{i}_compress']), False)
+        assert len(ours) == int(z[f'c{i}_f_n']), (seed, i)
+        from hybridq_amd.fusion import _embed
+        for j, (qs, U) in enumerate(ours):
+            fq = tuple(int(q) for q in z[f'c{i}_fq{j}'])
+            fU = z[f'c{i}_fU{j}']
+            if int(z[f'c{i}_compress']) == 0 and tuple(qs) != fq:
+                # unfused, the reference still passes every gate through to_matrix_gate, which sorts its qubits
+                # (utils.py:419-464); this driver applies the gate as given: the same operator, indices permuted
+                assert sorted(qs) == list(fq), (seed, i, j)
+                U = _embed(U, qs, list(fq))
+            else:
+                assert tuple(qs) == fq, (seed, i, j)
+            assert np.abs(np.asarray(U) - fU).max() <= (1e-12 if ctype == 'complex128' else 1e-6) * max(1.0, np.abs(fU).max()), (seed, i, j)
         ref = z[f'c{i}_psi']
         assert psi.dtype == ref.dtype and psi.shape == (2,) * n
         # the double computes in float64: against the reference's complex128 run that is rounding only, against its
