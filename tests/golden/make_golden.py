@@ -611,6 +611,51 @@ def live_cases(path, seed):
     np.savez_compressed(path, **out)
 
 
+def live_dm_cases(path, seed):
+    """python make_golden.py live_dm OUT.npz SEED: random noisy circuits (depolarizing / dephasing / amplitude-damping noise
+    from hybridq.noise.utils) through the reference's dm simulate(), as data like dm_circuit() records them."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    import hybridq.dm.circuit.simulation as dmsim
+    from hybridq.extras.random import get_rqc
+    from hybridq.noise.utils import add_amplitude_damping_noise, add_dephasing_noise, add_depolarizing_noise
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed)
+    out = {'n_cases': 0}
+    for i in range(4):
+        nq = int(rng.integers(6, 8))  # 2 nq > 10 qubits: below that the reference leaves its C++ core for einsum (:401-404)
+        circ = get_rqc(nq, int(rng.integers(16, 28)), use_random_indexes=False)
+        while len(circ.all_qubits()) != nq:  # every qubit in use
+            circ = get_rqc(nq, int(rng.integers(16, 28)), use_random_indexes=False)
+        kind = ['depolarizing', 'dephasing', 'damping', 'depolarizing'][i]
+        if kind == 'depolarizing':
+            noisy = add_depolarizing_noise(circ, probs=(float(rng.uniform(0.005, 0.05)), float(rng.uniform(0.01, 0.08))))
+        elif kind == 'dephasing':
+            noisy = add_dephasing_noise(circ, probs=float(rng.uniform(0.01, 0.1)), pauli_indexes=int(rng.integers(1, 4)))
+        else:
+            noisy = add_amplitude_damping_noise(circ, gammas=float(rng.uniform(0.01, 0.1)), probs=float(rng.uniform(0.0, 0.3)))
+        init = ''.join(rng.choice(list('01+-'), size=len(noisy.all_qubits()[0])))
+        kinds = ''
+        for j, g in enumerate(noisy):
+            out[f'c{i}_q{j}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+            if hasattr(g, 'Kraus'):
+                kinds += 'K'
+                L, R = g.Kraus.gates
+                out[f'c{i}_L{j}'] = np.stack([np.asarray(x.matrix(), dtype=np.complex128) for x in L])
+                out[f'c{i}_R{j}'] = np.stack([np.asarray(x.matrix(), dtype=np.complex128) for x in R])
+                out[f'c{i}_s{j}'] = np.asarray(g.Kraus.s, dtype=np.float64)
+            else:
+                kinds += 'U'
+                out[f'c{i}_U{j}'] = np.asarray(g.matrix(), dtype=np.complex128)
+        out[f'c{i}_kinds'] = np.frombuffer(kinds.encode(), dtype=np.uint8)
+        out[f'c{i}_init'] = np.array(init)
+        out[f'c{i}_kind'] = np.array(kind)
+        rho = dmsim.simulate(noisy, initial_state=init, optimize='evolution-hybridq', complex_type='complex128', verbose=False)
+        out[f'c{i}_rho'] = np.asarray(rho).reshape(-1)
+        out['n_cases'] = i + 1
+    np.savez_compressed(path, **out)
+
+
 def qasm_vectors():
     """e2e_qasm_ext.npz: a circuit with string / tuple-free labels, powers, conj / T and a MATRIX gate written
     by the reference's to_qasm (hybridq/extras/io/qasm.py:160) -- the text it produced (output data) and every
@@ -646,6 +691,9 @@ def qasm_vectors():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'qasm':
         qasm_vectors()
+        raise SystemExit(0)
+    if len(sys.argv) > 3 and sys.argv[1] == 'live_dm':
+        live_dm_cases(sys.argv[2], int(sys.argv[3]))
         raise SystemExit(0)
     if len(sys.argv) > 3 and sys.argv[1] == 'live':
         live_cases(sys.argv[2], int(sys.argv[3]))

@@ -24,7 +24,7 @@ def test_random_circuits_and_options_against_the_reference(numpy_device, tmp_pat
     out = str(tmp_path / 'live.npz')
     env = dict(os.environ, LD_LIBRARY_PATH=REF_CORE + ':' + os.environ.get('LD_LIBRARY_PATH', ''), PYTHONDONTWRITEBYTECODE='1')
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'golden', 'make_golden.py'), 'live', out, str(seed)],
-                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     z = np.load(out, allow_pickle=False)
     assert int(z['n_cases']) == 10
@@ -57,3 +57,33 @@ def test_random_circuits_and_options_against_the_reference(numpy_device, tmp_pat
         # complex64 run the reference's own single-precision error (<= 1e-5 over ~100 non-unitary gates)
         tol = 1e-11 if ctype == 'complex128' else 2e-5
         assert np.abs(psi.reshape(-1) - ref).max() / np.abs(ref).max() < tol, (seed, i, ctype)
+
+
+@pytest.mark.skipif(not (os.path.isdir('/root/reference/hybridq') and os.path.exists(os.path.join(REF_CORE, 'hybridq.so'))),
+                    reason='needs /root/reference and oracle/_ref (build container only)')
+def test_noisy_circuits_against_the_reference_dm_simulate(numpy_device, tmp_path):
+    """BASELINE config 5's front-end: random circuits with depolarizing / dephasing / amplitude-damping noise through the
+    reference's hybridq.dm simulate() (subprocess) and through hybridq_amd.dm.simulate on the double: the same rho."""
+    from hybridq_amd import dm
+    out = str(tmp_path / 'live_dm.npz')
+    env = dict(os.environ, LD_LIBRARY_PATH=REF_CORE + ':' + os.environ.get('LD_LIBRARY_PATH', ''), PYTHONDONTWRITEBYTECODE='1')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'golden', 'make_golden.py'), 'live_dm', out, '5'],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    z = np.load(out, allow_pickle=False)
+    assert int(z['n_cases']) == 4
+    for i in range(int(z['n_cases'])):
+        kinds = bytes(z[f'c{i}_kinds']).decode()
+        circuit = []
+        for j, kind in enumerate(kinds):
+            qs = tuple(int(q) for q in z[f'c{i}_q{j}'])
+            if kind == 'K':
+                circuit.append(dm.Kraus(list(z[f'c{i}_L{j}']), qs, s=z[f'c{i}_s{j}'], right_ops=list(z[f'c{i}_R{j}'])))
+            else:
+                circuit.append((z[f'c{i}_U{j}'], qs))
+        ref = z[f'c{i}_rho']
+        for kw in (dict(compress=4), dict(compress=0), {}):
+            rho = dm.simulate(circuit, initial_state=str(z[f'c{i}_init']), complex_type='complex128', **kw).reshape(-1)
+            assert np.abs(rho - ref).max() / np.abs(ref).max() < 1e-11, (i, str(z[f'c{i}_kind']), kw)
+        d = int(round(np.sqrt(ref.size)))
+        assert abs(np.trace(ref.reshape(d, d)) - 1) < 1e-9
