@@ -577,7 +577,8 @@ def live_cases(path, seed):
     out = {'n_cases': 0}
     for i in range(10):
         n = int(rng.integers(11, 14))
-        c = get_rqc(n, int(rng.integers(40, 120)), use_random_indexes=False, use_unitary_only=bool(rng.integers(0, 2)))
+        unitary = bool(rng.integers(0, 2))
+        c = get_rqc(n, int(rng.integers(40, 120)), use_random_indexes=False, use_unitary_only=unitary)
         qubits = c.all_qubits()
         init = ''.join(rng.choice(list('01+-'), size=len(qubits)))
         compress = int(rng.choice([0, 2, 4, 6]))
@@ -590,11 +591,38 @@ def live_cases(path, seed):
             out[f'c{i}_q{j}'] = np.asarray([qubits.index(q) for q in g.qubits], dtype=np.int32)
         out[f'c{i}_n'] = len(qubits)
         out[f'c{i}_names'] = np.array([g.name for g in c])
+        out[f'c{i}_unitary'] = unitary
         out[f'c{i}_init'] = np.array(init)
         out[f'c{i}_compress'] = compress
         out[f'c{i}_simplify'] = simplify
         out[f'c{i}_ctype'] = np.array(ctype)
         out[f'c{i}_psi'] = np.asarray(psi).reshape(-1)
+        # a Projection in the middle of the same circuit, and an expectation value on the final state
+        from hybridq.circuit import Circuit as _Circuit
+        from hybridq.circuit.simulation import expectation_value
+        from hybridq.gate import Projection
+        k = int(rng.integers(1, 4))
+        pq = [qubits[int(x)] for x in rng.permutation(len(qubits))[:k]]
+        bits = ''.join(rng.choice(list('01'), size=k))
+        cut = len(c) // 2
+        gl = list(c)
+        try:
+            proj = simulate(_Circuit(gl[:cut] + [Projection(state=bits, qubits=pq)] + gl[cut:]), initial_state=init,
+                            optimize='evolution-hybridq', complex_type='complex128', compress=compress, simplify=False)
+            out[f'c{i}_proj_psi'] = np.asarray(proj).reshape(-1)
+        except Exception as e:  # noqa: BLE001 -- e.g. nothing survives the projection: recorded as absent
+            print('projection case skipped:', repr(e))
+        out[f'c{i}_proj_q'] = np.asarray([qubits.index(q) for q in pq], dtype=np.int32)
+        out[f'c{i}_proj_bits'] = np.array(bits)
+        out[f'c{i}_proj_cut'] = cut
+        op = get_rqc(2, 3, indexes=[qubits[1], qubits[len(qubits) - 2]], use_random_indexes=False, use_unitary_only=False)
+        for j, g in enumerate(op):
+            out[f'c{i}_opU{j}'] = np.asarray(g.matrix(), dtype=np.complex128)
+            out[f'c{i}_opq{j}'] = np.asarray([qubits.index(q) for q in g.qubits], dtype=np.int32)
+        out[f'c{i}_op_n'] = len(op)
+        psi128 = np.asarray(psi).astype('complex128')
+        out[f'c{i}_ev'] = np.asarray(expectation_value(state=psi128, op=op, qubits_order=qubits, complex_type='complex128',
+                                                       verbose=False), dtype=np.complex128)
         # the gate stream the reference's driver hands to its core for this call (simulation.py:289-305, :436-454)
         from hybridq.circuit import Circuit, utils
         from hybridq.gate import property as pr

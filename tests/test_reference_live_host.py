@@ -53,6 +53,31 @@ def test_random_circuits_and_options_against_the_reference(numpy_device, tmp_pat
             assert np.abs(np.asarray(U) - fU).max() <= (1e-12 if ctype == 'complex128' else 1e-6) * max(1.0, np.abs(fU).max()), (seed, i, j)
         ref = z[f'c{i}_psi']
         assert psi.dtype == ref.dtype and psi.shape == (2,) * n
+        # a Projection (device-side functional gate here, host numpy code there) in the middle of the circuit
+        if f'c{i}_proj_psi' in z.files:
+            from hybridq_amd.functional import Projection
+            cut = int(z[f'c{i}_proj_cut'])
+            P = Projection(str(z[f'c{i}_proj_bits']), [int(q) for q in z[f'c{i}_proj_q']])
+            pp = simulate(gates[:cut] + [P] + gates[cut:], initial_state=str(z[f'c{i}_init']), optimize='evolution-hybridq',
+                          complex_type='complex128', compress=int(z[f'c{i}_compress']), simplify=False, qubits=list(range(n)))
+            pref, pp = z[f'c{i}_proj_psi'], pp.reshape(-1)
+            if not pref.any():  # nothing survived the projection (projection.py:58-66): all zeros on both sides
+                assert not pp.any(), (seed, i, 'projection onto nothing')
+                continue_projection = False
+            else:
+                continue_projection = True
+            if continue_projection and not bool(z[f'c{i}_unitary']):
+                # the reference's compression slides gates on other qubits across the (renormalising) projection; with
+                # non-unitary gates that changes the state's norm at the moment of renormalisation, i.e. the result by
+                # a positive factor -- this driver applies the circuit in the order written.  Same ray, compared as such.
+                pref, pp = pref / np.linalg.norm(pref), pp / np.linalg.norm(pp)
+            if continue_projection:
+                assert np.abs(pp - pref).max() / np.abs(pref).max() < 1e-10, (seed, i, 'projection')
+        # <psi| op |psi> of the reference's final state
+        from hybridq_amd.simulation import expectation_value
+        op = [(z[f'c{i}_opU{j}'], tuple(int(q) for q in z[f'c{i}_opq{j}'])) for j in range(int(z[f'c{i}_op_n']))]
+        ev = expectation_value(ref.astype(np.complex128).reshape((2,) * n), op, qubits_order=list(range(n)), complex_type='complex128')
+        assert abs(ev - complex(z[f'c{i}_ev'])) < 1e-10 * max(1.0, abs(complex(z[f'c{i}_ev']))), (seed, i, 'expectation_value')
         # the double computes in float64: against the reference's complex128 run that is rounding only, against its
         # complex64 run the reference's own single-precision error (<= 1e-5 over ~100 non-unitary gates)
         tol = 1e-11 if ctype == 'complex128' else 2e-5
