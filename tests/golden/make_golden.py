@@ -684,6 +684,62 @@ def live_dm_cases(path, seed):
     np.savez_compressed(path, **out)
 
 
+def live_qasm_write(path, seed):
+    """python make_golden.py live_qasm_write OUT.npz SEED: a random circuit over EVERY named gate of the reference
+    (hybridq/gate/gate.py:127-350), with parameters, powers, conj / T and MATRIX gates, written by the reference's to_qasm;
+    the text and every gate's matrix and qubits."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    from hybridq.circuit import Circuit
+    from hybridq.extras.io.qasm import to_qasm
+    from hybridq.gate import Gate
+    rng = np.random.default_rng(seed)
+    one = ['I', 'H', 'X', 'Y', 'Z', 'P', 'T', 'SQRT_X', 'SQRT_Y']
+    two = ['ZZ', 'CZ', 'CX', 'SWAP', 'ISWAP', 'SQRT_SWAP', 'SQRT_ISWAP']
+    par = {'RX': (1, 1), 'RY': (1, 1), 'RZ': (1, 1), 'R_PI_2': (1, 1), 'U3': (1, 3), 'CPHASE': (2, 1), 'FSIM': (2, 2)}
+    labels = [3, 17, 42, 5, 8, 100]
+    gates = []
+    for rep in range(3):
+        for name in one + two + list(par):
+            k, npar = (1, 0) if name in one else (2, 0) if name in two else par[name]
+            qs = [labels[int(x)] for x in rng.permutation(len(labels))[:k]]
+            g = Gate(name, qubits=qs, params=[float(x) for x in rng.uniform(-3, 3, size=npar)]) if npar else Gate(name, qubits=qs)
+            what = int(rng.integers(0, 5)) if rep else 0
+            if what == 1:
+                g = g**float(rng.choice([2, 3, -1, 0.5, 1.23, -0.7]))
+            elif what == 2:
+                g = g.conj()
+            elif what == 3:
+                g = g.T()
+            elif what == 4:
+                g = (g**float(rng.choice([2, 0.37]))).conj().T()
+            gates.append(g)
+    for k in (1, 2, 3):
+        M = rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k))
+        gates.append(Gate('MATRIX', qubits=[labels[int(x)] for x in rng.permutation(len(labels))[:k]], U=M))
+    c = Circuit(gates)
+    text = to_qasm(c)
+    out = {'text': np.frombuffer(text.encode(), dtype=np.uint8), 'n_gates': len(c)}
+    for i, g in enumerate(c):
+        out[f'U{i}'] = np.asarray(g.matrix(), dtype=np.complex128)
+        out[f'q{i}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int64)
+        out[f'name{i}'] = np.array(g.name)
+    np.savez_compressed(path, **out)
+
+
+def live_qasm_read(text_path, path):
+    """python make_golden.py live_qasm_read IN.txt OUT.npz: the reference's from_qasm on a text THIS package wrote."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    from hybridq.extras.io.qasm import from_qasm
+    c = from_qasm(open(text_path).read())
+    out = {'n_gates': len(c)}
+    for i, g in enumerate(c):
+        out[f'U{i}'] = np.asarray(g.matrix(), dtype=np.complex128)
+        out[f'q{i}'] = np.array([str(q) for q in g.qubits])
+    np.savez_compressed(path, **out)
+
+
 def qasm_vectors():
     """e2e_qasm_ext.npz: a circuit with string / tuple-free labels, powers, conj / T and a MATRIX gate written
     by the reference's to_qasm (hybridq/extras/io/qasm.py:160) -- the text it produced (output data) and every
@@ -719,6 +775,12 @@ def qasm_vectors():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'qasm':
         qasm_vectors()
+        raise SystemExit(0)
+    if len(sys.argv) > 3 and sys.argv[1] == 'live_qasm_write':
+        live_qasm_write(sys.argv[2], int(sys.argv[3]))
+        raise SystemExit(0)
+    if len(sys.argv) > 3 and sys.argv[1] == 'live_qasm_read':
+        live_qasm_read(sys.argv[2], sys.argv[3])
         raise SystemExit(0)
     if len(sys.argv) > 3 and sys.argv[1] == 'live_dm':
         live_dm_cases(sys.argv[2], int(sys.argv[3]))

@@ -112,3 +112,41 @@ def test_noisy_circuits_against_the_reference_dm_simulate(numpy_device, tmp_path
             assert np.abs(rho - ref).max() / np.abs(ref).max() < 1e-11, (i, str(z[f'c{i}_kind']), kw)
         d = int(round(np.sqrt(ref.size)))
         assert abs(np.trace(ref.reshape(d, d)) - 1) < 1e-9
+
+
+def _reference(args, cwd):
+    env = dict(os.environ, LD_LIBRARY_PATH=REF_CORE + ':' + os.environ.get('LD_LIBRARY_PATH', ''), PYTHONDONTWRITEBYTECODE='1')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'golden', 'make_golden.py')] + args, cwd=cwd, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/hybridq'), reason='needs /root/reference (build container only)')
+@pytest.mark.parametrize('seed', [1, 2])
+def test_qasm_both_ways_against_the_reference(tmp_path, seed):
+    """The reference's to_qasm on a random circuit over every named gate it has (parameters, powers, conj / T, MATRIX
+    gates, arbitrary integer labels) -> this package's from_qasm: every matrix and qubit tuple as the reference's
+    gate.matrix() / gate.qubits; then this package's to_qasm -> the reference's from_qasm: the same matrices again."""
+    from hybridq_amd.qasm import from_qasm, to_qasm
+    out = str(tmp_path / 'w.npz')
+    _reference(['live_qasm_write', out, str(seed)], str(tmp_path))
+    z = np.load(out, allow_pickle=False)
+    text = bytes(z['text']).decode()
+    gates = from_qasm(text)
+    assert len(gates) == int(z['n_gates'])
+    seen = set()
+    for i, (U, qs) in enumerate(gates):
+        assert tuple(qs) == tuple(int(q) for q in z[f'q{i}']), (i, str(z[f'name{i}']))
+        assert np.abs(U - z[f'U{i}']).max() < 1e-10 * max(1.0, np.abs(z[f'U{i}']).max()), (i, str(z[f'name{i}']))
+        seen.add(str(z[f'name{i}']))
+    assert len(seen) >= 23  # every named gate of hybridq/gate/gate.py:127-350 plus MATRIX
+    back = str(tmp_path / 'ours.qasm')
+    with open(back, 'w') as f:
+        f.write(to_qasm(gates))
+    out2 = str(tmp_path / 'r.npz')
+    _reference(['live_qasm_read', back, out2], str(tmp_path))
+    r = np.load(out2, allow_pickle=False)
+    assert int(r['n_gates']) == len(gates)
+    for i, (U, qs) in enumerate(gates):
+        assert [str(q) for q in qs] == [str(q) for q in r[f'q{i}']], i
+        assert np.abs(U - r[f'U{i}']).max() < 1e-10 * max(1.0, np.abs(U).max()), i
