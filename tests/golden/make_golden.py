@@ -740,6 +740,81 @@ def live_qasm_read(text_path, path):
     np.savez_compressed(path, **out)
 
 
+def live_named_cases(path, seed):
+    """python make_golden.py live_named OUT.npz SEED: circuits of NAMED gates -- diagonal ones that commute (Z, T, P, CZ,
+    RZ, CPHASE, ZZ), planted inverse pairs and identities -- through the reference's simplify / compress under random
+    option dictionaries (use_matrix_commutation, max_n_qubits_matrix, exclude_qubits), and through its simulate()."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    from hybridq.circuit import Circuit, utils
+    from hybridq.circuit.simulation import simulate
+    from hybridq.gate import Gate
+    from hybridq.gate import property as pr
+    rng = np.random.default_rng(seed)
+    out = {'n_cases': 0}
+    n = 12
+    one = ['H', 'X', 'Z', 'T', 'P', 'SQRT_X', 'I']
+    two = ['CZ', 'CX', 'ZZ', 'ISWAP']
+    for i in range(6):
+        gates = []
+        while len(gates) < 90:
+            r = rng.random()
+            if r < 0.45:
+                gates.append(Gate(str(rng.choice(one)), qubits=[int(rng.integers(0, n))]))
+            elif r < 0.7:
+                a, b = (int(x) for x in rng.permutation(n)[:2])
+                gates.append(Gate(str(rng.choice(two)), qubits=[a, b]))
+            elif r < 0.8:
+                gates.append(Gate('RZ', qubits=[int(rng.integers(0, n))], params=[float(rng.uniform(-3, 3))]))
+            elif r < 0.88:
+                a, b = (int(x) for x in rng.permutation(n)[:2])
+                gates.append(Gate('CPHASE', qubits=[a, b], params=[float(rng.uniform(-3, 3))]))
+            else:  # an inverse pair with something commuting (or not) in between
+                a, b = (int(x) for x in rng.permutation(n)[:2])
+                g = Gate(str(rng.choice(['CX', 'ISWAP', 'CZ'])), qubits=[a, b])
+                mid = Gate(str(rng.choice(['Z', 'T', 'H'])), qubits=[int(rng.integers(0, n))])
+                gates += [g, mid, g.inv()]
+        for q in range(n):  # every qubit in use
+            gates.append(Gate('H', qubits=[q]))
+        c = Circuit(gates)
+        qubits = c.all_qubits()
+        assert qubits == list(range(n))
+        simp = {'use_matrix_commutation': bool(rng.integers(0, 2))}
+        comp = {'max_n_qubits': int(rng.choice([2, 3, 4, 5])), 'use_matrix_commutation': bool(rng.integers(0, 2)),
+                'max_n_qubits_matrix': int(rng.choice([4, 10]))}
+        if rng.random() < 0.5:
+            comp['exclude_qubits'] = [int(x) for x in rng.permutation(n)[:2]]
+        init = ''.join(rng.choice(list('01+-'), size=n))
+        out[f'c{i}_n_gates'] = len(c)
+        for j, g in enumerate(c):
+            out[f'c{i}_U{j}'] = np.asarray(g.matrix(), dtype=np.complex128)
+            out[f'c{i}_q{j}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+        out[f'c{i}_names'] = np.array([g.name for g in c])
+        out[f'c{i}_init'] = np.array(init)
+        out[f'c{i}_simp_umc'] = simp['use_matrix_commutation']
+        out[f'c{i}_comp_n'] = comp['max_n_qubits']
+        out[f'c{i}_comp_umc'] = comp['use_matrix_commutation']
+        out[f'c{i}_comp_mnm'] = comp['max_n_qubits_matrix']
+        out[f'c{i}_comp_excl'] = np.asarray(comp.get('exclude_qubits', []), dtype=np.int32)
+        cc = Circuit(g for g in c if g.name != 'I')
+        cc = utils.simplify(cc, remove_id_gates=True, atol=1e-8, verbose=False, **simp)
+        out[f'c{i}_s_n'] = len(cc)
+        for j, g in enumerate(cc):
+            out[f'c{i}_sU{j}'] = np.asarray(g.matrix(), dtype=np.complex128)
+            out[f'c{i}_sq{j}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+        layers = utils.compress(cc, comp['max_n_qubits'], verbose=False, skip_compression=[pr.FunctionalGate],
+                                **{k: v for k, v in comp.items() if k != 'max_n_qubits'})
+        fused = [utils.to_matrix_gate(layer, complex_type='complex128') for layer in layers]
+        out[f'c{i}_f_n'] = len(fused)
+        for j, g in enumerate(fused):
+            out[f'c{i}_fU{j}'] = np.asarray(g.matrix())
+            out[f'c{i}_fq{j}'] = np.asarray([int(q) for q in g.qubits], dtype=np.int32)
+        psi = simulate(c, initial_state=init, optimize='evolution-hybridq', complex_type='complex128', compress=comp, simplify=simp)
+        out[f'c{i}_psi'] = np.asarray(psi).reshape(-1)
+        out['n_cases'] = i + 1
+    np.savez_compressed(path, **out)
+
+
 def qasm_vectors():
     """e2e_qasm_ext.npz: a circuit with string / tuple-free labels, powers, conj / T and a MATRIX gate written
     by the reference's to_qasm (hybridq/extras/io/qasm.py:160) -- the text it produced (output data) and every
@@ -781,6 +856,9 @@ if __name__ == '__main__':
         raise SystemExit(0)
     if len(sys.argv) > 3 and sys.argv[1] == 'live_qasm_read':
         live_qasm_read(sys.argv[2], sys.argv[3])
+        raise SystemExit(0)
+    if len(sys.argv) > 3 and sys.argv[1] == 'live_named':
+        live_named_cases(sys.argv[2], int(sys.argv[3]))
         raise SystemExit(0)
     if len(sys.argv) > 3 and sys.argv[1] == 'live_dm':
         live_dm_cases(sys.argv[2], int(sys.argv[3]))

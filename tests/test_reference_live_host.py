@@ -150,3 +150,41 @@ def test_qasm_both_ways_against_the_reference(tmp_path, seed):
     for i, (U, qs) in enumerate(gates):
         assert [str(q) for q in qs] == [str(q) for q in r[f'q{i}']], i
         assert np.abs(U - r[f'U{i}']).max() < 1e-10 * max(1.0, np.abs(U).max()), i
+
+
+@pytest.mark.skipif(not (os.path.isdir('/root/reference/hybridq') and os.path.exists(os.path.join(REF_CORE, 'hybridq.so'))),
+                    reason='needs /root/reference and oracle/_ref (build container only)')
+@pytest.mark.parametrize('seed', [1, 2])
+def test_named_gate_circuits_simplify_and_compress_options(numpy_device, tmp_path, seed):
+    """Where simplification and fusion have something to decide: circuits of named gates with commuting diagonal gates,
+    planted inverse pairs and identities, under random option dictionaries -- fusion.simplify and fusion.fuse return the
+    reference's gate lists one for one, and simulate() with those dictionaries the reference's state."""
+    from hybridq_amd.fusion import fuse, simplify
+    from hybridq_amd.simulation import simulate
+    out = str(tmp_path / 'named.npz')
+    _reference(['live_named', out, str(seed)], str(tmp_path))
+    z = np.load(out, allow_pickle=False)
+    assert int(z['n_cases']) == 6
+    n = 12
+    for i in range(int(z['n_cases'])):
+        gates = [(z[f'c{i}_U{j}'], tuple(int(q) for q in z[f'c{i}_q{j}'])) for j in range(int(z[f'c{i}_n_gates']))]
+        named = [g for g, name in zip(gates, z[f'c{i}_names']) if str(name) != 'I']
+        simp = {'use_matrix_commutation': bool(z[f'c{i}_simp_umc'])}
+        comp = {'max_n_qubits': int(z[f'c{i}_comp_n']), 'use_matrix_commutation': bool(z[f'c{i}_comp_umc']),
+                'max_n_qubits_matrix': int(z[f'c{i}_comp_mnm'])}
+        if len(z[f'c{i}_comp_excl']):
+            comp['exclude_qubits'] = [int(q) for q in z[f'c{i}_comp_excl']]
+        s_ours = simplify(named, atol=1e-8, remove_id_gates=True, **simp)
+        assert len(s_ours) == int(z[f'c{i}_s_n']), (seed, i, 'simplify', simp)
+        for j, (U, qs) in enumerate(s_ours):
+            assert tuple(qs) == tuple(int(q) for q in z[f'c{i}_sq{j}']), (seed, i, j, 'simplify')
+            assert np.abs(np.asarray(U) - z[f'c{i}_sU{j}']).max() < 1e-12, (seed, i, j, 'simplify')
+        f_ours = fuse(s_ours, comp['max_n_qubits'], complex_type='complex128', **{k: v for k, v in comp.items() if k != 'max_n_qubits'})
+        assert len(f_ours) == int(z[f'c{i}_f_n']), (seed, i, 'compress', comp)
+        for j, (U, qs) in enumerate(f_ours):
+            assert tuple(qs) == tuple(int(q) for q in z[f'c{i}_fq{j}']), (seed, i, j, 'compress')
+            assert np.abs(np.asarray(U) - z[f'c{i}_fU{j}']).max() < 1e-12, (seed, i, j, 'compress')
+        psi = simulate(named, initial_state=str(z[f'c{i}_init']), optimize='evolution-hybridq', complex_type='complex128',
+                       compress=comp, simplify=simp, qubits=list(range(n)))
+        ref = z[f'c{i}_psi']
+        assert np.abs(psi.reshape(-1) - ref).max() / np.abs(ref).max() < 1e-11, (seed, i)
