@@ -288,6 +288,32 @@ def prepare_state_planes(initial_state, n, float_type, device, placement='tuned'
     return planes
 
 
+def prepare_state(state, d=2, complex_type='complex64'):
+    """``hybridq.circuit.simulation.prepare_state`` (circuit/simulation/utils.py:41-156): the '01+-' product state as a
+    complex numpy array of shape (2,)*n.  Built where every state of this package is built -- by the device kernels
+    behind :func:`prepare_state_planes` -- and brought back; only qubits (d = 2) exist here."""
+    try:
+        state = str(state)
+    except Exception:  # noqa: BLE001
+        raise ValueError("'state' must be convertible to 'str'.")
+    try:
+        dims = (int(d),) * len(state)
+    except TypeError:
+        dims = tuple(int(x) for x in d)
+    if set(state).difference('+-01'):
+        raise ValueError(f"Symbols {set(state).difference('+-01')} are not allowed.")
+    if any(x <= 0 for x in dims):
+        raise ValueError("All dimensions must be positive")
+    if len(dims) != len(state):
+        raise ValueError("Number of qubits and dimensions are not consistent.")
+    if any(x != 2 for x in dims):
+        raise ValueError("Only qubits of dimension 2 are supported.")
+    if not state:
+        raise ValueError("'state' is empty.")
+    n = len(state)
+    return EvolutionState(list(range(n)), complex_type=complex_type, initial_state=state, placement='plain').to_numpy().reshape((2,) * n)
+
+
 class EvolutionState:
     """Split-plane state vector resident in HBM plus the logical->physical qubit map."""
 

@@ -275,3 +275,20 @@ def test_container_gates_against_the_reference_itself(torch_cuda):
     # gates in (they commute with everything: 79, 78, ... here), this driver in circuit order -- tests.py:2030-2034 sorts too
     ours = [int(x.strip()) for x in file.readlines()]
     assert ours == list(range(len(gs))) and sorted(int(x) for x in z['msg_lines']) == ours
+
+
+def test_prepare_state_api(torch_cuda):
+    """hybridq.circuit.simulation.prepare_state (utils.py:41-156) against the arrays the reference returned for the same
+    strings (tests/golden/e2e_api.npz), and its argument errors."""
+    import golden_util as gu
+    from hybridq_amd.simulation import prepare_state
+    z = gu.load('e2e_api.npz')
+    for i, st in enumerate(z['ps_strings']):
+        st = str(st)
+        for ct, tol in (('complex64', 1e-7), ('complex128', 1e-15)):
+            got = prepare_state(st, complex_type=ct)
+            assert got.shape == (2,) * len(st) and got.dtype == np.dtype(ct)
+            assert np.abs(got.reshape(-1) - z[f'ps_{i}']).max() <= tol, (st, ct)
+    for bad, kw in (('01a', {}), ('01', dict(d=3)), ('01', dict(d=[2, 2, 2])), ('0', dict(d=0))):
+        with pytest.raises(ValueError):
+            prepare_state(bad, **kw)

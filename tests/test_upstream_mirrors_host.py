@@ -50,3 +50,7 @@ def test_simulation_2__stochastic(host):
 
 def test_container_gates_against_the_reference_itself(host):
     mirrors.test_container_gates_against_the_reference_itself(None)
+
+
+def test_prepare_state_api(host):
+    mirrors.test_prepare_state_api(None)
