@@ -188,3 +188,19 @@ def test_named_gate_circuits_simplify_and_compress_options(numpy_device, tmp_pat
                        compress=comp, simplify=simp, qubits=list(range(n)))
         ref = z[f'c{i}_psi']
         assert np.abs(psi.reshape(-1) - ref).max() / np.abs(ref).max() < 1e-11, (seed, i)
+
+
+@pytest.mark.skipif(not (os.path.isdir('/root/reference/hybridq') and os.path.exists(os.path.join(REF_CORE, 'hybridq.so'))),
+                    reason='needs /root/reference and oracle/_ref (build container only)')
+def test_reference_gate_objects_through_this_driver(tmp_path):
+    """The drop-in claim for Python users, literally: circuits built from the REFERENCE'S OWN gate objects (named gates with
+    parameters / powers / conj / T, MATRIX gates, string and tuple labels, TupleGates, a StochasticGate under sampling seeds,
+    Projection / Measure FunctionalGates, zero-qubit MessageGates) handed unchanged to hybridq_amd.simulation.simulate give
+    the states hybridq's simulate() gives (tests/reference_objects_worker.py, one process importing both)."""
+    env = dict(os.environ, LD_LIBRARY_PATH=REF_CORE + ':' + os.environ.get('LD_LIBRARY_PATH', ''), PYTHONDONTWRITEBYTECODE='1')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'reference_objects_worker.py')], cwd=str(tmp_path), env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and 'ALL OK' in res.stdout, (res.stdout[-1500:], res.stderr[-2500:])
+    for line in ('named / matrix / powers: ok', 'string / tuple labels: ok', 'tuple / stochastic gates: ok',
+                 'reference FunctionalGates (Projection, Message, Measure): ok'):
+        assert line in res.stdout
