@@ -109,4 +109,19 @@ for s in range(40):  # some seed reproduces the reference's outcome; the collaps
 else:
     raise AssertionError('no outcome of the measurement reproduces the reference state')
 print('reference FunctionalGates (Projection, Message, Measure): ok')
+
+# 5. the reference's noisy SuperCircuit (KrausSuperGate objects) through hybridq_amd.dm.simulate
+import hybridq.dm.circuit.simulation as ref_dm  # noqa: E402
+from hybridq.noise.utils import add_depolarizing_noise  # noqa: E402
+from hybridq_amd import dm  # noqa: E402
+nq = 6
+cq = get_rqc(nq, 24, use_random_indexes=False)
+while len(cq.all_qubits()) != nq:
+    cq = get_rqc(nq, 24, use_random_indexes=False)
+noisy = add_depolarizing_noise(cq, probs=(0.02, 0.05))
+init_q = ''.join(rng.choice(list('01+-'), size=nq))
+r = ref_dm.simulate(noisy, initial_state=init_q, optimize='evolution-hybridq', complex_type='complex128', verbose=False)
+o = dm.simulate(list(noisy), initial_state=init_q, complex_type='complex128', optimize='evolution-hybridq')
+assert np.asarray(o).shape == np.asarray(r).shape and rel(o, r) < 1e-11, rel(o, r)
+print('reference SuperCircuit through dm.simulate: ok')
 print('ALL OK')

@@ -195,12 +195,12 @@ def test_named_gate_circuits_simplify_and_compress_options(numpy_device, tmp_pat
 def test_reference_gate_objects_through_this_driver(tmp_path):
     """The drop-in claim for Python users, literally: circuits built from the REFERENCE'S OWN gate objects (named gates with
     parameters / powers / conj / T, MATRIX gates, string and tuple labels, TupleGates, a StochasticGate under sampling seeds,
-    Projection / Measure FunctionalGates, zero-qubit MessageGates) handed unchanged to hybridq_amd.simulation.simulate give
-    the states hybridq's simulate() gives (tests/reference_objects_worker.py, one process importing both)."""
+    Projection / Measure FunctionalGates, zero-qubit MessageGates, a noisy SuperCircuit of KrausSuperGates) handed unchanged to
+    hybridq_amd.simulation.simulate / hybridq_amd.dm.simulate give the states hybridq's own simulate() functions give (tests/reference_objects_worker.py, one process importing both)."""
     env = dict(os.environ, LD_LIBRARY_PATH=REF_CORE + ':' + os.environ.get('LD_LIBRARY_PATH', ''), PYTHONDONTWRITEBYTECODE='1')
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'reference_objects_worker.py')], cwd=str(tmp_path), env=env,
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and 'ALL OK' in res.stdout, (res.stdout[-1500:], res.stderr[-2500:])
     for line in ('named / matrix / powers: ok', 'string / tuple labels: ok', 'tuple / stochastic gates: ok',
-                 'reference FunctionalGates (Projection, Message, Measure): ok'):
+                 'reference FunctionalGates (Projection, Message, Measure): ok', 'reference SuperCircuit through dm.simulate: ok'):
         assert line in res.stdout
