@@ -282,3 +282,78 @@ def test_sharded_density_matrix_config5_shape(tmp_path):
     rho = np.load(os.path.join(str(tmp_path), 'rho.npy'))
     exp = gu.load('e2e_dm_circuit.npz')['rho']
     assert np.abs(rho - exp).max() / np.abs(exp).max() < 5e-6
+
+
+def _api_worker(rank, world, port, out_dir):
+    """simulate(..., devices=N) / dm.simulate(..., devices=N): the reference-shaped calls, on gloo with the host backend."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import hybridq_amd.dist as hdist
+        import hybridq_amd.simulation as sim
+        from hybridq_amd import dm
+        from hybridq_amd.circuits import random_dense, rqc_1q2q
+        hdist.HipBackend = lambda float_type, placement=None: CpuBackend(float_type)  # the only stand-in: per-shard numerics
+        sim._torch = lambda: None
+        n = 12
+        gates = rqc_1q2q(n, depth=8, seed=3) + random_dense(n, 20, kmax=3, seed=4)
+        init = ('+-01' * n)[:n]
+        results = {}
+        for name, kw in (('auto', {}), ('hybridq', dict(optimize='evolution-hybridq')), ('c0', dict(compress=0)),
+                         ('bits', dict(shard_bits=int(np.log2(world))))):
+            kw = dict(kw)
+            if 'shard_bits' not in kw:
+                kw['devices'] = world
+            psi, info = sim.simulate(gates, initial_state=init, complex_type='complex128', qubits=list(range(n)), return_info=True, **kw)
+            assert info['n_ranks'] == world and info['n_qubits'] == n and info['n_exchanges'] >= 1
+            assert ('schedule' in info) == (name in ('auto', 'bits'))
+            results[name] = psi.reshape(-1)
+        sh = sim.simulate(gates, initial_state=init, complex_type='complex128', qubits=list(range(n)), devices=world,
+                          return_numpy_array=False)
+        results['sharded_object'] = sh.state_numpy().reshape(-1)
+        for bad in (dict(devices=2 * world), dict(devices=world, shard_bits=5)):
+            try:
+                sim.simulate(gates, initial_state=init, qubits=list(range(n)), **bad)
+                raise AssertionError('accepted ' + repr(bad))
+            except (RuntimeError, ValueError):
+                pass
+        try:
+            sim.simulate(gates, initial_state=np.zeros((2,) * n), qubits=list(range(n)), devices=world)
+            raise AssertionError('accepted an array initial state')
+        except NotImplementedError:
+            pass
+        noisy = [(U, qs) for U, qs in random_dense(6, 12, kmax=2, seed=8, unitary=True)]
+        noisy.insert(5, dm.depolarizing((1, 4), 0.1))
+        noisy.append(dm.depolarizing((0,), 0.05))
+        results['rho'] = dm.simulate(noisy, initial_state='0+1-00', complex_type='complex128', devices=world).reshape(-1)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, 'api.npz'), **results)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_simulate_devices_api_over_gloo(tmp_path, world):
+    """The reference-shaped sharded calls end to end on CPU: simulate(devices=N / shard_bits=g) under every schedule keyword,
+    the returned ShardedEvolution, the argument errors, dm.simulate(devices=N) -- against single-process evolutions."""
+    import torch.multiprocessing as mp
+    import oracle
+    from hybridq_amd import dm
+    from hybridq_amd.circuits import random_dense, rqc_1q2q
+    mp.spawn(_api_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out = np.load(os.path.join(str(tmp_path), 'api.npz'))
+    n = 12
+    gates = rqc_1q2q(n, depth=8, seed=3) + random_dense(n, 20, kmax=3, seed=4)
+    exp = oracle.evolve_tensordot(gates, n, initial_state=('+-01' * n)[:n], qubits=list(range(n)))
+    for name in ('auto', 'hybridq', 'c0', 'bits', 'sharded_object'):
+        assert np.abs(out[name] - exp).max() / np.abs(exp).max() < 1e-12, name
+    noisy = [(U, qs) for U, qs in random_dense(6, 12, kmax=2, seed=8, unitary=True)]
+    noisy.insert(5, dm.depolarizing((1, 4), 0.1))
+    noisy.append(dm.depolarizing((0,), 0.05))
+    sv = dm.to_statevector_circuit(noisy)
+    qubits = [(0, q) for q in range(6)] + [(1, q) for q in range(6)]
+    rho = oracle.evolve_tensordot(sv, 12, initial_state='0+1-00' * 2, qubits=qubits)
+    assert np.abs(out['rho'] - rho).max() / np.abs(rho).max() < 1e-12
+    assert abs(np.trace(out['rho'].reshape(64, 64)) - 1) < 1e-12
