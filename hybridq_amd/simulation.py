@@ -72,7 +72,11 @@ def flatten(circuit):
     out = []
     for g in circuit:
         if not isinstance(g, (tuple, list, np.ndarray)) and callable(getattr(g, 'flatten', None)):
-            out.extend(flatten(list(g)))
+            try:
+                inner = list(g)
+            except TypeError:
+                raise RuntimeError(f"'{g}' not supported")  # provides flatten but does not iterate over gates (simulation.py:648-649)
+            out.extend(flatten(inner))
         else:
             out.append(g)
     return out
