@@ -318,6 +318,59 @@ def prepare_state(state, d=2, complex_type='complex64'):
     return EvolutionState(list(range(n)), complex_type=complex_type, initial_state=state, placement='plain').to_numpy().reshape((2,) * n)
 
 
+class _LazySplitState:
+    """What a FunctionalGate on NO qubits receives as `psi` (the reference's MessageGate, extras/gate/gate.py:25-27, prints
+    and hands `psi` back): the (2,) + (2,)*n split array, fetched from the device only if the gate actually looks at it --
+    at n = 30 a round trip of the state is 16 GiB over PCIe, per message.  Anything but identity / shape / dtype queries
+    materialises the host array and behaves like it from then on."""
+
+    def __init__(self, fetch, shape, dtype):
+        self._fetch, self._host = fetch, None
+        self.shape, self.dtype, self.ndim = tuple(shape), np.dtype(dtype), len(shape)
+
+    def materialize(self):
+        if self._host is None:
+            self._host = self._fetch()
+        return self._host
+
+    @property
+    def materialized(self):
+        return self._host is not None
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialize()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, key):
+        return self.materialize()[key]
+
+    def __setitem__(self, key, value):
+        self.materialize()[key] = value
+
+    def __getattr__(self, name):  # every other ndarray attribute or method
+        return getattr(self.materialize(), name)
+
+
+def _apply_host_functional(gate, order, fetch, store, shape, float_type):
+    """The host form of the FunctionalGate branch (simulation.py:525-554): ``gate.apply(psi, order)`` on the split array
+    `fetch()` returns, the result written back with `store(array)`.  A gate on no qubits gets the lazy stand-in above and
+    costs nothing unless it touches the state."""
+    qubits = getattr(gate, 'qubits', None)
+    lazy = _LazySplitState(fetch, shape, float_type) if qubits is not None and len(qubits) == 0 else None
+    psi = lazy if lazy is not None else fetch()
+    new_psi, new_order = gate.apply(psi=psi, order=order)
+    if any(x != y for x, y in zip(order, new_order)):  # :552-554
+        raise RuntimeError("'order' has changed.")
+    if lazy is not None and new_psi is lazy:
+        if not lazy.materialized:
+            return  # the gate never looked: the state on the device is the state
+        new_psi = lazy.materialize()  # looked at, maybe modified in place
+    store(new_psi)
+
+
 class EvolutionState:
     """Split-plane state vector resident in HBM plus the logical->physical qubit map."""
 
@@ -386,12 +439,11 @@ class EvolutionState:
                 new_psi = torch.as_tensor(new_psi, device=self.planes.device).to(self.planes.dtype)
                 self.planes.copy_(new_psi.reshape(2, -1))
             return
-        new_psi, new_order = gate.apply(psi=self.to_split_array(), order=order)
-        if any(x != y for x, y in zip(order, new_order)):  # :552-554
-            raise RuntimeError("'order' has changed.")
-        new_psi = np.ascontiguousarray(new_psi, dtype=self.float_type).reshape(2, -1)
-        for p in (0, 1):
-            _from_host(new_psi[p], self.planes[p])
+        def store(new_psi):
+            new_psi = np.ascontiguousarray(new_psi, dtype=self.float_type).reshape(2, -1)
+            for p in (0, 1):
+                _from_host(new_psi[p], self.planes[p])
+        _apply_host_functional(gate, order, self.to_split_array, store, (2,) + (2,) * self.n, self.float_type)
 
     def to_split_array(self):
         """The state on the host in the reference's own working layout: a real array of shape (2,) + (2,)*n, [0] = real

@@ -37,11 +37,15 @@ def install(setattr_fn):
                 gate.apply_device(self)
                 return
             order = tuple(self.qubits)
-            host = np.stack([self.psi.real, self.psi.imag]).reshape((2,) + (2,) * self.n)
-            new_psi, new_order = gate.apply(psi=host, order=order)
-            assert tuple(new_order) == order
-            new_psi = np.asarray(new_psi).reshape(2, -1)
-            self.psi = new_psi[0] + 1j * new_psi[1]
+            shape = (2,) + (2,) * self.n
+
+            def fetch():
+                return np.stack([self.psi.real, self.psi.imag]).reshape(shape)
+
+            def store(new_psi):
+                new_psi = np.asarray(new_psi).reshape(2, -1)
+                self.psi = new_psi[0] + 1j * new_psi[1]
+            sim._apply_host_functional(gate, order, fetch, store, shape, np.float64)  # the product's own host branch
 
         def to_numpy(self):
             return self.psi.astype(self.complex_type)

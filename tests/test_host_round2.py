@@ -318,3 +318,56 @@ def test_gate_loop_positions_and_stream_binding(monkeypatch):
     assert calls == [('U', 're', 'im', 'U0', [2, 4], 5), ('F', 'probe'), ('U', 're', 'im', 'U1', [0], 5),
                      ('B', 're', 'im', [0, 1, 2], 5), ('U', 're', 'im', 'U2', [3, 0], 5)]
     assert binds == [0, 2]
+
+
+def test_functional_gate_on_no_qubits_does_not_move_the_state():
+    """_apply_host_functional: a FunctionalGate with qubits = () (the reference's MessageGate) receives a lazy stand-in of the
+    split array; the state is fetched -- and written back -- only if the gate touches it."""
+    from hybridq_amd.simulation import _apply_host_functional
+    n = 4
+    host = np.arange(2 << n, dtype=np.float32).reshape((2,) + (2,) * n)
+    calls = {'fetch': 0, 'store': []}
+
+    def fetch():
+        calls['fetch'] += 1
+        return host.copy()
+
+    def store(a):
+        calls['store'].append(np.array(a, copy=True))
+
+    order = tuple(range(n))
+
+    class Msg:
+        qubits = ()
+
+        def __init__(self, f):
+            self.f = f
+
+        def apply(self, psi, order):
+            return self.f(psi), order
+
+    run = lambda g: _apply_host_functional(g, order, fetch, store, host.shape, np.float32)  # noqa: E731
+    run(Msg(lambda psi: psi))  # prints and hands psi back: nothing moves
+    assert calls == {'fetch': 0, 'store': []}
+    seen = {}
+    run(Msg(lambda psi: seen.setdefault('shape', (psi.shape, psi.ndim, psi.dtype, len(psi))) and psi))  # metadata is free
+    assert calls['fetch'] == 0 and seen['shape'] == (host.shape, n + 1, np.dtype('float32'), 2)
+    run(Msg(lambda psi: seen.setdefault('norm', float(np.linalg.norm(np.asarray(psi).ravel()))) and psi))  # looks: one fetch, stored back
+    assert calls['fetch'] == 1 and len(calls['store']) == 1 and np.array_equal(calls['store'][0].reshape(host.shape), host)
+    assert seen['norm'] == pytest.approx(float(np.linalg.norm(host.ravel())))
+
+    def scale(psi):
+        psi[0] *= 2  # in place through the stand-in
+        return psi
+    run(Msg(scale))
+    assert calls['fetch'] == 2 and np.array_equal(calls['store'][1].reshape(host.shape)[0], 2 * host[0])
+    run(Msg(lambda psi: psi.sum() * 0 + np.ones_like(host)))  # a new array comes back
+    assert calls['fetch'] == 3 and np.array_equal(calls['store'][2].reshape(host.shape), np.ones_like(host))
+
+    class OnQubit(Msg):
+        qubits = (1,)
+    run(OnQubit(lambda psi: psi))  # a gate ON qubits always gets the real array and is stored back (it may have changed it)
+    assert calls['fetch'] == 4 and len(calls['store']) == 4
+    with pytest.raises(RuntimeError, match='order'):
+        _apply_host_functional(type('G', (), {'qubits': (), 'apply': lambda self, psi, order: (psi, order[::-1])})(), order, fetch, store,
+                               host.shape, np.float32)
