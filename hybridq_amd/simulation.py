@@ -762,6 +762,11 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     counterpart of circuit/utils.py:825) slides commuting gates and cancels inverse pairs before
     fusion; a dict passes ``use_matrix_commutation`` / ``max_n_qubits_matrix`` on.
     """
+    if isinstance(optimize, str) and optimize.startswith('evolution-einsum'):
+        # the reference's numpy.einsum engine for the same evolution (simulation.py:676-760; its own tests ask for it,
+        # tests.py:2098-2102): no separate engine here -- the HIP core evaluates it, with the reference core's schedule
+        warn(f"optimize={optimize!r}: hybridq_amd has one evolution engine; running on the HIP core.")
+        optimize = 'evolution-hybridq'
     if optimize not in ('evolution', 'evolution-hybridq', 'evolution-hip'):
         raise ValueError(f"hybridq_amd only implements optimize='evolution' (got {optimize!r})")
     kwargs.setdefault('return_info', False)

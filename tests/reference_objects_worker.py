@@ -110,6 +110,32 @@ else:
     raise AssertionError('no outcome of the measurement reproduces the reference state')
 print('reference FunctionalGates (Projection, Message, Measure): ok')
 
+# 4b. tests.py:2037-2110 (test_simulation_2__fn): half of the gates turned into the reference's FunctionalGates that call the
+# reference's own dot() on the split array they are handed -- here that array comes from this driver
+from hybridq.utils.dot import dot as ref_dot  # noqa: E402
+
+
+def as_fn(gate):
+    qubits, U = gate.qubits, gate.matrix()
+
+    def f(self, psi, order):
+        if not isinstance(psi, np.ndarray):
+            raise ValueError("Only 'numpy.ndarray' are supported.")
+        axes = [next(i for i, y in enumerate(order) if y == x) for x in qubits]
+        return ref_dot(a=U, b=psi, axes_b=axes, b_as_complex_array=psi.ndim > len(order), inplace=True), order
+    return Gate('fn', qubits=qubits, f=f)
+
+
+mixed = [as_fn(g) if rng.random() < 0.5 else g for g in base]
+r = ref_simulate(Circuit(base), initial_state=init, optimize='evolution-hybridq', complex_type='complex64')
+for opt in ('evolution-hybridq', 'evolution-einsum', 'evolution'):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        o = simulate(mixed, initial_state=init, optimize=opt, complex_type='complex64')
+    assert rel(o, r) < 2e-5, (opt, rel(o, r))
+print('reference FunctionalGates calling the reference dot(): ok')
+
 # 5. the reference's noisy SuperCircuit (KrausSuperGate objects) through hybridq_amd.dm.simulate
 import hybridq.dm.circuit.simulation as ref_dm  # noqa: E402
 from hybridq.noise.utils import add_depolarizing_noise  # noqa: E402

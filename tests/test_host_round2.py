@@ -371,3 +371,22 @@ def test_functional_gate_on_no_qubits_does_not_move_the_state():
     with pytest.raises(RuntimeError, match='order'):
         _apply_host_functional(type('G', (), {'qubits': (), 'apply': lambda self, psi, order: (psi, order[::-1])})(), order, fetch, store,
                                host.shape, np.float32)
+
+
+def test_evolution_einsum_alias_runs_on_the_one_engine(monkeypatch):
+    """optimize='evolution-einsum' (the reference's numpy engine for the same evolution, asked for by its own tests,
+    tests.py:2098-2102) is accepted: a warning, then the reference core's schedule on the HIP core."""
+    import hybridq_amd.simulation as sim
+    seen = {}
+
+    def fake_plan(circuit, qubits, n, ctype, compress, blocked):
+        seen['compress'], seen['blocked'] = compress, blocked
+        raise RuntimeError('stop before the device')
+    monkeypatch.setattr(sim, '_plan_ops', fake_plan)
+    for opt in ('evolution-einsum', 'evolution-einsum-greedy'):
+        with pytest.warns(UserWarning, match='one evolution engine'):
+            with pytest.raises(RuntimeError, match='stop before'):
+                sim.simulate([(np.eye(2), (0,)), (np.eye(2), (1,))], initial_state='00', optimize=opt, simplify=False)
+        assert seen == {'compress': 4, 'blocked': False}  # not the automatic schedule: the reference's default
+    with pytest.raises(ValueError, match="only implements optimize='evolution'"):
+        sim.simulate([(np.eye(2), (0,))], initial_state='0', optimize='tn')

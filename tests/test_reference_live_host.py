@@ -202,5 +202,6 @@ def test_reference_gate_objects_through_this_driver(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and 'ALL OK' in res.stdout, (res.stdout[-1500:], res.stderr[-2500:])
     for line in ('named / matrix / powers: ok', 'string / tuple labels: ok', 'tuple / stochastic gates: ok',
-                 'reference FunctionalGates (Projection, Message, Measure): ok', 'reference SuperCircuit through dm.simulate: ok'):
+                 'reference FunctionalGates (Projection, Message, Measure): ok', 'reference FunctionalGates calling the reference dot(): ok',
+                 'reference SuperCircuit through dm.simulate: ok'):
         assert line in res.stdout
