@@ -13,7 +13,7 @@ no CPU fallback anywhere in the product path.
 import importlib
 
 __version__ = '0.1.0'
-_SUBMODULES = ('core', 'simulation', 'circuits', 'build', 'dist', 'fusion', 'dot', 'transpose', 'dm', 'qasm', 'functional', 'blocking')
+_SUBMODULES = ('core', 'simulation', 'circuits', 'build', 'dist', 'fusion', 'dot', 'transpose', 'dm', 'qasm', 'functional', 'blocking', 'aligned')
 
 
 def __getattr__(name):
