@@ -769,6 +769,10 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
         optimize = 'evolution-hybridq'
     if optimize not in ('evolution', 'evolution-hybridq', 'evolution-hip'):
         raise ValueError(f"hybridq_amd only implements optimize='evolution' (got {optimize!r})")
+    if tensor_only:  # simulation.py:226-228
+        raise ValueError(f"'tensor_only' is not support for optimize={optimize}")
+    if use_mpi:  # simulation.py:379-380 warns and carries on: so does this driver (sharding is `devices=`, not MPI)
+        warn("Detected MPI but optimize='evolution' does not support MPI.")
     kwargs.setdefault('return_info', False)
     kwargs.setdefault('return_numpy_array', True)
     kwargs.setdefault('max_largest_intermediate', 2**36)

@@ -282,6 +282,8 @@ def test_simulate_argument_errors_precede_device_work():
         simulate(gates, initial_state='0', qubits=q, max_largest_intermediate=2**11)
     with pytest.raises(ValueError, match="only implements optimize='evolution'"):
         simulate(gates, initial_state='0', optimize='tn')
+    with pytest.raises(ValueError, match="'tensor_only' is not support"):  # simulation.py:226-228
+        simulate(gates, initial_state='0', qubits=q, tensor_only=True)
 
 
 def test_simulate_checks_compress_before_the_device():
