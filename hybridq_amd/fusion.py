@@ -80,9 +80,15 @@ def _sorted_union(a, b):
         return sorted(s, key=lambda q: (type(q).__name__, q))
 
 
-def commute(U1, q1, U2, q2, atol=1e-7):
+#: the tolerance of ``PowerMatrixGate.commutes_with``: its `atol` argument is not what decides -- the comparison is
+#: ``np.allclose(P1, P2, atol=1e-5)`` whatever the caller passes (hybridq/gate/property.py:573), for compress and simplify alike
+_COMMUTE_ATOL = 1e-5
+
+
+def commute(U1, q1, U2, q2, atol=None):
     """True if the two gates commute (trivially when they share no qubit); mirrors
-    ``PowerMatrixGate.commutes_with`` (hybridq/gate/property.py:498-580, default atol)."""
+    ``PowerMatrixGate.commutes_with`` (hybridq/gate/property.py:498-580), whose tolerance is fixed (`atol` is accepted and,
+    as there, not used)."""
     if not set(q1) & set(q2):
         return True
     Q = _sorted_union(q1, q2)
@@ -91,23 +97,28 @@ def commute(U1, q1, U2, q2, atol=1e-7):
     # test's: it needs EVERY entry to pass), for O(D^2) instead of two D^3 products -- which the planners otherwise pay
     # a thousand times per circuit, each a threaded BLAS call on a matrix too small for it
     r_ab, r_ba = A[0] @ B, B[0] @ A
-    if not (np.abs(r_ab - r_ba) <= atol + 1e-5 * np.abs(r_ba)).all():
+    if not (np.abs(r_ab - r_ba) <= _COMMUTE_ATOL + 1e-5 * np.abs(r_ba)).all():
         return False
     AB, BA = A @ B, B @ A
-    return bool((np.abs(AB - BA) <= atol + 1e-5 * np.abs(BA)).all())  # np.allclose's test without its bookkeeping
+    return bool((np.abs(AB - BA) <= _COMMUTE_ATOL + 1e-5 * np.abs(BA)).all())  # np.allclose's test without its bookkeeping
 
 
 class _Layer:
-    __slots__ = ('gates', 'qubits', 'U', 'compress')
+    __slots__ = ('gates', 'qubits', 'U', 'compress', 'has_matrix')
 
-    def __init__(self, U, qs, compress=True):
+    def __init__(self, U, qs, compress=True, has_matrix=True):
         self.gates = [(U, qs)]
         self.qubits = _sorted_union(qs, ())
         self.U = _embed(U, qs, self.qubits)
         self.compress = compress  # False: nothing may be merged into this layer (utils.py:615-617)
+        # the reference keeps a layer's matrix for its commutation tests only while the layer spans at most
+        # max_n_qubits_matrix qubits, and never gets it back afterwards (utils.py:660-669); the fused matrix `U` itself is
+        # always kept here -- it is the output
+        self.has_matrix = has_matrix
 
-    def merge(self, U, qs):
+    def merge(self, U, qs, has_matrix=True):
         self.gates.append((U, qs))
+        self.has_matrix = self.has_matrix and has_matrix
         Q = _sorted_union(self.qubits, qs)
         # the new gate acts AFTER everything already in the layer
         self.U = _embed(U, qs, Q) @ _embed(self.U, self.qubits, Q)
@@ -121,6 +132,8 @@ def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matr
         q = set(qs)
         can = not (q & exclude)  # gates on `exclude_qubits` are never compressed (utils.py:615-617)
         merge_to = len(layers)
+        # the gate's own matrix takes part in commutation tests only if the gate is small enough (utils.py:606-611)
+        gate_matrix = use_matrix_commutation and len(q) <= max_n_qubits_matrix
         for i in range(len(layers) - 1, -1, -1):
             L = layers[i]
             cq = set(L.qubits)
@@ -129,13 +142,15 @@ def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matr
             if use_matrix_commutation:  # utils.py:633-646
                 if not (q & cq):
                     continue
-                if len(q | cq) <= max_n_qubits_matrix and commute(U, qs, L.U, L.qubits, atol):
+                # both matrices must exist; the size of their UNION is not limited (commutes_with builds the product)
+                if gate_matrix and L.has_matrix and commute(U, qs, L.U, L.qubits, atol):
                     continue
             break
         if merge_to < len(layers):
-            layers[merge_to].merge(U, qs)
+            L = layers[merge_to]
+            L.merge(U, qs, has_matrix=gate_matrix and len(q | set(L.qubits)) <= max_n_qubits_matrix)  # utils.py:660-669
         else:
-            layers.append(_Layer(U, qs, can))
+            layers.append(_Layer(U, qs, can, has_matrix=gate_matrix))
     return layers
 
 
