@@ -584,7 +584,11 @@ def live_cases(path, seed):
         compress = int(rng.choice([0, 2, 4, 6]))
         simplify = bool(rng.integers(0, 2))
         ctype = 'complex128' if i % 3 else 'complex64'
-        psi = simulate(c, initial_state=init, optimize='evolution-hybridq', complex_type=ctype, compress=compress, simplify=simplify)
+        try:
+            psi = simulate(c, initial_state=init, optimize='evolution-hybridq', complex_type=ctype, compress=compress, simplify=simplify)
+        except ValueError as e:  # "Active qubits have changed after simplification": a qubit lost its only gates; next circuit
+            print('case skipped:', e)
+            continue
         out[f'c{i}_n_gates'] = len(c)
         for j, g in enumerate(c):
             out[f'c{i}_U{j}'] = np.asarray(g.matrix(), dtype=np.complex128)
@@ -769,6 +773,9 @@ def live_named_cases(path, seed):
             elif r < 0.88:
                 a, b = (int(x) for x in rng.permutation(n)[:2])
                 gates.append(Gate('CPHASE', qubits=[a, b], params=[float(rng.uniform(-3, 3))]))
+            elif r < 0.92:  # a random diagonal gate on three qubits: commutes with every other diagonal gate
+                qs = [int(x) for x in rng.permutation(n)[:3]]
+                gates.append(Gate('MATRIX', qubits=qs, U=np.diag(np.exp(1j * rng.uniform(-3, 3, size=8)))))
             else:  # an inverse pair with something commuting (or not) in between
                 a, b = (int(x) for x in rng.permutation(n)[:2])
                 g = Gate(str(rng.choice(['CX', 'ISWAP', 'CZ'])), qubits=[a, b])
@@ -780,8 +787,10 @@ def live_named_cases(path, seed):
         qubits = c.all_qubits()
         assert qubits == list(range(n))
         simp = {'use_matrix_commutation': bool(rng.integers(0, 2))}
-        comp = {'max_n_qubits': int(rng.choice([2, 3, 4, 5])), 'use_matrix_commutation': bool(rng.integers(0, 2)),
-                'max_n_qubits_matrix': int(rng.choice([4, 10]))}
+        if rng.random() < 0.5:
+            simp['max_n_qubits_matrix'] = int(rng.choice([1, 2, 10]))
+        comp = {'max_n_qubits': int(rng.choice([2, 3, 4, 5, 6])), 'use_matrix_commutation': bool(rng.integers(0, 2)),
+                'max_n_qubits_matrix': int(rng.choice([1, 2, 3, 4, 10]))}
         if rng.random() < 0.5:
             comp['exclude_qubits'] = [int(x) for x in rng.permutation(n)[:2]]
         init = ''.join(rng.choice(list('01+-'), size=n))
@@ -792,6 +801,7 @@ def live_named_cases(path, seed):
         out[f'c{i}_names'] = np.array([g.name for g in c])
         out[f'c{i}_init'] = np.array(init)
         out[f'c{i}_simp_umc'] = simp['use_matrix_commutation']
+        out[f'c{i}_simp_mnm'] = simp.get('max_n_qubits_matrix', -1)
         out[f'c{i}_comp_n'] = comp['max_n_qubits']
         out[f'c{i}_comp_umc'] = comp['use_matrix_commutation']
         out[f'c{i}_comp_mnm'] = comp['max_n_qubits_matrix']

@@ -29,6 +29,8 @@ def test_random_circuits_and_options_against_the_reference(numpy_device, tmp_pat
     z = np.load(out, allow_pickle=False)
     assert int(z['n_cases']) == 10
     for i in range(int(z['n_cases'])):
+        if f'c{i}_n_gates' not in z.files:  # the reference itself refused this circuit (active qubits changed)
+            continue
         gates = [(z[f'c{i}_U{j}'], tuple(int(q) for q in z[f'c{i}_q{j}'])) for j in range(int(z[f'c{i}_n_gates']))]
         n, ctype = int(z[f'c{i}_n']), str(z[f'c{i}_ctype'])
         psi = simulate(gates, initial_state=str(z[f'c{i}_init']), optimize='evolution-hybridq', complex_type=ctype,
@@ -170,6 +172,8 @@ def test_named_gate_circuits_simplify_and_compress_options(numpy_device, tmp_pat
         gates = [(z[f'c{i}_U{j}'], tuple(int(q) for q in z[f'c{i}_q{j}'])) for j in range(int(z[f'c{i}_n_gates']))]
         named = [g for g, name in zip(gates, z[f'c{i}_names']) if str(name) != 'I']
         simp = {'use_matrix_commutation': bool(z[f'c{i}_simp_umc'])}
+        if int(z[f'c{i}_simp_mnm']) >= 0:
+            simp['max_n_qubits_matrix'] = int(z[f'c{i}_simp_mnm'])
         comp = {'max_n_qubits': int(z[f'c{i}_comp_n']), 'use_matrix_commutation': bool(z[f'c{i}_comp_umc']),
                 'max_n_qubits_matrix': int(z[f'c{i}_comp_mnm'])}
         if len(z[f'c{i}_comp_excl']):
