@@ -210,8 +210,8 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', m
             chosen = _best_fusion_order(chosen, gq, fusion_orders, random.Random(seed * 7919 + len(ops)))
             # an inner gate costs about the same for k <= 3 and 1.9x that for k = 4 (INNER_COST): fuse to 3 qubits,
             # then let a second round merge neighbours into 4-qubit gates and keep it where that is cheaper
-            inner = fuse([gates[gi] for gi in chosen], 3, complex_type=complex_type)
-            wider = fuse(inner, 4, complex_type=complex_type)
+            inner = fuse([gates[gi] for gi in chosen], 3, complex_type=complex_type, exact_commutation=True)
+            wider = fuse(inner, 4, complex_type=complex_type, exact_commutation=True)
 
             def cost(gl):  # a pass whose operand + address tables overflow the LDS left beside the tile runs the
                 c = sum(INNER_COST[len(qs)] for _, qs in gl)  # slower global-memory variant of every gate
@@ -219,7 +219,7 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', m
             if cost(wider) < cost(inner):
                 inner = wider
         elif inner_max:
-            inner = fuse([gates[gi] for gi in chosen], inner_max, complex_type=complex_type)
+            inner = fuse([gates[gi] for gi in chosen], inner_max, complex_type=complex_type, exact_commutation=True)
         else:
             inner = [(np.asarray(gates[gi][0]), gq[gi]) for gi in chosen]
         ops.append(('B', np.asarray(sorted(S), dtype=np.uint32),

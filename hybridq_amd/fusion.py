@@ -85,10 +85,12 @@ def _sorted_union(a, b):
 _COMMUTE_ATOL = 1e-5
 
 
-def commute(U1, q1, U2, q2, atol=None):
+def commute(U1, q1, U2, q2, atol=None, exact=False):
     """True if the two gates commute (trivially when they share no qubit); mirrors
     ``PowerMatrixGate.commutes_with`` (hybridq/gate/property.py:498-580), whose tolerance is fixed (`atol` is accepted and,
-    as there, not used)."""
+    as there, not used).  ``exact=True``: only gates that commute to rounding (1e-12) count -- for this package's own
+    schedules, which have no reference behaviour to reproduce: reordering gates that commute only within 1e-5 moves the
+    final state by as much (seen live: 6e-6 on a noisy circuit, in the reference's compress=0 run just as here)."""
     if not set(q1) & set(q2):
         return True
     Q = _sorted_union(q1, q2)
@@ -96,11 +98,12 @@ def commute(U1, q1, U2, q2, atol=None):
     # one row of the commutator first: generic gates that share a qubit fail right here (the verdict is the full
     # test's: it needs EVERY entry to pass), for O(D^2) instead of two D^3 products -- which the planners otherwise pay
     # a thousand times per circuit, each a threaded BLAS call on a matrix too small for it
+    a_tol, r_tol = (1e-12, 1e-12) if exact else (_COMMUTE_ATOL, 1e-5)
     r_ab, r_ba = A[0] @ B, B[0] @ A
-    if not (np.abs(r_ab - r_ba) <= _COMMUTE_ATOL + 1e-5 * np.abs(r_ba)).all():
+    if not (np.abs(r_ab - r_ba) <= a_tol + r_tol * np.abs(r_ba)).all():
         return False
     AB, BA = A @ B, B @ A
-    return bool((np.abs(AB - BA) <= _COMMUTE_ATOL + 1e-5 * np.abs(BA)).all())  # np.allclose's test without its bookkeeping
+    return bool((np.abs(AB - BA) <= a_tol + r_tol * np.abs(BA)).all())  # np.allclose's test without its bookkeeping
 
 
 class _Layer:
@@ -125,7 +128,7 @@ class _Layer:
         self.qubits = Q
 
 
-def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits=()):
+def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits=(), exact_commutation=False):
     layers = []
     exclude = set(exclude_qubits or ())
     for U, qs in gates:
@@ -143,7 +146,7 @@ def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matr
                 if not (q & cq):
                     continue
                 # both matrices must exist; the size of their UNION is not limited (commutes_with builds the product)
-                if gate_matrix and L.has_matrix and commute(U, qs, L.U, L.qubits, atol):
+                if gate_matrix and L.has_matrix and commute(U, qs, L.U, L.qubits, atol, exact=exact_commutation):
                     continue
             break
         if merge_to < len(layers):
@@ -178,14 +181,15 @@ def to_matrix_gate(layer, complex_type='complex64'):
 
 
 def fuse(gates, max_n_qubits=4, complex_type='complex64', use_matrix_commutation=True,
-         max_n_qubits_matrix=10, atol=1e-7, exclude_qubits=None):
+         max_n_qubits_matrix=10, atol=1e-7, exclude_qubits=None, exact_commutation=False):
     """compress + to_matrix_gate in one go: the fused gate stream ``_simulate_evolution``
     hands to the core (simulation.py:436-454).  Layer matrices are accumulated in
     complex128 and cast once."""
     gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
     if max_n_qubits is None or max_n_qubits <= 0:
         return [(U.astype(complex_type), qs) for U, qs in gates]
-    layers = _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits)
+    layers = _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits,
+                           exact_commutation)
     return [(L.U.astype(complex_type), tuple(L.qubits)) for L in layers]
 
 
