@@ -18,6 +18,7 @@ def _order(a):
     return ('C' if a.flags.c_contiguous else '') + ('F' if a.flags.f_contiguous else '')
 
 
+@pytest.mark.filterwarnings('ignore')  # complex -> real and float -> int casts of random data, as in the reference's test
 @pytest.mark.parametrize('order', 'CF')
 @pytest.mark.parametrize('alignment', [16, 32, 64, 128])
 def test_utils__aligned_array(order, alignment):
