@@ -46,15 +46,19 @@ static Shard& shard() {
 static int load_rccl(Shard& sh) {
   if (sh.api.lib) return 0;
   std::vector<std::string> names;
-  if (const char* e = getenv("HQ_RCCL_LIBRARY")) names.push_back(e);
-  names.insert(names.end(), {"librccl.so.1", "librccl.so"});
+  const char* named = getenv("HQ_RCCL_LIBRARY");  // a library named by the user is the only candidate
+  if (named && *named) names.push_back(named);
+  else names.insert(names.end(), {"librccl.so.1", "librccl.so"});
   void* h = nullptr;
   // the copy already mapped by the process first (torch bundles its own librccl next to its own HIP
   // runtime: a second RCCL on another runtime could not see this process's allocations)
   for (const auto& nm : names) if (!h) h = dlopen(nm.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
   for (const auto& nm : names) if (!h) h = dlopen(nm.c_str(), RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) return fail(std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"));
+  if (!h && !(named && *named)) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) {
+    const char* err = dlerror();  // one call: dlerror() clears the message it returns
+    return fail(std::string("cannot load librccl: ") + (err ? err : "?"));
+  }
   RcclApi& a = sh.api;
   a.lib = h;
 #define HQ_SYM(field, name)                                                         \

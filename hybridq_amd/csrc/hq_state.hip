@@ -290,13 +290,20 @@ struct StateAlloc {
   Vmm vmm;            // tuned placements
   void* plain = nullptr;  // hipMalloc placements
   double probe_ms = 0;
-  std::string layout, report;
+  std::string layout, report;  // the report is the search's record and never changes afterwards
+  bool from_pool = false;      // added to the report only when it is emitted (hq_state_info)
   std::vector<size_t> vmm_order_used;  // granule -> virtual slot of the mapping in use
 };
 struct StatePool {
   std::vector<StateAlloc> live, idle;
   std::string last_report = "{}";
+  bool last_from_pool = false;
 };
+static std::string emit_report(const std::string& report, bool from_pool) {
+  const size_t close = report.rfind('}');
+  if (!from_pool || close == std::string::npos) return report;
+  return report.substr(0, close) + (close > 1 ? ", " : "") + "\"from_pool\": true}";
+}
 static StatePool& state_pool() { static StatePool p; return p; }
 
 static void state_release(StateAlloc& st) {
@@ -379,6 +386,7 @@ static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void**
     *out_im = s.im;
     pool.live.push_back(s);
     pool.last_report = s.report;
+    pool.last_from_pool = s.from_pool;
     return 0;
   };
   if (!tuned) {
@@ -403,7 +411,7 @@ static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void**
       if (pool.idle[i].n == n && pool.idle[i].float_bits == (unsigned)float_bits) {
         st = pool.idle[i];
         pool.idle.erase(pool.idle.begin() + (long)i);
-        st.report = st.report.substr(0, st.report.rfind('}')) + ", \"from_pool\": true}";
+        st.from_pool = true;
         return finish(st);
       }
   // placements of other sizes are released first: the pool must never be what makes a new state not fit
@@ -661,16 +669,21 @@ int hq_state_info(const void* psi_re, char* buf, uint64_t cap) {
   hq::Context& c = hq::ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   const std::string* txt = &hq::state_pool().last_report;
+  bool from_pool = hq::state_pool().last_from_pool;
   if (psi_re) {
     txt = nullptr;
     for (const auto& st : hq::state_pool().live)
-      if (st.re == psi_re) txt = &st.report;
+      if (st.re == psi_re) { txt = &st.report; from_pool = st.from_pool; }
     if (!txt) return hq::fail("hq_state_info: not a state of this library");
   }
   if (!buf || cap == 0) return hq::fail("hq_state_info: no buffer");
-  const size_t k = std::min<size_t>(txt->size(), (size_t)cap - 1);
-  memcpy(buf, txt->data(), k);
-  buf[k] = 0;
+  const std::string out = hq::emit_report(*txt, from_pool);
+  // a report that does not fit is replaced by a valid stub, never cut in the middle of the JSON text
+  const std::string stub = "{\"truncated\": true}";
+  const std::string& use = out.size() + 1 <= (size_t)cap ? out : stub;
+  if (use.size() + 1 > (size_t)cap) return hq::fail("hq_state_info: buffer too small");
+  memcpy(buf, use.data(), use.size());
+  buf[use.size()] = 0;
   return 0;
 }
 

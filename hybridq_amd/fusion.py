@@ -88,9 +88,10 @@ _COMMUTE_ATOL = 1e-5
 def commute(U1, q1, U2, q2, atol=None, exact=False):
     """True if the two gates commute (trivially when they share no qubit); mirrors
     ``PowerMatrixGate.commutes_with`` (hybridq/gate/property.py:498-580), whose tolerance is fixed (`atol` is accepted and,
-    as there, not used).  ``exact=True``: only gates that commute to rounding (1e-12) count -- for this package's own
-    schedules, which have no reference behaviour to reproduce: reordering gates that commute only within 1e-5 moves the
-    final state by as much (seen live: 6e-6 on a noisy circuit, in the reference's compress=0 run just as here)."""
+    as there, not used).  ``exact``: only gates that commute to rounding count (``True``: 1e-12; a float: that absolute
+    and relative tolerance -- see :func:`exact_tolerance`) -- for this package's own schedules, which have no reference
+    behaviour to reproduce: reordering gates that commute only within 1e-5 moves the final state by as much (seen live:
+    6e-6 on a noisy circuit, in the reference's compress=0 run just as here)."""
     if not set(q1) & set(q2):
         return True
     Q = _sorted_union(q1, q2)
@@ -98,12 +99,24 @@ def commute(U1, q1, U2, q2, atol=None, exact=False):
     # one row of the commutator first: generic gates that share a qubit fail right here (the verdict is the full
     # test's: it needs EVERY entry to pass), for O(D^2) instead of two D^3 products -- which the planners otherwise pay
     # a thousand times per circuit, each a threaded BLAS call on a matrix too small for it
-    a_tol, r_tol = (1e-12, 1e-12) if exact else (_COMMUTE_ATOL, 1e-5)
+    if exact:
+        a_tol = r_tol = 1e-12 if exact is True else float(exact)
+    else:
+        a_tol, r_tol = _COMMUTE_ATOL, 1e-5
     r_ab, r_ba = A[0] @ B, B[0] @ A
     if not (np.abs(r_ab - r_ba) <= a_tol + r_tol * np.abs(r_ba)).all():
         return False
     AB, BA = A @ B, B @ A
     return bool((np.abs(AB - BA) <= a_tol + r_tol * np.abs(BA)).all())  # np.allclose's test without its bookkeeping
+
+
+def exact_tolerance(gates):
+    """The "commutes to rounding" tolerance for a gate list: 1e-12 for double-precision matrices; 8 eps(float32) = 9.5e-7
+    as soon as one matrix is given in single precision -- the commutator of two such gates that commute mathematically is
+    ~sqrt(D) eps = 2-5e-7, and the stricter bound would silently stop the planner from sliding them, while
+    anything above stays below the 1e-6 bar of complex64 parity."""
+    single = any(np.asarray(U).dtype in (np.dtype('complex64'), np.dtype('float32'), np.dtype('float16')) for U, _ in gates)
+    return 8 * float(np.finfo(np.float32).eps) if single else 1e-12
 
 
 class _Layer:
@@ -188,6 +201,8 @@ def fuse(gates, max_n_qubits=4, complex_type='complex64', use_matrix_commutation
     gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
     if max_n_qubits is None or max_n_qubits <= 0:
         return [(U.astype(complex_type), qs) for U, qs in gates]
+    if exact_commutation is True:
+        exact_commutation = exact_tolerance(gates)
     layers = _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits,
                            exact_commutation)
     return [(L.U.astype(complex_type), tuple(L.qubits)) for L in layers]

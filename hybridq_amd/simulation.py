@@ -146,8 +146,21 @@ def alloc_planes(n, torch_dtype, device, vmm=True):
         except Exception as e:  # noqa: BLE001 -- the driver refused (fragmented HBM, VMM unavailable): torch's allocator
             warn(f'hybridq_amd: tuned state placement failed ({e!r}); using torch.empty')
             core.state_pool_trim()
-    raw = torch.empty((2, stride), dtype=torch_dtype, device=device)
+    raw = device_empty((2, stride), dtype=torch_dtype, device=device)
     return raw[:, :1 << n]
+
+
+def device_empty(shape, dtype, device=None):
+    """``torch.empty`` on the device that gives the library's idle state pool back before it gives up: hq_free_state
+    keeps one tuned placement per state size mapped (8-128 GiB at n = 30-34) where torch's caching allocator cannot see
+    it, so a large torch allocation may fail while a pooled state sits idle."""
+    torch = _torch()
+    try:
+        return torch.empty(shape, dtype=dtype, device=device)
+    except torch.OutOfMemoryError:
+        core.state_pool_trim()
+        torch.cuda.empty_cache()
+        return torch.empty(shape, dtype=dtype, device=device)
 
 
 #: States of at least this many bytes are copied to the host in 128 MiB chunks through a ring of page-locked staging
@@ -280,7 +293,7 @@ def prepare_state_planes(initial_state, n, float_type, device, placement='tuned'
     if psi.size * ctype.itemsize >= CHUNKED_RETURN_MIN_BYTES:
         # large arrays: one chunked upload of the complex amplitudes, split into the planes on the device (the host
         # would spend longer extracting .real / .imag than the whole transfer takes)
-        dev = torch.empty(psi.size, dtype=torch.complex64 if ctype == np.dtype('complex64') else torch.complex128,
+        dev = device_empty(psi.size, dtype=torch.complex64 if ctype == np.dtype('complex64') else torch.complex128,
                           device=planes.device)
         _from_host(np.ascontiguousarray(psi, dtype=ctype), dev)
         planes[0].copy_(dev.real)
@@ -485,7 +498,7 @@ class EvolutionState:
         torch = _torch()
         cdt = {np.dtype('complex64'): torch.complex64, np.dtype('complex128'): torch.complex128}[self.complex_type]
         core.use_torch_stream()
-        out = torch.empty(1 << self.n, dtype=cdt, device=self.device)
+        out = device_empty(1 << self.n, dtype=cdt, device=self.device)
         core.to_complex(self.planes[0], self.planes[1], out)
         return out
 
@@ -565,7 +578,9 @@ def _simplify_runs(circuit, remove_id_gates, atol, opts):
 
 def _compress_args(compress):
     """(max_n_qubits, keyword arguments for fusion.fuse) of a `compress` argument, validated: the core applies gates of
-    up to MAX_GATE_QUBITS qubits, and only these keys of the reference's utils.compress have a counterpart in fusion.fuse."""
+    up to MAX_GATE_QUBITS qubits, and only these keys of the reference's utils.compress have a counterpart in fusion.fuse.
+    ``atol`` is accepted and has no effect, exactly as in the reference: ``commutes_with`` compares with a fixed 1e-5
+    whatever it is passed (hybridq/gate/property.py:573; fusion._COMMUTE_ATOL)."""
     comp_kw = {k: v for k, v in compress.items() if k != 'max_n_qubits'} if isinstance(compress, dict) else {}
     comp_n = compress.get('max_n_qubits', 4) if isinstance(compress, dict) else compress
     if comp_n and comp_n > MAX_GATE_QUBITS:

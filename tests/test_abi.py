@@ -93,3 +93,38 @@ def test_apply_U_argument_marshalling_without_a_device():
         core.apply_U(pre, pim, U, [1, 2, 3], 10)
     with pytest.raises(TypeError):
         core.apply_U(pre, pim, U, [1.5, 2], 10)
+    with pytest.raises(ValueError, match='non-negative'):  # ctypes would wrap -1 to 4294967295 silently
+        core.apply_U(pre, pim, U, [-1, 2], 10)
+
+
+def test_rccl_that_cannot_be_loaded_is_an_error_not_a_crash():
+    """the message was built from two dlerror() calls (the second returns NULL).  A rank without a loadable
+    librccl must come back with rc = 1 and a message, so that it can vote for the fallback instead of dying while its peers
+    wait.  HQ_RCCL_LIBRARY names the only candidate; a fresh process because a loaded RCCL stays loaded."""
+    import subprocess
+    import sys
+    code = ("from hybridq_amd import core\n"
+            "rc = core._lib.hq_shard_load_rccl()\n"
+            "print('RC', rc, core.last_error())\n")
+    env = dict(os.environ, HQ_RCCL_LIBRARY='/nonexistent/librccl.so', PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'RC 1 cannot load librccl' in out.stdout and '/nonexistent/librccl.so' in out.stdout, out.stdout
+
+
+def test_exact_commutation_tolerance_follows_the_precision_of_the_gates():
+    """gates given in complex64 that commute mathematically have commutators ~1e-7; the blocked planner's
+    "commutes to rounding" test must still slide them, and must stay at 1e-12 for double-precision gates."""
+    from hybridq_amd import fusion
+
+    def rx(t):
+        return np.array([[np.cos(t / 2), -1j * np.sin(t / 2)], [-1j * np.sin(t / 2), np.cos(t / 2)]])
+
+    a64, b64 = rx(0.3).astype(np.complex64), rx(1.1).astype(np.complex64)
+    assert fusion.exact_tolerance([(rx(0.3), (0,))]) == 1e-12
+    tol = fusion.exact_tolerance([(a64, (0,)), (rx(0.2), (1,))])
+    assert 1e-7 < tol < 1e-6
+    assert not fusion.commute(a64, (0,), b64, (0,), exact=True) or np.abs(a64 @ b64 - b64 @ a64).max() <= 1e-12
+    assert fusion.commute(a64, (0,), b64, (0,), exact=tol)
+    z = np.diag([1, 1j]).astype(np.complex64)
+    assert not fusion.commute(a64, (0,), z, (0,), exact=tol)
