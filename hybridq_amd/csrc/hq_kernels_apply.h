@@ -283,7 +283,7 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
                       const MfmaRoles ro, const BigOffsets tab, const uint64_t niter) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
-  extern __shared__ __attribute__((aligned(16))) unsigned char hq_big_smem[];
+  HQ_DYN_LDS(hq_big_smem);
   constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB, G = 16 / (int)sizeof(T);
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR, NA = KBITS - 1 - KV;
   constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS, NG = NSTEP / G;
@@ -458,7 +458,7 @@ apply_mfma_stream_kernel(T* __restrict__ re, T* __restrict__ im, const T* __rest
                          const MfmaRoles ro, const BigOffsets tab, const uint64_t niter) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
-  extern __shared__ __attribute__((aligned(16))) unsigned char hq_big_smem[];
+  HQ_DYN_LDS(hq_big_smem);
   constexpr int BLOCK = 256;
   constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB, G = 16 / (int)sizeof(T);
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR, NA = KBITS - 1 - KV;
@@ -773,6 +773,18 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
 // argument in blocked_inner_gate), one ds_read_b32 + one v_xor3 per vector, and the result rows go back with
 // ds_write2_b32 pairs straight from the accumulators instead of 15 v_mov + 4 ds_write_b128.
 // Two elements from two unrelated registers to consecutive element slots `first`, `first + 1` after LDS byte address `a`.
+#ifdef HQ_EMU  // tests/emu: the two stores spelled out (LDS byte addresses are host addresses there)
+__device__ __forceinline__ void lds_write2(unsigned a, float v0, float v1, int first) {
+  float* p = reinterpret_cast<float*>(hq_emu::lds_at(a)) + (first == 0 ? 0 : 2);
+  p[0] = v0;
+  p[1] = v1;
+}
+__device__ __forceinline__ void lds_write2(unsigned a, double v0, double v1, int) {
+  double* p = reinterpret_cast<double*>(hq_emu::lds_at(a));
+  p[0] = v0;
+  p[1] = v1;
+}
+#else
 __device__ __forceinline__ void lds_write2(unsigned a, float v0, float v1, int first) {
   if (first == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(a), "v"(v0), "v"(v1) : "memory");
   else asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" ::"v"(a), "v"(v0), "v"(v1) : "memory");
@@ -780,6 +792,7 @@ __device__ __forceinline__ void lds_write2(unsigned a, float v0, float v1, int f
 __device__ __forceinline__ void lds_write2(unsigned a, double v0, double v1, int) {
   asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" ::"v"(a), "v"(v0), "v"(v1) : "memory");
 }
+#endif
 typedef unsigned BlockedTabT;  // 16-bit entries were tried: more passes fit their tables, each gate 7 % slower
 constexpr unsigned kBlockedTabLane = 0, kBlockedTabIter = 64, kBlockedTabOff = 128, kBlockedTabWords = 136;
 
@@ -1094,7 +1107,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
                      const BlockedArg ba, const uint64_t ntiles) {
   using V = typename Vec<T>::type;
   constexpr unsigned CB = Vec<T>::VB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HQ_DYN_LDS(smem);
   T* xr = reinterpret_cast<T*>(smem);
   T* xi = xr + (1u << ba.tb);
   T* als = xi + (1u << ba.tb);
@@ -1351,7 +1364,7 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
                   const unsigned* __restrict__ offs, const GemmArg a, const uint64_t ntiles) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
-  extern __shared__ __attribute__((aligned(16))) unsigned char hq_gemm_smem[];
+  HQ_DYN_LDS(hq_gemm_smem);
   constexpr int CB = Vec<T>::VB, G = 16 / (int)sizeof(T);
   T* __restrict__ xr = reinterpret_cast<T*>(hq_gemm_smem);
   T* __restrict__ xi = xr + ((size_t)1 << a.tb);
@@ -1552,7 +1565,7 @@ __global__ void __launch_bounds__(kBlock)
 apply_generic_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ U,
                      const GenArg a, const uint64_t nblocks) {
   using Q = typename Vec<T>::quad;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HQ_DYN_LDS(smem);
   const unsigned D = 1u << a.k, C = 1u << a.c, CQ = C >> 2;
   uint64_t* toff = reinterpret_cast<uint64_t*>(smem);
   uint32_t* coff = reinterpret_cast<uint32_t*>(toff + D);
@@ -1650,7 +1663,7 @@ apply_mfma_tile_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restri
   constexpr int D = 1 << K, E = 2 * D, NSTEP = E / 4, NRBT = E / 16, RBW = NRBT / 4;
   constexpr int CBITS = (sizeof(T) == 4 ? 12 : 11) - K, C = 1 << CBITS, NCG = C / (16 * CW);
   static_assert(NCG >= 1 && RBW >= 1, "tile shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HQ_DYN_LDS(smem);
   uint64_t* toff = reinterpret_cast<uint64_t*>(smem);
   uint32_t* coff = reinterpret_cast<uint32_t*>(toff + D);
   T* xr = reinterpret_cast<T*>(coff + C);

@@ -75,7 +75,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 norm2_kernel(const T* __restrict__ re, const T* __restrict__ im, const uint64_t size,
              double* __restrict__ out) {
-  __shared__ double part[kBlock / 64];
+  HQ_LDS double part[kBlock / 64];
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   double acc = 0;
   using V = typename Vec<T>::type;
@@ -128,7 +128,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 probabilities_kernel(const T* __restrict__ re, const T* __restrict__ im, const uint64_t size,
                      const BitsArg ba, double* __restrict__ out /* 2^k, pre-zeroed */) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HQ_DYN_LDS(smem);
   double* bins = reinterpret_cast<double*>(smem);
   const unsigned nb = 1u << ba.k;
   for (unsigned i = threadIdx.x; i < nb; i += kBlock) bins[i] = 0.0;
@@ -158,7 +158,7 @@ probabilities_stream_kernel(const T* __restrict__ re, const T* __restrict__ im, 
   using V = typename Vec<T>::type;
   constexpr unsigned CB = Vec<T>::VB, NC = 1u << CB;
   constexpr unsigned TB = 8, IB = 6, CHUNK = CB + TB + IB;  // bits of the thread / it fields; 2^CHUNK amplitudes per chunk
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HQ_DYN_LDS(smem);
   double* bins = reinterpret_cast<double*>(smem);
   const unsigned nb = 1u << ba.k;
   for (unsigned i = threadIdx.x; i < nb; i += kBlock) bins[i] = 0.0;
@@ -246,7 +246,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 vdot_kernel(const T* __restrict__ are, const T* __restrict__ aim, const T* __restrict__ bre,
             const T* __restrict__ bim, const uint64_t size, double* __restrict__ out) {
-  __shared__ double part[2][kBlock / 64];
+  HQ_LDS double part[2][kBlock / 64];
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   double sr = 0, si = 0;
   using V = typename Vec<T>::type;

@@ -24,6 +24,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// LDS declarations go through two macros so that tests/emu (a host emulation of the HIP model used to execute these very
+// kernels on a box without a GPU -- test infrastructure, never part of the product) can place them; for the device build
+// they are the plain HIP spellings.
+#ifdef HQ_EMU
+#define HQ_DYN_LDS(name) unsigned char* const name = hq_emu::dyn_lds()
+#define HQ_LDS static
+#else
+#define HQ_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define HQ_LDS __shared__
+#endif
+
 namespace hq {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

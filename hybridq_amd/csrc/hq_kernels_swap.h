@@ -26,7 +26,7 @@ swap_lds_kernel(E* __restrict__ a, const SwapArg sa, const unsigned tile_bits,
                 const uint64_t ntiles) {
   struct alignas(sizeof(E) * VEC) Pack { E e[VEC]; };
   typedef E PackV __attribute__((ext_vector_type(VEC)));
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HQ_DYN_LDS(smem);
   const unsigned S = 1u << sa.s, TILE = 1u << tile_bits;
   uint16_t* src = reinterpret_cast<uint16_t*>(smem);          // S entries (TABLE only)
   E* buf = reinterpret_cast<E*>(smem + (TABLE ? (((size_t)S * 2 + 15) & ~(size_t)15) : 0));
@@ -111,7 +111,7 @@ template <typename E, int VEC, int NPV>
 __global__ void __launch_bounds__(kBlock)
 tile_permute_kernel(E* __restrict__ a, const TilePermArg ta, const uint64_t ntiles) {
   using Pack = typename PackOf<E, VEC>::type;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HQ_DYN_LDS(smem);
   constexpr unsigned VBITS = VEC == 4 ? 2 : (VEC == 2 ? 1 : 0);
   const unsigned TILE = 1u << ta.tb, NV = TILE >> VBITS;
   uint16_t* src = reinterpret_cast<uint16_t*>(smem);                                        // TILE entries: permuted tile-local index
@@ -323,9 +323,9 @@ bitperm_tile_kernel(const E* __restrict__ src0, const E* __restrict__ src1, cons
   constexpr int VEC = 16 / (int)sizeof(E);
   constexpr unsigned VB = VEC == 4 ? 2 : 1;
   typedef E PackV __attribute__((ext_vector_type(VEC)));
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  HQ_DYN_LDS(smem);
   E* buf = reinterpret_cast<E*>(smem);
-  __shared__ unsigned char* dptr[kMaxShardRanks][2];
+  HQ_LDS unsigned char* dptr[kMaxShardRanks][2];
   const unsigned tid = threadIdx.x;
   if (tid < 2 * kMaxShardRanks) dptr[tid >> 1][tid & 1] = reinterpret_cast<unsigned char*>(a.dst[tid >> 1][tid & 1]);
   // ---- per-thread address terms (every map below is a bit permutation or an XOR of them: terms of disjoint parts of

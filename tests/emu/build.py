@@ -1,0 +1,63 @@
+"""TEST INFRASTRUCTURE: builds tests/emu/_build/libhq_emu.so -- the five translation units of libhq_hip.so compiled as
+plain C++ for the host against the emulation shim (tests/emu/shim), plus the emulator runtime (hip_emu.cpp).  Same
+sources, same planners, same kernel bodies; the HIP programming model is provided by the shim.  Only tests load the
+result (tests/emu_util.py); nothing under hybridq_amd/ knows about it."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'hybridq_amd', 'csrc')
+OUT = os.path.join(HERE, '_build')
+LIB = os.path.join(OUT, 'libhq_emu.so')
+UNITS = ['hq_core', 'hq_apply', 'hq_swap', 'hq_shard', 'hq_state']
+
+
+def _cxx():
+    for cand in (os.environ.get('HQ_EMU_CXX'), '/opt/rocm/lib/llvm/bin/clang++', '/usr/bin/clang++'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('the emulation build needs clang++ (ext_vector_type, address_space, __builtin_nontemporal_*)')
+
+
+def _deps():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
+    deps += [os.path.join(ROOT, 'include', 'hq_hip.h'), os.path.join(HERE, 'hip_emu.cpp'), os.path.abspath(__file__),
+             os.path.join(HERE, 'shim', 'hip', 'hip_runtime.h'), os.path.join(HERE, 'shim', 'rccl', 'rccl.h')]
+    return deps
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in _deps()):
+        return LIB
+    os.makedirs(OUT, exist_ok=True)
+    cxx = _cxx()
+    flags = ['-std=c++17', '-O1', '-g1', '-fPIC', '-DHQ_EMU=1', '-ffp-contract=off', '-Wno-unused-function', '-Wno-unused-value',
+             '-Wno-unknown-attributes', '-Wno-ignored-attributes', '-I', os.path.join(HERE, 'shim')]
+    jobs, objs = [], []
+    for u in UNITS:
+        obj = os.path.join(OUT, u + '.o')
+        objs.append(obj)
+        jobs.append([cxx, '-x', 'c++'] + flags + ['-c', os.path.join(CSRC, u + '.hip'), '-o', obj])
+    obj = os.path.join(OUT, 'hip_emu.o')
+    objs.append(obj)
+    jobs.append([cxx] + flags + ['-c', os.path.join(HERE, 'hip_emu.cpp'), '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError('emulation build failed:\n' + ' '.join(cmd) + '\n' + r.stdout + r.stderr[-6000:])
+
+    with ThreadPoolExecutor(len(jobs)) as pool:
+        list(pool.map(run, jobs))
+    run([cxx, '-shared', '-fPIC'] + objs + ['-o', LIB + '.tmp', '-ldl', '-lpthread'])
+    os.replace(LIB + '.tmp', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))
