@@ -105,8 +105,13 @@ def _best_fusion_order(chosen, gq, n_orders, rnd):
 
 
 def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', min_gates=3, tries=32, seed=0,
-                 complex_type='complex64', fusion_orders=16):
+                 complex_type='complex64', fusion_orders=16, native=True):
     """Schedule `gates` ([(U, qubits), ...]) given the placement ``pos_of[qubit] = position``.
+
+    ``native=True`` (default): the planner behind the C ABI (``hq_plan_blocked``, csrc/hq_plan.hip) -- the algorithm
+    below in C++, 20-40x faster (the caller of simulate() waits for the plan); ``native=False`` runs this Python
+    statement of it.  Both are deterministic for a seed; they draw different random numbers, so their plans may differ
+    by a pass.
 
     Returns a list of ops:
         ('B', tile_pos uint32[tile_bits] ascending, [(U, positions LSB-first), ...])
@@ -117,6 +122,9 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', m
     import random
     tile_bits = min(tile_bits, n)
     low_bits = min(low_bits, tile_bits)
+    if native:
+        return _plan_blocked_native(gates, pos_of, n, tile_bits, low_bits, inner_max, min_gates, tries, seed, complex_type,
+                                    fusion_orders)
     gq = [tuple(qs) for _, qs in gates]
     gp = [frozenset(pos_of[q] for q in qs) for qs in gq]
     gk = [len(qs) for qs in gq]
@@ -224,6 +232,33 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', m
             inner = [(np.asarray(gates[gi][0]), gq[gi]) for gi in chosen]
         ops.append(('B', np.asarray(sorted(S), dtype=np.uint32),
                     [(U, [pos_of[q] for q in reversed(qs)]) for U, qs in inner]))
+    return ops
+
+
+def _plan_blocked_native(gates, pos_of, n, tile_bits, low_bits, inner_max, min_gates, tries, seed, complex_type, fusion_orders):
+    from . import core
+    from .fusion import exact_tolerance
+    ctype = np.dtype(complex_type)
+    single = ctype == np.dtype('complex64')
+    # positions stand for the qubits: the planner sorts a fused gate's qubits by them (most significant first), this
+    # module by label -- the same operator either way
+    as_pos = [(U, [pos_of[q] for q in qs]) for U, qs in gates]
+    tol = exact_tolerance(gates)
+    kind, first, tile, gk, gpos, mats = core.plan_blocked(n, as_pos, tile_bits, low_bits, inner_max, min_gates, max(1, tries),
+                                                           max(1, fusion_orders), 4 if single else 8, seed, tol)
+    ops = []
+    po = np.concatenate([[0], np.cumsum(gk)]).astype(np.int64)
+    mo = np.concatenate([[0], np.cumsum(np.int64(1) << (2 * gk.astype(np.int64)))])
+    mats = mats.astype(ctype)
+    for i in range(len(kind)):
+        inner = []
+        for g in range(first[i], first[i + 1]):
+            d = 1 << int(gk[g])
+            inner.append((mats[mo[g]:mo[g + 1]].reshape(d, d), [int(p) for p in gpos[po[g]:po[g + 1]][::-1]]))  # LSB first
+        if kind[i]:
+            ops.append(('B', tile[i].copy(), inner))
+        else:
+            ops.append(('G', inner[0][0], inner[0][1]))
     return ops
 
 

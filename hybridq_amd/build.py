@@ -1,7 +1,7 @@
 """Build libhq_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so lives next
 to its sources so that it travels with the repo snapshot to the GPU box.
 
-The library is five translation units (csrc/hq_{core,apply,swap,shard,state}.hip) compiled in parallel
+The library is six translation units (csrc/hq_{core,apply,swap,shard,state,plan}.hip) compiled in parallel
 and linked into one shared object; an object is rebuilt when its source or any header is newer."""
 import os
 import shutil
@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libhq_hip.so')
-UNITS = ['hq_core', 'hq_apply', 'hq_swap', 'hq_shard', 'hq_state']
+UNITS = ['hq_core', 'hq_apply', 'hq_swap', 'hq_shard', 'hq_state', 'hq_plan']
 SOURCES = [os.path.join(CSRC, u + '.hip') for u in UNITS]
 HEADERS = [os.path.join(CSRC, h) for h in ('hq_common.h', 'hq_kernels_common.h', 'hq_kernels_apply.h', 'hq_kernels_swap.h',
                                            'hq_kernels_aux.h', 'hq_bitperm.h')] + [os.path.join(HERE, '..', 'include', 'hq_hip.h')]

@@ -177,6 +177,14 @@ _program_end = _define_function(_lib, 'hq_program_end', ctypes.c_int, ctypes.POI
 _program_size = _define_function(_lib, 'hq_program_size', ctypes.c_int, ctypes.c_void_p)
 _program_run = _define_function(_lib, 'hq_program_run', ctypes.c_int, ctypes.c_void_p)
 _program_free = _define_function(_lib, 'hq_program_free', ctypes.c_int, ctypes.c_void_p)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_plan_blocked = _define_function(_lib, 'hq_plan_blocked', ctypes.c_int, ctypes.c_uint, ctypes.c_uint, _u32p, _u32p, ctypes.c_void_p,
+                                 ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint,
+                                 ctypes.c_uint, ctypes.c_uint64, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p))
+_plan_counts = _define_function(_lib, 'hq_plan_counts', ctypes.c_int, ctypes.c_void_p, _u32p, _u32p, ctypes.POINTER(ctypes.c_uint64),
+                                ctypes.POINTER(ctypes.c_uint64), _u32p)
+_plan_read = _define_function(_lib, 'hq_plan_read', ctypes.c_int, ctypes.c_void_p, _u32p, _u32p, _u32p, _u32p, _u32p, ctypes.c_void_p)
+_plan_free = _define_function(_lib, 'hq_plan_free', ctypes.c_int, ctypes.c_void_p)
 
 #: symbols the C header include/hq_hip.h declares (checked by tests/test_abi.py)
 EXPORTED = [
@@ -194,6 +202,7 @@ EXPORTED = [
     'hq_shard_info', 'hq_shard_free', 'hq_shard_rccl_selftest', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
     'hq_exchange_float32', 'hq_exchange_float64', 'hq_alloc', 'hq_free', 'hq_alloc_mapped', 'hq_alloc_scattered',
     'hq_alloc_state', 'hq_free_state', 'hq_state_info', 'hq_state_pool_trim',
+    'hq_plan_blocked', 'hq_plan_counts', 'hq_plan_read', 'hq_plan_free',
 ]
 
 
@@ -570,6 +579,36 @@ def state_info(psi_re=None):
 
 def state_pool_trim():
     _check(_state_pool_trim(), 'hq_state_pool_trim')
+
+
+def plan_blocked(n, gates, tile_bits, low_bits, inner_max, min_gates, tries, fusion_orders, elem_bytes, seed, commute_tol):
+    """``hq_plan_blocked`` (include/hq_hip.h): the cache-blocked schedule of `gates` = [(U, positions)], positions with
+    the matrix's MOST significant qubit first.  Returns (op_kind, op_first_gate, op_tile[n_ops, tile_bits], gate_k,
+    gate_positions (flat, most significant first), matrices (list of complex128 arrays))."""
+    G = len(gates)
+    k = np.fromiter((len(p) for _, p in gates), dtype=np.uint32, count=G)
+    pos = np.fromiter((int(x) for _, p in gates for x in p), dtype=np.uint32, count=int(k.sum()))
+    U = np.concatenate([np.asarray(u, dtype=np.complex128).reshape(-1) for u, _ in gates]) if G else np.zeros(0, np.complex128)
+    handle = ctypes.c_void_p()
+    _check(_plan_blocked(n, G, k.ctypes.data_as(_u32p), pos.ctypes.data_as(_u32p), U.ctypes.data, tile_bits, low_bits,
+                         255 if inner_max == 'auto' else int(inner_max or 0), min_gates, tries, fusion_orders, elem_bytes,
+                         seed, commute_tol, ctypes.byref(handle)), 'hq_plan_blocked')
+    try:
+        n_ops, n_g, tb = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        n_pos, n_el = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(_plan_counts(handle, ctypes.byref(n_ops), ctypes.byref(n_g), ctypes.byref(n_pos), ctypes.byref(n_el), ctypes.byref(tb)),
+               'hq_plan_counts')
+        kind = np.empty(n_ops.value, np.uint32)
+        first = np.empty(n_ops.value + 1, np.uint32)
+        tile = np.empty((n_ops.value, tb.value), np.uint32)
+        gk = np.empty(n_g.value, np.uint32)
+        gpos = np.empty(n_pos.value, np.uint32)
+        mats = np.empty(n_el.value, np.complex128)
+        _check(_plan_read(handle, kind.ctypes.data_as(_u32p), first.ctypes.data_as(_u32p), tile.ctypes.data_as(_u32p),
+                          gk.ctypes.data_as(_u32p), gpos.ctypes.data_as(_u32p), mats.ctypes.data), 'hq_plan_read')
+    finally:
+        _plan_free(handle)
+    return kind, first, tile, gk, gpos, mats
 
 
 def pack_blocked(gates, complex_type='complex64'):

@@ -87,11 +87,17 @@ int apply_device_f64(Context& c, double* re, double* im, const double* U, const 
 
 }  // namespace hq
 
+// A failed runtime call leaves its code in the thread's "last error"; it is cleared here so that the launch checks
+// (HQ_HIP_CHECK(hipGetLastError()) after a kernel launch) of LATER calls do not report it again -- callers do carry on
+// after a failure (the tuned placement falling back to hipMalloc / torch memory, a transport falling back).  Found by
+// running the -m gpu tests against the host emulation (tests/emu), where the VMM calls fail by construction.
 #define HQ_HIP_CHECK(expr)                                                             \
   do {                                                                                 \
     hipError_t _e = (expr);                                                            \
-    if (_e != hipSuccess)                                                              \
+    if (_e != hipSuccess) {                                                            \
+      (void)hipGetLastError();                                                         \
       return hq::fail(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    }                                                                                  \
   } while (0)
 
 // Launch now, or append to the program being recorded (arguments are captured by value).

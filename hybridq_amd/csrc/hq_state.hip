@@ -313,7 +313,11 @@ static void state_release(StateAlloc& st) {
 }
 
 constexpr size_t kPlanePadBytes = 12288;     // measured at n = 30 (tools/sweep_pad.py): +3..15 % for high targets
-constexpr size_t kTunedMinBytes = 1u << 28;  // states below this stay on hipMalloc memory
+constexpr size_t kTunedMinBytes = 1u << 28;  // states below this stay on hipMalloc memory (HQ_STATE_TUNED_MIN_BYTES: tests)
+static size_t tuned_min_bytes() {
+  const char* e = getenv("HQ_STATE_TUNED_MIN_BYTES");
+  return e && atoll(e) > 0 ? (size_t)atoll(e) : kTunedMinBytes;
+}
 
 static size_t state_stride(unsigned n, size_t itemsize) {
   const size_t pad = n >= 12 ? kPlanePadBytes / itemsize : 0;
@@ -380,7 +384,7 @@ static int state_alloc(Context& c, unsigned n, int float_bits, int flags, void**
   st.bytes = bytes;
   const char* env_alloc = getenv("HQ_STATE_ALLOC");
   const bool env_plain = env_alloc && std::string(env_alloc) != "vmm";
-  const bool tuned = !(flags & 1) && !env_plain && bytes >= kTunedMinBytes && n >= 8;
+  const bool tuned = !(flags & 1) && !env_plain && bytes >= tuned_min_bytes() && n >= 8;
   auto finish = [&](StateAlloc& s) {
     *out_re = s.re;
     *out_im = s.im;

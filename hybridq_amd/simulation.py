@@ -641,9 +641,10 @@ BLOCKED_OVERLAP_MS = 1.3  # ... what of the stream does NOT hide behind the gate
 BLOCKED_INNER_MS = {1: 0.38, 2: 0.63, 3: 0.63, 4: 1.20}
 TUNED_PLACEMENT_SEARCH_MS = 2500.0  # what alloc_planes' draw-and-probe search costs (n = 30; measured 2.5 s)
 #: host time of planning one candidate schedule, per matrix gate of the circuit (measured on the benchmark circuits,
-#: n = 16..30: fusion to 4 ~0.04 ms / gate, to 5 ~0.07, the blocked planner ~0.13 at full search effort, ~0.055 with
-#: tries=8 / fusion_orders=1)
-PLAN_HOST_MS_PER_GATE = {'per_gate': 0.0, 'fused_4': 0.045, 'fused_5': 0.075, 'blocked': 0.13, 'blocked_quick': 0.055}
+#: n = 16..30: fusion to 4 ~0.04 ms / gate, to 5 ~0.07; the Python blocked planner needed ~0.13 at full search effort).
+#: Round 4: the blocked planner runs behind the C ABI (hq_plan_blocked): 0.02 ms / gate at full search effort (17 ms for
+#: the 900-gate n = 30 circuit; tools/plan_time.py), so the quick search of round 3 is gone
+PLAN_HOST_MS_PER_GATE = {'per_gate': 0.0, 'fused_4': 0.045, 'fused_5': 0.075, 'blocked': 0.02}
 BLOCKED_VS_FUSED5 = 0.55  # modelled time of the cache-blocked plan over the fused-5 plan (0.45 benchmark circuit, 0.63 dense 3q/4q gates)
 PREDICTION_SLACK = 0.85  # a plan may come out this much better than predicted (commuting gates fuse further)
 LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)
@@ -704,12 +705,10 @@ def choose_schedule(circuit, qubits, n, ctype):
     n_matrix = sum(1 for g in circuit if not _is_functional(g))
     cost = {name: PLAN_HOST_MS_PER_GATE[name] * n_matrix for name in cands}
     if n >= 14:
-        # the blocked planner's search effort (visiting orders per pass, fusion orders per pass) buys ~9 % of device time
-        # (n = 30: 139 instead of 151 ms) for 65 ms more host time: worth it from n = 33 on, or when the plan is reused
-        # (an explicit blocked=True, EvolutionState.compile)
-        full = n >= 33
-        cands['blocked'] = dict(compress=5, blocked=True if full else dict(tries=8, fusion_orders=1))
-        cost['blocked'] = (PLAN_HOST_MS_PER_GATE['blocked'] if full else PLAN_HOST_MS_PER_GATE['blocked_quick']) * n_matrix
+        # full search effort (32 visiting orders and 16 fusion orders per pass): ~5 % less device time than the quick
+        # search for 8 ms more host time now that the planner is native
+        cands['blocked'] = dict(compress=5, blocked=True)
+        cost['blocked'] = PLAN_HOST_MS_PER_GATE['blocked'] * n_matrix
     plans = {'per_gate': _plan_ops(circuit, qubits, n, ctype, 0, False)}
     est = {'per_gate': estimate_ms(plans['per_gate'], n, ctype)}
     pred = {}

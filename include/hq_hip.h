@@ -289,6 +289,27 @@ int hq_program_size(void *handle);   /* recorded launches, -1 for NULL */
 int hq_program_run(void *handle);
 int hq_program_free(void *handle);
 
+/* ---- host-side planning (no device work; hybridq_amd/csrc/hq_plan.hip) --------------------------------------------
+ * The cache-blocked schedule of a run of matrix gates: list scheduling of the dependency DAG into passes over LDS tiles
+ * and fusion of each pass's gates (the reference's greedy rule, hybridq/circuit/utils.py:606-669, on gates that commute
+ * to `commute_tol`).  No reference counterpart for the schedule itself (the reference applies one fused gate per pass,
+ * simulation.py:522-646); hybridq_amd/blocking.py is the same algorithm in Python.
+ *   gate g acts on k[g] POSITIONS (index bits), listed with the matrix's most significant qubit first (gate.qubits
+ *   order); U holds the matrices one after the other, row-major, interleaved (re, im) doubles.
+ *   inner_max: widest fused inner gate (0 = keep the gates as they are, 255 = 3 with a widening round to 4 where cheaper).
+ * hq_plan_read fills caller-allocated arrays sized by hq_plan_counts: op_kind[n_ops] (0 plain gate, 1 blocked pass),
+ * op_first_gate[n_ops + 1] (its gates are [first, next first)), op_tile[n_ops * tile_bits] (ascending positions of a
+ * pass's tile), gate_k[n_gates], gate_positions[n_positions] (most significant first), U[2 * n_matrix_elems]. */
+int hq_plan_blocked(unsigned int n_qubits, unsigned int n_gates, const unsigned int *k, const unsigned int *positions,
+                    const double *U, unsigned int tile_bits, unsigned int low_bits, unsigned int inner_max,
+                    unsigned int min_gates, unsigned int tries, unsigned int fusion_orders, unsigned int elem_bytes,
+                    uint64_t seed, double commute_tol, void **plan);
+int hq_plan_counts(const void *plan, unsigned int *n_ops, unsigned int *n_gates, uint64_t *n_positions,
+                   uint64_t *n_matrix_elems, unsigned int *tile_bits);
+int hq_plan_read(const void *plan, unsigned int *op_kind, unsigned int *op_first_gate, unsigned int *op_tile,
+                 unsigned int *gate_k, unsigned int *gate_positions, double *U);
+int hq_plan_free(void *plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,9 +25,64 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+#: HQ_EMU_GPU_SUITE=1: run the `-m gpu` tests on a box WITHOUT a GPU against the host emulation of the HIP library
+#: (tests/emu: the same planners and kernel bodies compiled for the host, lane-exact wave operations) with CPU torch
+#: tensors standing for device tensors (tests/emu/fake_cuda.py).  tests/test_emu_gpu_suite.py does this in a subprocess
+#: as part of the CPU suite; it is evidence that the code paths and index arithmetic are right, not a GPU run.
+EMU_SUITE = os.environ.get('HQ_EMU_GPU_SUITE') == '1'
+if EMU_SUITE:
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import emu_util  # noqa: E402
+    os.environ['HQ_HIP_LIBRARY'] = emu_util.emu_library()
+    os.environ['HQ_EMU_HOST_IS_DEVICE'] = '1'
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+    import fake_cuda  # noqa: E402
+    fake_cuda.install()
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+#: -m gpu tests that cannot (or need not) run against the host emulation, with the reason; everything else does
+EMU_SKIP = (
+    ('test_gpu_fullsize.py', 'BASELINE-size states (n = 30...) are hours of emulation'),
+    ('test_gpu_determinism.py', 'run-to-run determinism of the hardware; the emulation has tests/test_emu_kernels.py::test_wave_order'),
+    ('two_ranks_one_gpu', 'several processes sharing one real GPU'),
+    ('eight_ranks_sharing', 'several processes sharing one real GPU'),
+    ('sharded_api', 'several processes sharing one real GPU'),
+    ('rccl', 'needs the real RCCL on a real device'),
+    ('c_abi_demo_without_python', 'a C program linked against the real HIP runtime'),
+    ('c_abi_state_demo_without_python', 'a C program linked against the real HIP runtime'),
+    ('many_tiles_per_workgroup[complex', 'n = 23...25: minutes of emulation per case'),
+    ('swap_many_tiles_per_workgroup', 'n = 25, 26'),
+    ('one_pass_tiles[', 'n = 25, 26'),
+    ('one_pass_in_place[', 'n = 25, 26'),
+    ('simulation_large_like_reference[2', 'n = 20, 22 with 600 gates (n = 16 runs)'),
+    ('test_gpu_depth_parity.py', 'n = 24 depth-40 circuits (the same statements at n = 16: smoke(), test_emu_kernels.py)'),
+    ('simple_qasm_trace_and_circuit', 'n = 24'),
+    ('large_state_comes_back', 'n >= 25'),
+    ('large_array_initial_state', 'n >= 25'),
+    ('host_functional_gate_on_a_large_state', 'n >= 25'),
+    ('to_numpy_never_holds', 'n >= 25 and the real allocator statistics'),
+    ('test_dm_1__simulation_1', '12-qubit density matrices = 24-qubit states'),
+    ('initialize_state[', 'n = 24'),
+    ('prepare_state_mixed_large', 'n = 26'),
+    ('auto_dispatch_follows_the_measured_rule', 'n = 30 planes'),
+    ('guard_bands', 'torch device fills of the margins; sizes n = 19, 20'),
+    ('qasm_text_to_gpu', 'n = 24'),
+    ('stream_switch_is_ordered', 'real streams'),
+)
+
+
+def pytest_collection_modifyitems(config, items):
+    if not EMU_SUITE:
+        return
+    for item in items:
+        for pat, why in EMU_SKIP:
+            if pat in item.nodeid:
+                item.add_marker(pytest.mark.skip(reason=f'not under emulation: {why}'))
+                break
 
 
 def pytest_sessionstart(session):

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'hybridq_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libhq_emu.so')
-UNITS = ['hq_core', 'hq_apply', 'hq_swap', 'hq_shard', 'hq_state']
+UNITS = ['hq_core', 'hq_apply', 'hq_swap', 'hq_shard', 'hq_state', 'hq_plan']
 
 
 def _cxx():

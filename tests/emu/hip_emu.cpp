@@ -202,7 +202,23 @@ static int order_mode() {
   return m;
 }
 
-void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()>& body) {
+}  // namespace hq_emu
+struct hq_emu_graph { std::vector<std::function<void()>> ops; };
+struct hq_emu_graph_exec { std::vector<std::function<void()>> ops; };
+struct hq_emu_stream { hq_emu_graph* capture = nullptr; };
+namespace hq_emu {
+
+static void run_grid(dim3 grid, dim3 block, size_t lds, const std::function<void()>& body);
+
+void launch(dim3 grid, dim3 block, size_t lds, hipStream_t stream, std::function<void()> body) {
+  if (stream && stream->capture) {
+    stream->capture->ops.push_back([=]() { run_grid(grid, block, lds, body); });
+    return;
+  }
+  run_grid(grid, block, lds, body);
+}
+
+static void run_grid(dim3 grid, dim3 block, size_t lds, const std::function<void()>& body) {
   init_once();
   const unsigned nt = block.x * block.y * block.z;
   if (nt == 0 || nt > (unsigned)kMaxThreads || lds > kLdsBytes) { fprintf(stderr, "hq_emu: launch shape not supported (%u threads, %zu B LDS)\n", nt, lds); abort(); }
@@ -282,7 +298,6 @@ static bool find_alloc(const void* p, uintptr_t* base, size_t* size) {
 }  // namespace hq_emu
 
 using namespace hq_emu;
-struct hq_emu_stream { int id; };
 struct hq_emu_event { std::chrono::steady_clock::time_point t; };
 static hipError_t g_last = hipSuccess;
 static hipError_t ret(hipError_t e) { if (e != hipSuccess) g_last = e; return e; }
@@ -323,7 +338,10 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemcpyFromSymbol(void* d, const void* s, size_t n) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
-  if (!find_alloc(p, nullptr, nullptr)) return ret(hipErrorInvalidValue);
+  // HQ_EMU_HOST_IS_DEVICE=1: every pointer counts as device memory (CPU torch tensors stand for device tensors when the
+  // -m gpu tests run against the emulation; tests/emu/fake_cuda.py)
+  static const bool all_device = getenv("HQ_EMU_HOST_IS_DEVICE") && atoi(getenv("HQ_EMU_HOST_IS_DEVICE")) != 0;
+  if (!all_device && !find_alloc(p, nullptr, nullptr)) return ret(hipErrorInvalidValue);
   a->type = hipMemoryTypeDevice;
   a->device = 0;
   a->devicePointer = const_cast<void*>(p);
@@ -336,18 +354,34 @@ hipError_t hipMemGetAddressRange(hipDeviceptr_t* base, size_t* size, hipDevicept
   *base = (void*)b;
   return hipSuccess;
 }
-hipError_t hipStreamCreate(hipStream_t* s) { *s = new hq_emu_stream{1}; return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = new hq_emu_stream(); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return ret(hipErrorNotSupported); }
-hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return ret(hipErrorNotSupported); }
-hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return ret(hipErrorNotSupported); }
-hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return ret(hipErrorNotSupported); }
-hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+// graphs: kernel launches on a capturing stream are recorded (arguments by value) and replayed by hipGraphLaunch
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+  if (!s || s->capture) return ret(hipErrorInvalidValue);
+  s->capture = new hq_emu_graph();
+  return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
+  if (!s || !s->capture) return ret(hipErrorInvalidValue);
+  *g = s->capture;
+  s->capture = nullptr;
+  return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
+  *e = new hq_emu_graph_exec{g->ops};
+  return hipSuccess;
+}
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+  for (auto& op : e->ops) op();
+  return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = new hq_emu_event{std::chrono::steady_clock::now()}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
@@ -358,16 +392,72 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-// virtual-memory management and IPC: not emulated (the tuned placement and the peer-to-peer transport are about physical
-// memory and other processes' devices); callers take their documented failure paths
-hipError_t hipMemGetAllocationGranularity(size_t*, const hipMemAllocationProp*, hipMemAllocationGranularity_flags) { return ret(hipErrorNotSupported); }
-hipError_t hipMemAddressReserve(void**, size_t, size_t, void*, unsigned long long) { return ret(hipErrorNotSupported); }
-hipError_t hipMemAddressFree(void*, size_t) { return ret(hipErrorNotSupported); }
-hipError_t hipMemCreate(hipMemGenericAllocationHandle_t*, size_t, const hipMemAllocationProp*, unsigned long long) { return ret(hipErrorNotSupported); }
-hipError_t hipMemRelease(hipMemGenericAllocationHandle_t) { return ret(hipErrorNotSupported); }
-hipError_t hipMemMap(void*, size_t, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return ret(hipErrorNotSupported); }
-hipError_t hipMemUnmap(void*, size_t) { return ret(hipErrorNotSupported); }
-hipError_t hipMemSetAccess(void*, size_t, const hipMemAccessDesc*, size_t) { return ret(hipErrorNotSupported); }
+// virtual-memory management: address ranges are PROT_NONE reservations, physical granules are memfd files, a mapping is
+// a MAP_SHARED | MAP_FIXED view of a granule -- so remapping the same granules elsewhere keeps their contents, an
+// unmapped range faults, and the library's bookkeeping (hq_state.hip) is exercised for real.  IPC is not emulated.
+namespace {
+constexpr size_t kGranule = 1 << 16;  // "minimum granularity" of the emulated device
+struct Granule { int fd; size_t size; };
+std::map<uint64_t, Granule>& granules() { static std::map<uint64_t, Granule> m; return m; }
+std::map<uintptr_t, size_t>& reservations() { static std::map<uintptr_t, size_t> m; return m; }
+uint64_t g_next_handle = 1;
+bool inside_reservation(void* p, size_t n) {
+  auto& m = reservations();
+  auto it = m.upper_bound((uintptr_t)p);
+  if (it == m.begin()) return false;
+  --it;
+  return (uintptr_t)p + n <= it->first + it->second;
+}
+}  // namespace
+hipError_t hipMemGetAllocationGranularity(size_t* g, const hipMemAllocationProp*, hipMemAllocationGranularity_flags) { *g = kGranule; return hipSuccess; }
+hipError_t hipMemAddressReserve(void** p, size_t n, size_t, void*, unsigned long long) {
+  void* q = mmap(nullptr, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (q == MAP_FAILED) return ret(hipErrorOutOfMemory);
+  reservations()[(uintptr_t)q] = n;
+  *p = q;
+  return hipSuccess;
+}
+hipError_t hipMemAddressFree(void* p, size_t n) {
+  auto it = reservations().find((uintptr_t)p);
+  if (it == reservations().end() || it->second != n) return ret(hipErrorInvalidValue);
+  munmap(p, n);
+  reservations().erase(it);
+  return hipSuccess;
+}
+hipError_t hipMemCreate(hipMemGenericAllocationHandle_t* h, size_t n, const hipMemAllocationProp*, unsigned long long) {
+  if (n == 0 || n % kGranule) return ret(hipErrorInvalidValue);
+  const int fd = memfd_create("hq_emu_granule", 0);
+  if (fd < 0 || ftruncate(fd, (off_t)n)) { if (fd >= 0) close(fd); return ret(hipErrorOutOfMemory); }
+  *h = g_next_handle++;
+  granules()[*h] = Granule{fd, n};
+  return hipSuccess;
+}
+hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) {
+  auto it = granules().find(h);
+  if (it == granules().end()) return ret(hipErrorInvalidValue);
+  close(it->second.fd);  // views that are still mapped keep the pages alive, as on the device
+  granules().erase(it);
+  return hipSuccess;
+}
+hipError_t hipMemMap(void* p, size_t n, size_t off, hipMemGenericAllocationHandle_t h, unsigned long long) {
+  auto it = granules().find(h);
+  if (it == granules().end() || off + n > it->second.size || !inside_reservation(p, n)) return ret(hipErrorInvalidValue);
+  // no access until hipMemSetAccess, as on the device
+  if (mmap(p, n, PROT_NONE, MAP_SHARED | MAP_FIXED, it->second.fd, (off_t)off) == MAP_FAILED) return ret(hipErrorInvalidValue);
+  allocs()[(uintptr_t)p] = n;  // device memory from now on
+  return hipSuccess;
+}
+hipError_t hipMemUnmap(void* p, size_t n) {
+  if (!inside_reservation(p, n)) return ret(hipErrorInvalidValue);
+  if (mmap(p, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) == MAP_FAILED) return ret(hipErrorInvalidValue);
+  auto& m = allocs();
+  for (auto it = m.lower_bound((uintptr_t)p); it != m.end() && it->first < (uintptr_t)p + n;) it = m.erase(it);
+  return hipSuccess;
+}
+hipError_t hipMemSetAccess(void* p, size_t n, const hipMemAccessDesc*, size_t) {
+  if (!inside_reservation(p, n)) return ret(hipErrorInvalidValue);
+  return mprotect(p, n, PROT_READ | PROT_WRITE) ? ret(hipErrorInvalidValue) : hipSuccess;
+}
 hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return ret(hipErrorNotSupported); }
 hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return ret(hipErrorNotSupported); }
 hipError_t hipIpcCloseMemHandle(void*) { return ret(hipErrorNotSupported); }

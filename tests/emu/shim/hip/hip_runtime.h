@@ -140,7 +140,13 @@ int readfirstlane(int);
 void mfma_f32(float a, float b, const float* c, float* d);
 void mfma_f64(double a, double b, const double* c, double* d);
 uint64_t shfl_bits(uint64_t bits, int src_lane_delta, int mode);  // mode 0: down, 1: xor, 2: idx
-void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()>& body);
+// runs the workgroups now -- or, while `stream` is being captured into a graph, records the launch
+void launch(dim3 grid, dim3 block, size_t lds, hipStream_t stream, std::function<void()> body);
+// arguments are evaluated and copied at the call, as a kernel launch does
+template <typename K, typename... A>
+inline void launch_kernel(dim3 grid, dim3 block, size_t lds, hipStream_t stream, K kern, A... args) {
+  launch(grid, block, lds, stream, [=]() { kern(args...); });
+}
 inline unsigned char* lds_at(unsigned a) { return reinterpret_cast<unsigned char*>((uintptr_t)a); }
 }  // namespace hq_emu
 
@@ -193,4 +199,4 @@ template <typename T> inline T __shfl_xor(T v, int mask, int width = 64) {
 template <typename T, typename U> inline T atomicAdd(T* p, U v) { T old = *p; *p = old + (T)v; return old; }
 
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
-  hq_emu::launch(grid, block, lds, [&]() { (kern)(__VA_ARGS__); })  /* runs to completion before it returns */
+  hq_emu::launch_kernel(grid, block, lds, stream, kern, __VA_ARGS__)

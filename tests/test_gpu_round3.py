@@ -253,7 +253,7 @@ def test_reference_driver_protocol_over_the_host_pointer_path(torch_cuda, ct):
     n = 14
     gates = rqc_1q2q(n, depth=6, seed=4) + random_dense(n, 20, kmax=5, seed=5, unitary=True)
     cpu = oracle.load_ref() if oracle.have_ref() else oracle.load_port()
-    hip = OracleLib(core._LIB_PATH, kind='hip, host pointers')
+    hip = OracleLib(core._lib._name, kind='hip, host pointers')  # the library the binding loaded
     assert hip.log2_pack_size >= 1  # truthy, else the reference falls back to einsum (simulation.py:393-397)
     trace_cpu, trace_hip = [], []
     exp, _ = oracle.evolve_reference_protocol(cpu, gates, n, complex_type=ct, log2_pack_size=3, trace=trace_cpu)

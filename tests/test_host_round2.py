@@ -19,12 +19,11 @@ def test_choose_schedule_cost_model():
     ops, info = choose_schedule(gates, list(range(n)), n, np.dtype('complex64'))
     est = dict(info['modelled_ms'])
     # measured on MI355X (profiles/r02_v7_bench.json): 2415-2509 / 399-408 / 307-311 / 135-148 ms
-    # the auto schedule plans the blocked passes with the quick search (tries=8, one fusion order: 151 ms modelled, 50 ms
-    # of host time); the full search of an explicit blocked=True reaches the measured 137
-    assert abs(est['per_gate'] - 2431) < 50 and abs(est['blocked'] - 151) < 10 and info['chosen'] == 'blocked'
+    # the auto schedule plans the blocked passes at full search effort (round 4: the planner is native, 17 ms of host
+    # time); the model puts the plan at the measured 137 ms within 10
+    assert abs(est['per_gate'] - 2431) < 50 and abs(est['blocked'] - 140) < 12 and info['chosen'] == 'blocked'
     full = estimate_ms(_plan_ops(gates, list(range(n)), n, np.dtype('complex64'), 5, True), n, np.dtype('complex64'))
-    assert abs(full - 137) < 10 and full < est['blocked']
-    est['blocked'] = full
+    assert full == pytest.approx(est['blocked'])
     # the fused schedules are only PREDICTED here (from the qubit sets), not planned: they cannot beat the blocked one
     assert info['not_planned'] == ['fused_4', 'fused_5']
     for name, k, ms, tol in (('fused_4', 4, 400, 25), ('fused_5', 5, 307, 15)):
@@ -41,13 +40,13 @@ def test_choose_schedule_cost_model():
     _, small = choose_schedule(rqc_1q2q(10, depth=8, seed=1), list(range(10)), 10, np.dtype('complex64'))
     assert 'blocked' not in small['modelled_ms'] and 'blocked' not in small['not_planned']
     # ... and planning is host time too: a schedule is planned only when its predicted device time plus its planning time
-    # beats the best plan in hand, so short loops run gate by gate at once, n = 25 plans fusion to 4 only and
-    # n >= 26 the cache-blocked schedule only
+    # beats the best plan in hand, so short loops run gate by gate at once and n >= 24 plans the cache-blocked schedule
+    # only (round 3, with the Python planner: fusion to 4 at n = 25, blocked from n = 26)
     assert small['chosen'] == 'per_gate' and small['not_planned'] == ['fused_4', 'fused_5']
     _, mid = choose_schedule(rqc_1q2q(20, depth=40, seed=20), list(range(20)), 20, np.dtype('complex64'))
     assert mid['chosen'] == 'per_gate' and mid['not_planned'] == ['fused_4', 'fused_5', 'blocked']
     _, m25 = choose_schedule(rqc_1q2q(25, depth=40, seed=25), list(range(25)), 25, np.dtype('complex64'))
-    assert m25['chosen'] == 'fused_4' and m25['not_planned'] == ['fused_5', 'blocked']
+    assert m25['chosen'] == 'blocked' and m25['not_planned'] == ['fused_4', 'fused_5']
     _, m28 = choose_schedule(rqc_1q2q(28, depth=40, seed=28), list(range(28)), 28, np.dtype('complex64'))
     assert m28['chosen'] == 'blocked' and m28['not_planned'] == ['fused_4', 'fused_5']
     # FunctionalGates cut the prediction's runs like they cut the plans
@@ -204,10 +203,12 @@ def test_blocked_planner_keeps_passes_inside_the_lds_tables():
     again = plan_blocked(gates, pos, n)
     assert [(o[0], len(o[2])) for o in ops] == [(o[0], len(o[2])) for o in again]
     st = blocked_stats(ops)
-    assert st['blocked_passes'] <= 30 and st['plain_gates'] == 0 and st['inner_gates'] <= 160
+    # (the native planner and the Python one draw different random numbers: 26-30 passes, now and then a leftover gate)
+    assert st['blocked_passes'] + st['plain_gates'] <= 31 and st['plain_gates'] <= 2 and st['inner_gates'] <= 160
     inv = {p: q for q, p in pos.items()}
     for op in ops:
-        assert op[0] == 'B'
+        if op[0] != 'B':
+            continue
         assert lds_bytes([(U, [inv[p] for p in ps]) for U, ps in op[2]]) <= LDS_TABLE_BUDGET
     unfused = plan_blocked(gates, pos, n, inner_max=0)
     assert sum(len(o[2]) for o in unfused if o[0] == 'B') + sum(1 for o in unfused if o[0] == 'G') == len(gates)
