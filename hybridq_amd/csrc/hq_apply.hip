@@ -330,40 +330,6 @@ static int launch_mfma_big_kv(Context& c, T* re, T* im, const T* dA, const MfmaP
       if ((ld >> b) & 1) { o |= P.ro.r_off[b]; pl = pl || P.ro.r_plane == b; }
     tab.off[ld] = (int64_t)(16 * o) + (pl ? plane_step : 0);
   }
-  // experiment / candidate default: one wave per SIMD with two register sets and the memory operations interleaved into
-  // the MFMA stream (apply_mfma_stream_kernel); HQ_BIG_STREAM = quarters of the phase the memory operations span (2..4)
-  static const int stream_q = env_int("HQ_BIG_STREAM", 0);
-  if constexpr (sizeof(T) == 4) {  // complex128 k = 6 with two register sets spills (256 + 256 registers, 308 B scratch): float only
-    if (stream_q >= 2 && stream_q <= 4) {
-      constexpr unsigned CBs = Vec<T>::VB;
-      constexpr int NSs = KBITS - 2, NRBs = 1 << (NSs - 2), NSTEPs = 1 << NSs;
-      constexpr size_t lds = (size_t)NRBs * NSTEPs * 64 * sizeof(T);
-      const uint64_t niter = (1ull << (n - CBs - P.n_addr)) >> 4;
-      static const int sgrid = env_int("HQ_BIG_GRID", 256);
-      const unsigned grid = (unsigned)std::min<uint64_t>((niter + 3) / 4, (uint64_t)sgrid);
-      const MfmaRoles ro = P.ro;
-      auto go = [&](auto nt_tag, auto q_tag) -> int {
-        constexpr bool NTv = decltype(nt_tag)::value;
-        constexpr int Q = decltype(q_tag)::value;
-        static bool attr_done = false;
-        if (!attr_done) {
-          HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_mfma_stream_kernel<T, KBITS, VMASK, NTv, Q>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          attr_done = true;
-        }
-        HQ_LAUNCH(c, (apply_mfma_stream_kernel<T, KBITS, VMASK, NTv, Q>), dim3(grid), dim3(256), lds, re, im, dA, ro, tab, niter);
-        return 0;
-      };
-      auto by_q = [&](auto nt_tag) -> int {
-        switch (stream_q) {
-          case 2: return go(nt_tag, std::integral_constant<int, 2>{});
-          case 3: return go(nt_tag, std::integral_constant<int, 3>{});
-          default: return go(nt_tag, std::integral_constant<int, 4>{});
-        }
-      };
-      return P.nt ? by_q(std::true_type{}) : by_q(std::false_type{});
-    }
-  }
   if (big_phased(KBITS, sizeof(T) == 8)) return launch_mfma_big_var<T, KBITS, VMASK, true>(c, re, im, dA, P, n, tab);
   return launch_mfma_big_var<T, KBITS, VMASK, false>(c, re, im, dA, P, n, tab);
 }
@@ -918,21 +884,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
     if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
     const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes;
-    // experiment (HQ_BLOCKED_GPRE=1): the operand / lane-table reads of the NEXT inner gate issued in front of the barrier that
-    // ends the current one.  Measured on the n = 30 benchmark circuit: 138.6 ms with it, 136.8 without -- the per-gate
-    // prologue is not what holds the matrix pipe at 73 % -- so it stays off.
-    static int use_gpre = env_int("HQ_BLOCKED_GPRE", 0);
-    if (pref && use_gpre && sizeof(T) == 4) {  // complex128 has no registers left for it
-      static bool attr2 = false;
-      if (!attr2) {
-        if constexpr (sizeof(T) == 4)
-          HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_blocked_kernel<T, 512, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr2 = true;
-      }
-      if constexpr (sizeof(T) == 4)
-        HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
-                  n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
-    } else if (pref) {
+    if (pref) {
       HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
                 n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
     } else {
@@ -995,8 +947,3 @@ int hq_apply_blocked_float64(double* re, double* im, unsigned int n, const unsig
 
 }  // extern "C"
 
-#ifdef HQ_EXP_TIMELINE
-extern "C" int hq_debug_timeline(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hq::hq_timeline), sizeof(unsigned long long) * 512);
-}
-#endif

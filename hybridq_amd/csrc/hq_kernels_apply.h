@@ -7,12 +7,6 @@
 // Pins a wave-uniform value to scalar registers (stops the optimiser from hoisting per-lane copies of it out of a loop).
 // Under AddressSanitizer (-DHQ_ASAN: tools/asan_smoke.sh) the instrumented code computes it per lane and the constraint
 // cannot be met: the pin is dropped there, it only matters for speed.
-#ifndef HQ_BLOCKED_MERGE2
-#define HQ_BLOCKED_MERGE2 0  // experiment: both wave-iterations of a k <= 3 inner gate as one body (139.0 vs 137.0 ms: off)
-#endif
-#ifndef HQ_BIG_F64_PIPE
-#define HQ_BIG_F64_PIPE 0  // 1: keep the operand double buffer in the complex128 k = 6 kernel (218 registers, spills)
-#endif
 #ifdef HQ_ASAN
 #define HQ_PIN_SGPR(x) ((void)0)
 #else
@@ -320,12 +314,7 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
       V* ptr = reinterpret_cast<V*>(lane_base + (it_off + tab.off[ld]));
-#ifdef HQ_EXP_BIG_NOMEM  // experiment: MFMA phase alone
-      x[ld] = V{};
-      asm volatile("" : "+v"(x[ld]));
-#else
       x[ld] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
-#endif
     }
   };
   // the store addresses are computed from an opaque copy of the iteration offset: shared with the
@@ -336,26 +325,18 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
       V* ptr = reinterpret_cast<V*>(lane_base + (st_off + tab.off[ld]));
-#ifdef HQ_EXP_BIG_NOMEM
-      asm volatile("" ::"v"(x[ld]), "v"(ptr));
-#else
       if (NT) __builtin_nontemporal_store(x[ld], ptr);
       else *ptr = x[ld];
-#endif
     }
   };
-#ifdef HQ_EXP_BIG_NOMFMA  // experiment: memory phases alone
-#define HQ_BIG_MFMA(a_, b_, c_) (c_ + Acc{(a_) * (b_), 0, 0, 0})
-#else
 #define HQ_BIG_MFMA(a_, b_, c_) Mfma<T>::run(a_, b_, c_)
-#endif
   // MFMA phase, software-pipelined: the operand reads of pair-group g+1 (two ds_read_b128: row blocks
   // 2p and 2p+1 of one step group) are issued BEFORE the 2*G MFMAs of pair-group g, which alternate
   // between the two accumulators (a 16x16x4 MFMA issues every 32 cycles but its result is only
   // available after 40: back-to-back MFMAs on ONE accumulator lose a fifth of the pipe).  The
   // pipeline runs across column blocks (the operand sequence repeats): only the first read of an
   // iteration is exposed.  Alone this phase runs at 149 of 157 TFLOP/s (k = 6 knock-out).
-  constexpr bool kOperandPipe = !(sizeof(T) == 8 && NL == 32) || HQ_BIG_F64_PIPE;
+  constexpr bool kOperandPipe = !(sizeof(T) == 8 && NL == 32);  // (with it the complex128 k = 6 kernel needs 218 registers and spills)
   auto compute = [&](V (&x)[NL]) {
     V a0 = Al[0], a1 = Al[NG * 64];
 #pragma unroll
@@ -440,155 +421,6 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
 }
 
 // ---------------------------------------------------------------------------------
-// apply_mfma_stream_kernel: k = 5, 6 with ONE wave per SIMD and TWO register sets (round 3).
-//
-// The barrier-phased form above alternates two waves per SIMD: while one multiplies, the other stores its 2^NR result
-// vectors and requests its next 2^NR input vectors in one burst.  At k = 6 the matrix-core phase (3.69 ms alone at
-// n = 30) and the memory phases (3.6 ms alone) are the same length, so every late vector of a burst stalls the pipe
-// (4.65 ms together).  Here a wave owns 256 threads' worth of registers (launch bounds 256, one workgroup per CU) and
-// keeps TWO sets of 2^NR vectors: while it multiplies set X (wave-iteration p) it stores set Y (the results of p-1) and
-// re-fills Y with the inputs of p+1 -- one store / one load placed between the MFMA groups of the stream, so that the
-// memory traffic of a CU is a steady trickle instead of a burst and the matrix pipe of a SIMD is fed by one wave without
-// a phase switch.  vmcnt is in order: every load is issued after the store of the register it overwrites and is waited
-// for (by the compiler's own counters) a whole phase later.  No barriers after the operand table is staged.
-// ---------------------------------------------------------------------------------
-template <typename T, int KBITS, int VMASK, bool NT, int SPANQ>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-apply_mfma_stream_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ A,
-                         const MfmaRoles ro, const BigOffsets tab, const uint64_t niter) {
-  using V = typename Vec<T>::type;
-  using Acc = typename Mfma<T>::acc;
-  HQ_DYN_LDS(hq_big_smem);
-  constexpr int BLOCK = 256;
-  constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB, G = 16 / (int)sizeof(T);
-  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR, NA = KBITS - 1 - KV;
-  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS, NG = NSTEP / G;
-  constexpr int FMASK = ~VMASK & (NCOMP - 1);
-  constexpr int NP = NRB / 2, NGRP = NG * NP, NPG = NGRP * NCB;  // pair-groups of 2 G MFMAs per wave-iteration
-  static_assert(NL <= 32 && NRB >= 2, "shape");
-  V* __restrict__ As = reinterpret_cast<V*>(hq_big_smem);
-  {
-    const V* __restrict__ Ag = reinterpret_cast<const V*>(A);
-    for (int e = threadIdx.x; e < NRB * NG * 64; e += BLOCK) As[e] = Ag[e];
-  }
-  __syncthreads();
-  const unsigned lane = threadIdx.x & 63;
-  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned q = lane >> 4, j = lane & 15;
-  const V* __restrict__ Al = As + lane;
-  auto spread = [&](uint64_t v) {
-#pragma unroll
-    for (int m = 0; m < NA; ++m) {
-      const uint64_t lo = (1ull << ro.pos[m]) - 1;
-      v = ((v & ~lo) << 1) | (v & lo);
-    }
-    return v;
-  };
-  const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
-  const uint64_t lane_vec = spread((uint64_t)j) | ((q & 1) ? (uint64_t)ro.q_off[0] : 0ull) | ((q & 2) ? (uint64_t)ro.q_off[1] : 0ull);
-  unsigned char* const lane_base = reinterpret_cast<unsigned char*>(lane_plane ? im : re) + 16 * lane_vec;
-  auto vptr = [&](int64_t it_off, int ld) { return reinterpret_cast<V*>(lane_base + (it_off + tab.off[ld])); };
-  auto it_offset = [&](uint64_t it) { return (int64_t)(16 * spread(it * 16)); };
-  auto load1 = [&](V& x, int64_t off, int ld) { x = NT ? __builtin_nontemporal_load(vptr(off, ld)) : *vptr(off, ld); };
-  auto store1 = [&](const V& x, int64_t off, int ld) {
-    if (NT) __builtin_nontemporal_store(x, vptr(off, ld));
-    else *vptr(off, ld) = x;
-  };
-  // one wave-iteration on X; between its MFMA pair-groups: store Y[ld] (results of the previous iteration, at st_off) and
-  // re-fill Y[ld] (inputs of the next one, at ld_off).  The 2 NL memory operations sit in the first SPANQ quarters of the
-  // pair-groups (compile time: register indices must be static).
-  constexpr int span = NPG * SPANQ / 4;
-  auto phase = [&](V (&x)[NL], V (&y)[NL], auto overlap_tag, int64_t st_off, int64_t ld_off) {
-    constexpr bool overlap = decltype(overlap_tag)::value;
-    HQ_PIN_SGPR(st_off);
-    HQ_PIN_SGPR(ld_off);
-    V a0 = Al[0], a1 = Al[NG * 64];
-#pragma unroll
-    for (int cf = 0; cf < NCB; ++cf) {
-      Acc acc[NRB];
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) acc[rb] = Acc{0, 0, 0, 0};
-#pragma unroll
-      for (int g = 0; g < NGRP; ++g) {
-        const int sg = g / NP, rb = 2 * (g % NP);
-        const int gn = (g + 1) % NGRP, sgn = gn / NP, rbn = 2 * (gn % NP);
-        V n0 = a0, n1 = a1;
-        if (g + 1 < NGRP || cf + 1 < NCB) {
-          n0 = Al[(rbn * NG + sgn) * 64];
-          n1 = Al[((rbn + 1) * NG + sgn) * 64];
-        }
-        if constexpr (overlap) {
-          const int gg = cf * NGRP + g;  // 0 .. NPG-1
-          // memory operation number mo = 0 .. 2 NL - 1 (even: store ld = mo / 2, odd: load ld = mo / 2) goes in front of
-          // pair-group floor(mo * span / (2 NL))
-          const int m_lo = (gg * 2 * NL + span - 1) / span, m_hi = ((gg + 1) * 2 * NL + span - 1) / span;
-#pragma unroll
-          for (int mo = m_lo; mo < m_hi && mo < 2 * NL; ++mo) {
-            if (mo & 1) load1(y[mo >> 1], ld_off, mo >> 1);
-            else store1(y[mo >> 1], st_off, mo >> 1);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < G; ++t) {
-          const int s = sg * G + t;
-          const int ck = s & ((1 << KV) - 1), ld = s >> KV;
-          const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
-          acc[rb] = Mfma<T>::run(a0[t], x[ld][comp], acc[rb]);
-          acc[rb + 1] = Mfma<T>::run(a1[t], x[ld][comp], acc[rb + 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = n0;
-        a1 = n1;
-      }
-#pragma unroll
-      for (int ld = 0; ld < NL; ++ld) {
-#pragma unroll
-        for (int ck = 0; ck < (1 << KV); ++ck) {
-          const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
-          const int so = ck | (ld << KV);
-          x[ld][comp] = acc[so >> 2][so & 3];
-        }
-        if (NCB > 1) asm volatile("" : "+v"(x[ld]));
-      }
-    }
-  };
-  const uint64_t stride = (uint64_t)gridDim.x * (BLOCK / 64);
-  const uint64_t first = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
-  if (first >= niter) return;
-  const uint64_t m = (niter - first + stride - 1) / stride;  // wave-iterations of this wave
-  auto it_of = [&](uint64_t p) { return first + (p < m ? p : m - 1) * stride; };  // clamped: a wasted, harmless load at the end
-  V xa[NL], xb[NL];
-  {
-    const int64_t o0 = it_offset(it_of(0)), o1 = it_offset(it_of(1));
-#pragma unroll
-    for (int ld = 0; ld < NL; ++ld) load1(xa[ld], o0, ld);
-#pragma unroll
-    for (int ld = 0; ld < NL; ++ld) load1(xb[ld], o1, ld);
-  }
-  phase(xa, xb, std::false_type{}, 0, 0);  // wave-iteration 0: nothing to store yet
-  uint64_t p = 1;
-  while (true) {
-    if (p >= m) {
-      const int64_t o = it_offset(it_of(p - 1));
-#pragma unroll
-      for (int ld = 0; ld < NL; ++ld) store1(xa[ld], o, ld);
-      break;
-    }
-    phase(xb, xa, std::true_type{}, it_offset(it_of(p - 1)), it_offset(it_of(p + 1)));
-    ++p;
-    if (p >= m) {
-      const int64_t o = it_offset(it_of(p - 1));
-#pragma unroll
-      for (int ld = 0; ld < NL; ++ld) store1(xb[ld], o, ld);
-      break;
-    }
-    phase(xa, xb, std::true_type{}, it_offset(it_of(p - 1)), it_offset(it_of(p + 1)));
-    ++p;
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // apply_blocked (f32 and f64): MANY gates in ONE HBM pass.
 //
 // The per-gate kernels above sit at the memory system's ceiling (~3 ms per pass at n = 30),
@@ -620,29 +452,10 @@ struct BlockedGate {
   unsigned pad_;
 };
 
-#ifdef HQ_EXP_TIMELINE  // experiment: s_memtime stamps of one workgroup's waves through one inner gate
-__device__ unsigned long long hq_timeline[2 * 16 * 16];
-__device__ int hq_timeline_on;  // set by the kernel for the (workgroup, tile, gate) being recorded
-#define HQ_STAMP(i)                                                                                              \
-  do {                                                                                                           \
-    if (hq_tl_rec) hq_timeline[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter();                      \
-  } while (0)
-#define HQ_TSTAMP(i)                                                                                             \
-  do {                                                                                                           \
-    if (hq_tile_rec) hq_timeline[128 + (threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter();             \
-  } while (0)
-#else
-#define HQ_STAMP(i) do {} while (0)
-#define HQ_TSTAMP(i) do {} while (0)
-#endif
 template <typename T, int KBITS, int VMASK, int BLOCK>
 __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __restrict__ xi,
                                                    const BlockedGate& G, const T* __restrict__ A,
-                                                   const unsigned tile_vec_bits
-#ifdef HQ_EXP_TIMELINE
-                                                   , const bool hq_tl_flag = false
-#endif
-) {
+                                                   const unsigned tile_vec_bits) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
   constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;
@@ -651,10 +464,6 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
   constexpr int FMASK = ~VMASK & (NCOMP - 1);
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#ifdef HQ_EXP_TIMELINE
-  const bool hq_tl_rec = hq_tl_flag && lane == 0;
-#endif
-  HQ_STAMP(1);
   const unsigned q = lane >> 4, j = lane & 15;
   const MfmaRoles& ro = G.ro;
   T a[NRB][NSTEP];
@@ -694,7 +503,6 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
   }
   unsigned char* const tile = reinterpret_cast<unsigned char*>(xr);  // xi = xr + one plane: the plane is bit tile_vec_bits
   const unsigned niter = (1u << (tile_vec_bits - G.n_addr)) >> 4;  // 16 slots per wave iteration
-  HQ_STAMP(2);
   for (unsigned t = 0; (t << WB) + wave < niter; ++t) {
     const unsigned Lt = L ^ (blocked_swz(deposit(t << (4 + WB))) << 4);
     unsigned addr[NL];
@@ -704,16 +512,6 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
       addr[ld] = Lt ^ OFF[ld];
       x[ld] = *reinterpret_cast<V*>(tile + addr[ld]);
     }
-#ifdef HQ_EXP_READS_FIRST
-    __builtin_amdgcn_sched_barrier(0);  // all reads of the iteration in flight before the first MFMA
-#endif
-#ifdef HQ_EXP_TIMELINE
-    __builtin_amdgcn_sched_barrier(0);
-    HQ_STAMP(3 + 4 * t);  // reads issued
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    HQ_STAMP(4 + 4 * t);  // reads returned
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     Acc acc[NCB][NRB];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf)
@@ -727,11 +525,7 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
         const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
-#ifdef HQ_EXP_NO_MFMA  // experiment: LDS traffic only
-          acc[cf][rb] += x[ld][comp] * a[rb][s];
-#else
           acc[cf][rb] = Mfma<T>::run(a[rb][s], x[ld][comp], acc[cf][rb]);
-#endif
       }
     }
 #pragma unroll
@@ -743,23 +537,8 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
         const int so = ck | (ld << KV);
         y[comp] = acc[cf][so >> 2][so & 3];
       }
-#ifdef HQ_EXP_NO_WRITE  // experiment: keep the result alive without the LDS store
-      asm volatile("" ::"v"(y));
-#else
-#ifdef HQ_EXP_TIMELINE
-      if (ld == 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        HQ_STAMP(5 + 4 * t);  // MFMAs done (first result consumed)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
       *reinterpret_cast<V*>(tile + addr[ld]) = y;
-#endif
     }
-#ifdef HQ_EXP_TIMELINE
-    __builtin_amdgcn_sched_barrier(0);
-    HQ_STAMP(6 + 4 * t);  // writes issued
-#endif
   }
 }
 
@@ -770,29 +549,7 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
 // (x 4 waves) cost as much issue time as the MFMAs cost pipe time -- segments of 15-30 instructions took 900-1300
 // cycles.  So every per-gate quantity that does not depend on the data is read from a table the workgroup builds
 // ONCE per kernel: address(lane, iteration it, register digit ld) = LANE[lane] ^ ITER[it] ^ OFF[ld] (see the XOR
-// argument in blocked_inner_gate), one ds_read_b32 + one v_xor3 per vector, and the result rows go back with
-// ds_write2_b32 pairs straight from the accumulators instead of 15 v_mov + 4 ds_write_b128.
-// Two elements from two unrelated registers to consecutive element slots `first`, `first + 1` after LDS byte address `a`.
-#ifdef HQ_EMU  // tests/emu: the two stores spelled out (LDS byte addresses are host addresses there)
-__device__ __forceinline__ void lds_write2(unsigned a, float v0, float v1, int first) {
-  float* p = reinterpret_cast<float*>(hq_emu::lds_at(a)) + (first == 0 ? 0 : 2);
-  p[0] = v0;
-  p[1] = v1;
-}
-__device__ __forceinline__ void lds_write2(unsigned a, double v0, double v1, int) {
-  double* p = reinterpret_cast<double*>(hq_emu::lds_at(a));
-  p[0] = v0;
-  p[1] = v1;
-}
-#else
-__device__ __forceinline__ void lds_write2(unsigned a, float v0, float v1, int first) {
-  if (first == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(a), "v"(v0), "v"(v1) : "memory");
-  else asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" ::"v"(a), "v"(v0), "v"(v1) : "memory");
-}
-__device__ __forceinline__ void lds_write2(unsigned a, double v0, double v1, int) {
-  asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" ::"v"(a), "v"(v0), "v"(v1) : "memory");
-}
-#endif
+// argument in blocked_inner_gate), one ds_read_b32 + one v_xor3 per vector.
 typedef unsigned BlockedTabT;  // 16-bit entries were tried: more passes fit their tables, each gate 7 % slower
 constexpr unsigned kBlockedTabLane = 0, kBlockedTabIter = 64, kBlockedTabOff = 128, kBlockedTabWords = 136;
 
@@ -836,23 +593,9 @@ __device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ t
   }
 }
 
-// The prologue of the NEXT gate (4 operand values and the lane entry of a k <= 3 gate: the reads whose address hangs on the
-// gate descriptor's scalar load) requested while the current gate runs; the 4 register-digit entries are read at the
-// gate's start (holding them too spills: 128 registers is the budget of four waves per SIMD).  Unconditional, whatever the next
-// gate's kind (wider gates load the rest themselves): a conditional request would merge old and new register values.
-template <typename T> struct BlockedPre {
-  T a[4];
-  unsigned L;
-};
-
-template <typename T, int KBITS, int VMASK, int BLOCK, bool USEPRE = false>
+template <typename T, int KBITS, int VMASK, int BLOCK>
 __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
-                                                       const BlockedTabT* __restrict__ tab, const unsigned niter,
-                                                       const BlockedPre<T>& pre
-#ifdef HQ_EXP_TIMELINE
-                                                       , const bool hq_tl_flag = false
-#endif
-) {
+                                                       const BlockedTabT* __restrict__ tab, const unsigned niter) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
   constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;
@@ -862,83 +605,17 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
   constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#ifdef HQ_EXP_TIMELINE
-  const bool hq_tl_rec = hq_tl_flag && lane == 0;
-  int hq_t = 0;
-#endif
-  HQ_STAMP(1);
   T a[NRB][NSTEP];
   unsigned L;
   unsigned OFF[NL];
-  if constexpr (USEPRE && KBITS == 4) {  // requested one gate ahead (apply_blocked_kernel): nothing to wait for here
-    static_assert(NRB == 1 && NSTEP == 4 && NL <= 4, "k <= 3 shape");
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) a[0][s] = pre.a[s];
-    L = pre.L;
+  for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-    for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
-  } else {
+    for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
+  L = tab[kBlockedTabLane + lane];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
-    L = tab[kBlockedTabLane + lane];
-#pragma unroll
-    for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
-  }
+  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
   typedef __attribute__((address_space(3))) V LdsV;  // addresses are absolute LDS byte addresses (base folded in LANE)
-  HQ_STAMP(2);
-#if HQ_BLOCKED_MERGE2
-  // The usual case of a k <= 3 gate on a 2^13 tile: exactly TWO wave-iterations per wave.  Both as ONE body -- 2 NL reads,
-  // 32 MFMAs alternating between the two iterations' accumulators, 2 NL writes -- instead of read / 16 MFMAs / write twice:
-  // one drain of the matrix pipe per gate and wave instead of two (tools/lds_mfma_overlap.hip: 2601 -> 2429 cycles per
-  // 16 wave-iterations with the per-gate barrier).
-  if constexpr (KBITS == 4 && NRB == 1) {
-    if (niter == (2u << WB)) {
-      const unsigned Lt0 = L ^ tab[kBlockedTabIter + wave], Lt1 = L ^ tab[kBlockedTabIter + wave + (1u << WB)];
-      unsigned ad0[NL], ad1[NL];
-      V x0[NL], x1[NL];
-#pragma unroll
-      for (int ld = 0; ld < NL; ++ld) {
-        ad0[ld] = Lt0 ^ OFF[ld];
-        x0[ld] = *reinterpret_cast<LdsV*>((uintptr_t)ad0[ld]);
-      }
-#pragma unroll
-      for (int ld = 0; ld < NL; ++ld) {
-        ad1[ld] = Lt1 ^ OFF[ld];
-        x1[ld] = *reinterpret_cast<LdsV*>((uintptr_t)ad1[ld]);
-      }
-      Acc c0[NCB], c1[NCB];
-#pragma unroll
-      for (int cf = 0; cf < NCB; ++cf) { c0[cf] = Acc{0, 0, 0, 0}; c1[cf] = Acc{0, 0, 0, 0}; }
-#pragma unroll
-      for (int s2 = 0; s2 < NSTEP; ++s2) {
-        const int ck = s2 & ((1 << KV) - 1), ld = s2 >> KV;
-#pragma unroll
-        for (int cf = 0; cf < NCB; ++cf) {
-          const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
-          c0[cf] = Mfma<T>::run(a[0][s2], x0[ld][comp], c0[cf]);
-          c1[cf] = Mfma<T>::run(a[0][s2], x1[ld][comp], c1[cf]);
-        }
-      }
-#pragma unroll
-      for (int ld = 0; ld < NL; ++ld) {
-        V y0, y1;
-#pragma unroll
-        for (int comp = 0; comp < NCOMP; ++comp) {
-          const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
-          const int so = ck | (ld << KV);
-          y0[comp] = c0[cf][so & 3];
-          y1[comp] = c1[cf][so & 3];
-        }
-        *reinterpret_cast<LdsV*>((uintptr_t)ad0[ld]) = y0;
-        *reinterpret_cast<LdsV*>((uintptr_t)ad1[ld]) = y1;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      return;
-    }
-  }
-#endif
   for (unsigned it = wave; it < niter; it += 1u << WB) {
     const unsigned Lt = L ^ tab[kBlockedTabIter + it];
     unsigned addr[NL];
@@ -948,13 +625,6 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
       addr[ld] = Lt ^ OFF[ld];
       x[ld] = *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]);
     }
-#ifdef HQ_EXP_TIMELINE
-    __builtin_amdgcn_sched_barrier(0);
-    HQ_STAMP(3 + 4 * hq_t);  // reads issued
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    HQ_STAMP(4 + 4 * hq_t);  // reads returned
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     Acc acc[NCB][NRB];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf)
@@ -975,26 +645,6 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
     // stores into exactly that); ds_write2 takes its two elements from any two registers.  Inline assembly: the
     // compiler neither counts these stores (lgkmcnt is drained by hand after the loop) nor pads the
     // MFMA-result -> LDS-read hazard in front of them (s_nop by hand: 8-pass MFMA, 16 wait states cover it).
-#ifdef HQ_BLOCKED_WRITE2
-    // (each accumulator block passes through an empty volatile asm first: volatile asms keep their order, so every
-    // MFMA is issued before the s_nop and every store after it)
-#pragma unroll
-    for (int cf = 0; cf < NCB; ++cf)
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) asm volatile("" : "+v"(acc[cf][rb]));
-    asm volatile("s_nop 15" ::: "memory");
-    HQ_STAMP(5 + 4 * hq_t);  // MFMAs issued
-#pragma unroll
-    for (int ld = 0; ld < NL; ++ld) {
-      const unsigned la = addr[ld];
-#pragma unroll
-      for (int c2 = 0; c2 < NCOMP; c2 += 2) {
-        const int so0 = pext_c(c2, VMASK) | (ld << KV), so1 = pext_c(c2 + 1, VMASK) | (ld << KV);
-        lds_write2(la, acc[pext_c(c2, FMASK)][so0 >> 2][so0 & 3], acc[pext_c(c2 + 1, FMASK)][so1 >> 2][so1 & 3], c2);
-      }
-    }
-#else
-    HQ_STAMP(5 + 4 * hq_t);
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
       V y;
@@ -1006,11 +656,6 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
       }
       *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]) = y;
     }
-#endif
-#ifdef HQ_EXP_TIMELINE
-    HQ_STAMP(6 + 4 * hq_t);  // writes issued
-    ++hq_t;
-#endif
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -1100,7 +745,7 @@ __device__ __forceinline__ void blocked_inner_gate_valu(T* __restrict__ xr, T* _
 // before the gates of the current tile start and dropped into LDS after its stores were issued.  Needs the
 // no-scratch register budget: a scratch reload is a vector-memory load and would queue (vmcnt is in order) behind
 // the prefetch it was supposed to overlap.
-template <typename T, int BLOCK, bool ALDS, bool PREF, bool GPRE = false>
+template <typename T, int BLOCK, bool ALDS, bool PREF>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* __restrict__ gates,
                      const unsigned ngates, const T* __restrict__ Atab, const unsigned a_elems,
@@ -1171,13 +816,6 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
   // (70 scalar instructions with spilled masks each)
   const uint64_t dep_mask = tile_base(~0ull), dep_stride = tile_base(stride);
   auto next_base = [&](uint64_t b) { return ((b | ~dep_mask) + dep_stride) & dep_mask; };
-#ifdef HQ_EXP_STAGGER  // experiment: start half of the workgroups late (HQ_EXP_STAGGER_ODD: by parity, else second half of the grid)
-#ifdef HQ_EXP_STAGGER_ODD
-  if (blockIdx.x & 1) __builtin_amdgcn_s_sleep(HQ_EXP_STAGGER);
-#else
-  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(HQ_EXP_STAGGER);
-#endif
-#endif
   if constexpr (PREF) {
     if (blockIdx.x >= ntiles) return;
     // the tile is filled at the END of the loop body, right after the stores of the previous tile were issued: on
@@ -1196,56 +834,22 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
   }
   uint64_t base_cur = tile_base(blockIdx.x);
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += stride) {
-#ifdef HQ_EXP_TIMELINE
-    const bool hq_tile_rec = blockIdx.x == 7 && tile == blockIdx.x + 3 * stride && (threadIdx.x & 63) == 0;
-#endif
-    HQ_TSTAMP(0);
     const uint64_t base = PREF ? base_cur : tile_base(tile);
-    HQ_TSTAMP(1);
     if constexpr (!PREF) {
       for (unsigned e = tid; e < nvec; e += BLOCK) {
         const uint64_t g = base | vec_off(e);
-#ifdef HQ_BLOCKED_PLAIN_IO
-        reinterpret_cast<V*>(xr)[blocked_swz(e)] = vre[g];
-        reinterpret_cast<V*>(xi)[blocked_swz(e)] = vim[g];
-#else  // streamed once per pass: keep the tile out of the caches
         reinterpret_cast<V*>(xr)[blocked_swz(e)] = __builtin_nontemporal_load(vre + g);
         reinterpret_cast<V*>(xi)[blocked_swz(e)] = __builtin_nontemporal_load(vim + g);
-#endif
       }
     }
     __syncthreads();
-    HQ_TSTAMP(2);
-    BlockedPre<T> pre_next;
-    auto request = [&](unsigned gn) {  // prologue of gate gn (clamped by the caller): LDS reads only, waited for when used
-      const T* An = als + gates[gn].a_off;
-      const BlockedTabT* tn = tabs + gn * kBlockedTabWords;
-      const unsigned lane = tid & 63;
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) pre_next.a[s2] = An[s2 * 64 + lane];
-      pre_next.L = tn[kBlockedTabLane + lane];
-    };
-    if constexpr (GPRE && ALDS) request(0);
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedGate& G = gates[gi];
       const T* A = ALDS ? als + G.a_off : Atab + G.a_off;
-      const BlockedPre<T>& pre = pre_next;  // consumed in the gate's first instructions; re-requested after its last
-#ifdef HQ_EXP_TIMELINE
-      const bool hq_tl_flag = blockIdx.x == 7 && tile == blockIdx.x + 3 * stride && gi == 3;
-      const bool hq_tl_rec = hq_tl_flag && (threadIdx.x & 63) == 0;
-      HQ_STAMP(0);
-      if (!ALDS && G.kv == 16) blocked_inner_gate<T, 4, 0, BLOCK>(xr, xi, G, A, tvb, hq_tl_flag);
-      else
-#endif
-#ifdef HQ_EXP_TIMELINE
-#define HQ_TL_ARG , hq_tl_flag
-#else
-#define HQ_TL_ARG
-#endif
 #define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
   do {                                                                                                  \
     if constexpr (ALDS)                                                                                 \
-      blocked_inner_gate_tab<T, KB, VM, BLOCK, GPRE>(A, tabs + gi * kBlockedTabWords, (1u << (tvb - G.n_addr)) >> 4, pre HQ_TL_ARG); \
+      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * kBlockedTabWords, (1u << (tvb - G.n_addr)) >> 4);       \
     else                                                                                                \
       blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
   } while (0)
@@ -1273,18 +877,8 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
           }
           break;
       }
-#ifdef HQ_EXP_TIMELINE
-      HQ_STAMP(11);
-#endif
-      // the next gate's prologue reads are issued in front of the barrier and land while the workgroup gathers at it
-      // (requested at the gate's START they cost 5 more live registers through the MFMA phase: spills)
-      if constexpr (GPRE && ALDS) request(gi + 1 < ngates ? gi + 1 : gi);
       __syncthreads();
-#ifdef HQ_EXP_TIMELINE
-      HQ_STAMP(12);
-#endif
     }
-    HQ_TSTAMP(3);
     if constexpr (PREF) {
       V sr[NPV], si[NPV];  // all LDS reads in flight before the first store (the gates' registers are free here)
 #pragma unroll
@@ -1304,26 +898,17 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     } else {
       for (unsigned e = tid; e < nvec; e += BLOCK) {
         const uint64_t g = base | vec_off(e);
-#ifdef HQ_BLOCKED_PLAIN_IO
-        vre[g] = reinterpret_cast<V*>(xr)[blocked_swz(e)];
-        vim[g] = reinterpret_cast<V*>(xi)[blocked_swz(e)];
-#else
         __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[blocked_swz(e)], vre + g);
         __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[blocked_swz(e)], vim + g);
-#endif
       }
     }
-    HQ_TSTAMP(4);
     // no barrier between the store phase and the fill with PREF: a thread refills exactly the LDS slots it has just
     // read for its stores (fs + i * BLOCK both times), in its own program order
     if constexpr (!PREF) __syncthreads();
-    HQ_TSTAMP(5);
     if constexpr (PREF) {
       fill();  // tile + stride (a repeat of a finished tile past the end: never used)
-      HQ_TSTAMP(6);
       base_cur = next_base(base);
       prefetch(tile + 2 * stride < ntiles ? next_base(base_cur) : base);
-      HQ_TSTAMP(7);
     }
   }
 }

@@ -66,19 +66,29 @@ EMU_SKIP = (
     ('host_functional_gate_on_a_large_state', 'n >= 25'),
     ('to_numpy_never_holds', 'n >= 25 and the real allocator statistics'),
     ('test_dm_1__simulation_1', '12-qubit density matrices = 24-qubit states'),
-    ('initialize_state[', 'n = 24'),
     ('prepare_state_mixed_large', 'n = 26'),
     ('auto_dispatch_follows_the_measured_rule', 'n = 30 planes'),
-    ('guard_bands', 'torch device fills of the margins; sizes n = 19, 20'),
     ('qasm_text_to_gpu', 'n = 24'),
     ('stream_switch_is_ordered', 'real streams'),
 )
 
 
+#: HQ_EMU_QUICK=1 (what tests/test_emu_gpu_suite.py runs inside the CPU suite): also leave out what takes more than ~20 s
+#: of emulation; the full emulated run is a few minutes on 8 cores (profiles/r04_emulated_gpu_suite.txt)
+EMU_SLOW = ('apply_U_mfma_kernels', 'randomized_differential', 'apply_U_gemm_kernel', 'simulate_blocked_matches_oracle',
+            'evolution_hip_chooses', 'compiled_program', 'exchange_pack_one_pass', 'simulation_large_like_reference',
+            'state_allocator_behind', 'restore_order_hip_backend', 'simulate_matches_reference_protocol',
+            'permute_bits_many_moved_bits', 'initialize_state[', 'guard_bands')
+
+
 def pytest_collection_modifyitems(config, items):
     if not EMU_SUITE:
         return
+    quick = os.environ.get('HQ_EMU_QUICK') == '1'
     for item in items:
+        if quick and any(pat in item.nodeid for pat in EMU_SLOW):
+            item.add_marker(pytest.mark.skip(reason='HQ_EMU_QUICK: more than ~20 s of emulation (runs in the full emulated suite)'))
+            continue
         for pat, why in EMU_SKIP:
             if pat in item.nodeid:
                 item.add_marker(pytest.mark.skip(reason=f'not under emulation: {why}'))

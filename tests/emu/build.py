@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(OUT, exist_ok=True)
     cxx = _cxx()
-    flags = ['-std=c++17', '-O1', '-g1', '-fPIC', '-DHQ_EMU=1', '-ffp-contract=off', '-Wno-unused-function', '-Wno-unused-value',
+    flags = ['-std=c++17', '-O2', '-g1', '-fPIC', '-DHQ_EMU=1', '-ffp-contract=off', '-Wno-unused-function', '-Wno-unused-value',
              '-Wno-unknown-attributes', '-Wno-ignored-attributes', '-I', os.path.join(HERE, 'shim')]
     jobs, objs = [], []
     for u in UNITS:

@@ -123,6 +123,11 @@ def install():
     for name in ('empty', 'zeros', 'ones', 'full', 'arange', 'randn', 'rand', 'tensor', 'as_tensor', 'empty_like', 'zeros_like',
                  'ones_like', 'randint', 'eye', 'linspace'):
         wrap_factory(name)
+    orig_gen = torch.Generator
+
+    def generator(device='cpu'):
+        return orig_gen(device=_to_cpu_device(device))
+    torch.Generator = generator
     T = torch.Tensor
     T.cuda = lambda self, *a, **k: self.clone()
     T.pin_memory = lambda self, *a, **k: self

@@ -135,6 +135,9 @@ def test_state_allocator_behind_the_c_abi(torch_cuda):
     core.use_torch_stream()
     core.state_pool_trim()
     n = 26
+    if os.environ.get('HQ_EMU_GPU_SUITE') == '1':  # host emulation: the same allocator code on a state it can probe in seconds
+        n = 15
+        os.environ['HQ_STATE_TUNED_MIN_BYTES'] = str(1 << 17)
     os.environ['HQ_STATE_TRIES'] = '3'
     try:
         owner = core.StatePlanes(n, np.float32)
@@ -166,13 +169,15 @@ def test_state_allocator_behind_the_c_abi(torch_cuda):
     fresh.free()
     plain = core.StatePlanes(n, np.float32, flags=core.STATE_PLAIN)
     assert plain.info['chosen'] == 'hipMalloc'
-    handle, off = core.ipc_export(plain.re)  # what the peer-to-peer transport needs (core._ptr accepts an address)
-    assert len(handle) == 64
+    if os.environ.get('HQ_EMU_GPU_SUITE') != '1':  # (HIP IPC is not emulated)
+        handle, off = core.ipc_export(plain.re)  # what the peer-to-peer transport needs (core._ptr accepts an address)
+        assert len(handle) == 64
     plain.free()
     core.state_pool_trim()
     small = core.StatePlanes(12, np.float64)  # below 256 MiB: plain memory, no search
     assert small.info['chosen'] == 'hipMalloc' and small.stride == (1 << 12) + 12288 // 8
     small.free()
+    os.environ.pop('HQ_STATE_TUNED_MIN_BYTES', None)
 
 
 def test_c_abi_state_demo_without_python(torch_cuda, tmp_path):

@@ -15,7 +15,7 @@ c = 0.16..0.40 along the circuit, this repo's per-gate path the same 0.16..0.40,
 0.22; the 13 fused four-qubit gates of examples/circuit_simple.qasm (structured H/CZ/T products):
 0.73 between two float32 runs (0.52 per evolution); config-4 generator (200 dense 3-/4-qubit gates)
 0.31..0.34 (reference 0.32); config-5 generator (noisy 11-qubit circuit as a 22-qubit state vector,
-non-unitary superoperators) 0.11..0.25 (reference 0.27).  The tests take c = 0.6 (round 3; 1.0 before: VERDICT r02 -- 1.5x above the
+non-unitary superoperators) 0.11..0.25 (reference 0.27).  The tests take c = 0.5 (round 4; 0.6 in round 3, 1.0 before: VERDICT r02 / r03 -- 1.25x above the
 largest constant measured, so a kernel that loses a factor of two in accuracy fails, rounding noise does
 not) and never go below the bar itself.  Every end-to-end check also reports whether the LITERAL bar was
 met (`literal_bar_met`), whatever the model allows.  Two independent float32 evolutions may be apart by the
@@ -27,7 +27,7 @@ import numpy as np
 
 BAR = {np.dtype('complex64'): 1e-6, np.dtype('complex128'): 1e-12}
 _UNIT = {np.dtype('complex64'): float(np.finfo(np.float32).eps) / 2, np.dtype('complex128'): float(np.finfo(np.float64).eps) / 2}
-C_MODEL = 0.6
+C_MODEL = 0.5
 #: circuits of STRUCTURED gates (examples/circuit_simple.qasm: H / CZ / T / sqrt-X products fused to 4 qubits; matrix
 #: entries 0, +-1/2, +-1/sqrt(2)...): the rounding errors of successive gates are correlated instead of a random walk;
 #: measured 0.73 between the reference's float32 run and ours (both schedules), so these tests take 0.8
