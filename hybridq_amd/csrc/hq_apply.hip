@@ -879,6 +879,47 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
   static int use_pref = env_int("HQ_BLOCKED_PREF", 1);
   const bool pref = use_pref && block_threads != 256 && tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits);
+  unsigned n_barriers = n_gates;
+  static int elide = env_int("HQ_BLOCKED_GROUPS", 1);
+  if (fits && elide) {
+    // Barrier-free groups (round 4).  A matrix-core inner gate splits the tile among the 8 waves by three tile-local
+    // vector bits that are not address digits of the gate; consecutive gates that can agree on those three bits hand
+    // the tile on wave by wave, and the workgroup barrier between them goes ("barrier only when a
+    // gate crosses waves").  Greedy over the given order; the register-butterfly gates (k = 1) and gates with fewer
+    // than 8 wave-iterations keep their barriers.
+    const unsigned tvb = tb - CB, all = (1u << tvb) - 1;
+    auto free_bits = [&](const BlockedGate& G) -> unsigned {
+      if (G.kv >= 64 || ((1u << (tvb - G.n_addr)) >> 4) < 8) return 0;
+      unsigned d = 0;
+      for (int m = 0; m < 4; ++m)
+        if (G.ro.pos[m] < 31) d |= 1u << G.ro.pos[m];
+      const unsigned f = all & ~d;
+      return __builtin_popcount(f) >= 7 ? f : 0;  // 4 slot bits + 3 wave bits
+    };
+    unsigned g0 = 0;
+    while (g0 < n_gates) {
+      unsigned common = free_bits(gates[g0]), g1 = g0 + 1;
+      if (common) {
+        while (g1 < n_gates) {
+          const unsigned f = free_bits(gates[g1]);
+          if (!f || __builtin_popcount(common & f) < 3) break;
+          common &= f;
+          ++g1;
+        }
+      }
+      if (g1 - g0 >= 2) {
+        unsigned w = 0, rest = common;
+        for (int i = 0; i < 3; ++i) {  // the three HIGHEST common bits: the slot bits stay the lowest free ones (bank behaviour)
+          const unsigned top = 31 - (unsigned)__builtin_clz(rest);
+          w |= 1u << top;
+          rest &= ~(1u << top);
+        }
+        for (unsigned g = g0; g < g1; ++g) gates[g].wave_bits = w | (g + 1 < g1 ? kBlockedNoBarrier : 0u);
+        n_barriers -= g1 - g0 - 1;
+      }
+      g0 = g1;
+    }
+  }
   if (fits) {
     void *dG = nullptr, *dA = nullptr;
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
@@ -908,7 +949,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   c.last_kernel = "blocked";
   c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
                 std::to_string(block_threads == 256 ? 256 : 512) + "> tb=" + std::to_string(tb) + " gates=" +
-                std::to_string(n_gates);
+                std::to_string(n_gates) + " barriers=" + std::to_string(n_barriers);
   return 0;
 }
 

@@ -449,8 +449,11 @@ struct BlockedGate {
   unsigned a_off;    // offset (elements) of this gate's A table
   unsigned kv;       // kbits * 4 + vmask
   unsigned n_addr;   // number of address digits
-  unsigned pad_;
+  unsigned wave_bits;  // bits 0..30: the three tile-local vector bits that carry the WAVE index of this gate's iterations (0: the
+                       // three lowest free bits above the slot bits, as round 1-3); bit 31: the gate after this one works on the
+                       // same per-wave partition of the tile, so no workgroup barrier is needed between them (host: hq_apply.hip)
 };
+constexpr unsigned kBlockedNoBarrier = 1u << 31;
 
 template <typename T, int KBITS, int VMASK, int BLOCK>
 __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __restrict__ xi,
@@ -563,12 +566,21 @@ __device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ t
   const unsigned tid = threadIdx.x;
   for (unsigned g = 0; g < ngates; ++g) {
     const MfmaRoles& ro = gates[g].ro;
+    const unsigned wmask = gates[g].wave_bits & ~kBlockedNoBarrier;
+    unsigned digits = 0;
+    for (int m = 0; m < 4; ++m)
+      if (ro.pos[m] < 31) digits |= 1u << ro.pos[m];
+    // bits of (iteration << 4 | slot) -> the tile-local vector bits that are not address digits of this gate, in ascending
+    // order; with `wave_bits` the three bits that number the waves (iteration bits 0..2) go to those positions instead,
+    // so that every gate of a barrier-free group gives wave w the SAME part of the tile
     auto deposit = [&](unsigned v) {
-      for (int m = 0; m < 4; ++m) {
-        const unsigned lo = (1u << ro.pos[m]) - 1;
-        v = ((v & ~lo) << 1) | (v & lo);
+      unsigned rest = ~(digits | wmask) & ((1u << tile_vec_bits) - 1), out = 0, b = 0;
+      if (wmask) {
+        for (int i = 0; i < 4 && rest; ++i, ++b) { out |= ((v >> b) & 1u) << __builtin_ctz(rest); rest &= rest - 1; }
+        for (unsigned w = wmask; w; w &= w - 1, ++b) out |= ((v >> b) & 1u) << __builtin_ctz(w);
       }
-      return v;
+      for (; rest; rest &= rest - 1, ++b) out |= ((v >> b) & 1u) << __builtin_ctz(rest);
+      return out;
     };
     BlockedTabT* tb = tabs + g * kBlockedTabWords;
     for (unsigned e = tid; e < kBlockedTabWords; e += BLOCK) {
@@ -877,7 +889,9 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
           }
           break;
       }
-      __syncthreads();
+      // gates of one barrier-free group touch, wave by wave, the same part of the tile (same `wave_bits`): a wave only
+      // needs its OWN stores to have landed (LDS operations of a wave complete in order; the gate ends with lgkmcnt(0))
+      if (!(ALDS && (G.wave_bits & kBlockedNoBarrier))) __syncthreads();
     }
     if constexpr (PREF) {
       V sr[NPV], si[NPV];  // all LDS reads in flight before the first store (the gates' registers are free here)

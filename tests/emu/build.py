@@ -24,7 +24,7 @@ def _cxx():
 
 def _deps():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
-    deps += [os.path.join(ROOT, 'include', 'hq_hip.h'), os.path.join(HERE, 'hip_emu.cpp'), os.path.abspath(__file__),
+    deps += [os.path.join(ROOT, 'include', 'hq_hip.h'), os.path.join(HERE, 'hip_emu.cpp'), os.path.join(HERE, 'emu_selftest.cpp'), os.path.abspath(__file__),
              os.path.join(HERE, 'shim', 'hip', 'hip_runtime.h'), os.path.join(HERE, 'shim', 'rccl', 'rccl.h')]
     return deps
 
@@ -41,9 +41,10 @@ def build(force=False, verbose=False):
         obj = os.path.join(OUT, u + '.o')
         objs.append(obj)
         jobs.append([cxx, '-x', 'c++'] + flags + ['-c', os.path.join(CSRC, u + '.hip'), '-o', obj])
-    obj = os.path.join(OUT, 'hip_emu.o')
-    objs.append(obj)
-    jobs.append([cxx] + flags + ['-c', os.path.join(HERE, 'hip_emu.cpp'), '-o', obj])
+    for extra in ('hip_emu', 'emu_selftest'):
+        obj = os.path.join(OUT, extra + '.o')
+        objs.append(obj)
+        jobs.append([cxx] + flags + ['-c', os.path.join(HERE, extra + '.cpp'), '-o', obj])
 
     def run(cmd):
         if verbose:

@@ -258,23 +258,40 @@ static void run_grid(dim3 grid, dim3 block, size_t lds, const std::function<void
     }
     g_blk = &blk;
     for (int w = 0; w < nw; ++w) worder[w] = order_mode() == 1 ? nw - 1 - w : w;
+    // One "wave round" runs each lane of a wave up to its next rendezvous.  forward: one round per wave in turn (the
+    // waves advance together).  reverse: the waves in descending order, each as far as it can go -- up to a workgroup
+    // barrier or its end -- before the next one starts: the largest drift between waves the program allows, which is what
+    // exposes a missing barrier (a fair schedule hides it: every wave reads long after every wave has written).
+    // random: a random wave for a random number of rounds.
+    auto wave_round = [&](int w) {
+      const unsigned long before = blk.progress;
+      for (unsigned l = 0; l < 64; ++l) {
+        const unsigned t = (unsigned)w * 64 + l;
+        if (t >= nt || blk.f[t].done) continue;
+        g_fib = &blk.f[t];
+        cur = &g_fib->lane;
+        hq_emu_switch(&g_sched_sp, g_fib->sp);
+      }
+      return blk.progress != before;
+    };
     unsigned long seen = ~0ul;
     while (blk.nactive > 0) {
       if (blk.progress == seen) { fprintf(stderr, "hq_emu: deadlock in workgroup (%u,%u,%u): %d threads wait at a rendezvous nobody else reaches\n", bx, by, bz, blk.nactive); abort(); }
       seen = blk.progress;
-      if (order_mode() == 2)
-        for (int w = nw - 1; w > 0; --w) {
-          rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-          std::swap(worder[w], worder[(rng >> 33) % (unsigned)(w + 1)]);
-        }
-      for (int wi = 0; wi < nw; ++wi)
-        for (unsigned l = 0; l < 64; ++l) {
-          const unsigned t = (unsigned)worder[wi] * 64 + l;
-          if (t >= nt || blk.f[t].done) continue;
-          g_fib = &blk.f[t];
-          cur = &g_fib->lane;
-          hq_emu_switch(&g_sched_sp, g_fib->sp);
-        }
+      if (order_mode() == 2) {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        const int w = (int)((rng >> 33) % (unsigned)nw);
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        int burst = 1 + (int)((rng >> 33) % 300u);
+        while (burst-- > 0 && wave_round(w)) {}
+        if (blk.progress == seen)  // that wave is stuck at a barrier: give everybody a turn so that the check above is fair
+          for (int wi = 0; wi < nw; ++wi) wave_round(wi);
+      } else if (order_mode() == 1) {
+        for (int wi = 0; wi < nw; ++wi)
+          while (wave_round(worder[wi])) {}
+      } else {
+        for (int wi = 0; wi < nw; ++wi) wave_round(worder[wi]);
+      }
     }
   }
   g_blk = nullptr;

@@ -45,10 +45,10 @@ for ft, ct in ((np.float32, np.complex64), (np.float64, np.complex128)):
     # cache-blocked pass: k <= 4 gates inside one tile, every LDS round trip separated by a workgroup barrier
     tb = 13 if ft == np.float32 else 12
     tile = np.concatenate([np.arange(5), np.sort(rng.permutation(np.arange(5, n))[:tb - 5])]).astype(np.uint32)
-    gates = [(rand_u(k, ct), rng.permutation(tile)[:k]) for k in (1, 2, 3, 4, 3, 2, 4, 3, 1, 3)]
+    gates = [(rand_u(k, ct), rng.permutation(tile)[:k]) for k in (2, 3, 3, 4, 3, 1, 3)]  # few enough for the in-LDS tables
     re[:], im[:] = psi[0], psi[1]
     core.apply_blocked(re, im, tile, gates, n)
-    print(f'blocked_{ft.__name__}', digest(re, im))
+    print(f'blocked_{ft.__name__}_' + core.last_kernel_desc().split()[-1].replace('=', ''), digest(re, im))
     # low-bit swaps and general bit permutations through LDS tiles
     for s in (3, 8, 11, 13):
         re[:] = psi[0]
@@ -66,3 +66,9 @@ for ft, ct in ((np.float32, np.complex64), (np.float64, np.complex128)):
     v = core.vdot(re, im, im, re)
     print(f'vdot_{ft.__name__}', digest(np.complex128(v)))
     free()
+# the emulator's own check: a kernel with a missing barrier must come out differently under the greedy schedules
+import ctypes  # noqa: E402
+out = (ctypes.c_uint32 * 8)()
+for wb in (1, 0):
+    core._lib.hq_emu_selftest_race(wb, out)
+    print(f'selftest_race_barrier{wb}', '-'.join(str(x) for x in out))

@@ -20,8 +20,10 @@ SETTINGS = [
     {'HQ_BLOCKED_THREADS': '256', 'HQ_BIG_PHASED': '0'},
     {'HQ_BIG_PHASED': '1', 'HQ_PERM_TB': '12', 'HQ_PERM_INPLACE_TB': '14'},
     {'HQ_PERM_TILE': '0'},  # round-2 paths: table-driven swap, two tile passes, gather kernels
+    {'HQ_BLOCKED_GROUPS': '0'},  # round 4: a workgroup barrier after EVERY inner gate (default: barrier-free wave groups)
 ]
 _seen = {}
+_blocked = {}
 
 
 @pytest.mark.parametrize('idx', range(len(SETTINGS)))
@@ -37,3 +39,5 @@ def test_lds_kernels_are_deterministic(torch_cuda, idx, capsys):
         name, h = ln.rsplit(' ', 1)
         if 'swap' in name or 'permute_bits' in name or 'exchange pack' in name:  # pure data movement: one right answer
             assert _seen.setdefault(name, h) == h, (name, SETTINGS[idx])
+        if 'blocked' in name and SETTINGS[idx] in ({}, {'HQ_BLOCKED_GROUPS': '0'}):  # the groups change barriers, not arithmetic
+            assert _blocked.setdefault(name, h) == h, (name, SETTINGS[idx])
