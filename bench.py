@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument('--no-fused', action='store_true', help='skip the fused (compress=4) variant')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-events', action='store_true', help='skip per-gate HIP events in the timed region')
+    ap.add_argument('--overlap', action='store_true', help='N > 1: exchanges in rounds with the independent local gates applied to the pieces as they land (hybridq_amd.dist.overlap_exchanges; default off until measured on xGMI)')
     ap.add_argument('--no-config-legs', action='store_true', help='skip the short BASELINE config 4 / config 5 legs after the timed region')
     ap.add_argument('--parity-qubits', type=int, default=24, help='size of the parity_check circuit (the CPU reference runs all of it)')
     ap.add_argument('--leg-parity-qubits', type=int, default=16, help='size of the small-n parity runs of the config legs (even)')
@@ -366,7 +367,7 @@ def main():
         n_exchanges = n_permutes = 0
     else:
         from hybridq_amd.dist import ShardedEvolution
-        sharded = ShardedEvolution(n, complex_type=args.dtype, initial_state='0' * n)
+        sharded = ShardedEvolution(n, complex_type=args.dtype, initial_state='0' * n, overlap=args.overlap)
         # every step applies the SAME logical circuit; the qubit placement it starts from is
         # whatever the previous step left, so each step gets its own (pre-computed) schedule
         pos0 = dict(sharded.pos)
@@ -376,11 +377,11 @@ def main():
             sharded.pos = dict(sharded._planned_final_pos)
         pos_after_main = dict(sharded.pos)
         sharded.pos = pos0
-        n_exchanges = sum(1 for op in schedules[-1] if op[0] in ('X', 'XP'))
+        n_exchanges = sum(1 for op in schedules[-1] if op[0] in ('X', 'XP', 'XO'))
         n_permutes = sum(1 for op in schedules[-1] if op[0] in ('P', 'XP'))
         step_no = [0]
 
-        OP_NAMES = {'P': 'permute_bits', 'X': 'exchange', 'XP': 'exchange_with_folded_permutation'}
+        OP_NAMES = {'P': 'permute_bits', 'X': 'exchange', 'XP': 'exchange_with_folded_permutation', 'XO': 'exchange_in_rounds_with_overlapped_gates'}
 
         class OpTimer:
             """HIP events around every op of the sharded schedule (torch's current stream IS the
@@ -520,7 +521,7 @@ def main():
                     'logical_amplitudes_per_s': len(gates) / elb * float(1 << n),
                     'blocked_passes_per_step': sum(1 for op in bsched[-1] if op[0] == 'B'),
                     'plain_gates_per_step': sum(1 for op in bsched[-1] if op[0] == 'G'),
-                    'exchanges_per_step': sum(1 for op in bsched[-1] if op[0] in ('X', 'XP')),
+                    'exchanges_per_step': sum(1 for op in bsched[-1] if op[0] in ('X', 'XP', 'XO')),
                 }
             result['exchange'] = {
                 'transport': getattr(sharded.backend, 'transport', None),
@@ -558,6 +559,16 @@ def main():
                                                 max(1e-9, n_local_gates * gate_ms_model + (n_exchanges - n_permutes) * link_ms + n_permutes * (link_ms + pack_ms_model)),
                 'note': 'model, not a measurement: compare with ms_per_exchange / GBps_per_link above on a node with xGMI',
             }
+            # exchange / compute overlap (--overlap; hybridq_amd.dist.overlap_exchanges): the gates taken along per exchange are
+            # budgeted at 1.25 x the modelled transfer time, so at most that much of every exchange hides behind them
+            k_att = int(1.25 * link_ms / gate_ms_model)
+            hidden = min(link_ms, k_att * gate_ms_model)
+            result['exchange']['expected']['overlap'] = {
+                'enabled_in_this_run': bool(args.overlap), 'rounds_per_exchange': 4,
+                'attached_gates_per_exchange_budget': k_att, 'ms_hidden_per_exchange_model': hidden,
+                'ms_per_step_model_with_overlap': result['exchange']['expected']['ms_per_step_model'] - n_exchanges * hidden,
+                'exchanges_in_rounds_this_run': sum(1 for op in schedules[-1] if op[0] == 'XO'),
+                'note': 'unmeasured on hardware: no multi-GPU node was available to this build'}
         except Exception as e:  # noqa: BLE001
             result['extras_error'] = repr(e)
     if rank == 0 and (events is not None or (sharded_path and op_timer is not None)):
@@ -882,7 +893,7 @@ def main():
                     for _ in range(2):
                         scheds.append(st_s.plan(gs))
                         st_s.pos = dict(st_s._planned_final_pos)
-                    n_x_s = sum(1 for op in scheds[1] if op[0] in ('X', 'XP'))
+                    n_x_s = sum(1 for op in scheds[1] if op[0] in ('X', 'XP', 'XO'))
                     it_s = iter(scheds)
 
                     def once():

@@ -209,6 +209,89 @@ def fuse_evictions(schedule):
     return out
 
 
+#: sub-chunks per peer of an overlapped exchange (2^OVERLAP_SUB_BITS): enough pieces for the arithmetic on piece s to hide
+#: behind the transfer of piece s + 1, few enough that a piece (n = 33 on 8 GPUs: 256 MiB per peer) still fills a link
+OVERLAP_SUB_BITS = 2
+#: a sub-state of fewer qubits than this is not worth separate launches
+OVERLAP_MIN_SUB_QUBITS = 12
+
+
+def overlap_exchanges(schedule, m, g, sub_bits=OVERLAP_SUB_BITS, itemsize=4, budget=1.25):
+    """Exchange / compute overlap.  The exchange swaps the top g local bits with the rank bits, so
+    a gate that touches NONE of the top g + sub_bits local positions acts inside every 2^(m-g-sub_bits)-amplitude piece
+    of every chunk on its own -- on the sender before the exchange or on the receiver after it, the same arithmetic.
+    The list scheduler has run everything runnable BEFORE it pays for an exchange, so the candidates are the local gates
+    in front of an exchange: scanning back from it, a gate is taken along while it qualifies (in the layout the exchange
+    sees, i.e. behind the eviction permutation), nothing between it and the exchange that stays shares a position with it,
+    and the work taken does not exceed `budget` x the modelled transfer time (one chunk per link at 153 GB/s against
+    6.3 TB/s gate passes: more would only add launches).  They are attached to the exchange,
+
+        ('XO', perm or None, sub_bits, [('G', U, positions in the exchange's layout), ...])
+
+    and the executor moves the shard in 2^sub_bits rounds of one piece per peer (all links busy in every round), applying
+    the attached gates to the pieces of round s while round s + 1 is on the wire.  Everything else keeps its place."""
+    limit = m - g - sub_bits
+    if g == 0 or limit < OVERLAP_MIN_SUB_QUBITS:
+        return list(schedule)
+    shard_bytes = 2.0 * (1 << m) * itemsize
+    transfer_s = shard_bytes / (1 << g) / 153e9
+    gate_s = 2.0 * shard_bytes / 6.3e12
+    out = []
+    for op in schedule:
+        if op[0] not in ('X', 'XP'):
+            out.append(op)
+            continue
+        perm = None if op[0] == 'X' else [int(p) for p in op[1]]
+        where = {p: p for p in range(m)} if perm is None else {src: dst for dst, src in enumerate(perm)}  # dst bit i <- src bit perm[i]
+        taken, held, spent = [], set(), 0.0
+        k = len(out)
+        while k > 0 and out[k - 1][0] == 'G' and spent + gate_s <= budget * transfer_s + 1e-12:
+            o = out[k - 1]
+            pos = [where[int(p)] for p in o[2]]
+            if max(pos) < limit and not (set(int(p) for p in o[2]) & held):
+                taken.append((k - 1, ('G', o[1], np.asarray(pos, dtype=np.uint32))))
+                spent += gate_s
+            else:
+                held |= set(int(p) for p in o[2])  # whatever it shares a position with, further back, must stay in front of it
+            k -= 1
+        if not taken:
+            out.append(op)
+            continue
+        for idx, _ in taken:  # indices descend: deleting from the back keeps the others valid
+            del out[idx]
+        out.append(('XO', None if perm is None else np.asarray(perm, dtype=np.uint32), sub_bits, [o for _, o in reversed(taken)]))
+    return out
+
+
+def exchange_in_rounds(be, dist, src, dst, m, g, sub_bits, ops, group, rank, apply_ops):
+    """The executor of 'XO' on top of torch.distributed point-to-point operations (RCCL send / recv on the device, gloo
+    in the CPU tests): round s posts, for every peer j, the send of piece s of chunk j and the receive of piece s of the
+    peer's chunk for this rank; all rounds are posted at once, then the attached ops run on the pieces of round s as soon
+    as that round has landed -- on the compute stream, while the later rounds are still moving.  The result is in `dst`."""
+    G, S = 1 << g, 1 << sub_bits
+    sub = 1 << (m - g - sub_bits)
+    sv = [src[pl].view(G, S, sub) for pl in (0, 1)]
+    dv = [dst[pl].view(G, S, sub) for pl in (0, 1)]
+    peer = (lambda j: j) if group is None else (lambda j: dist.get_global_rank(group, j))
+    rounds = []
+    for s_ in range(S):
+        p2p = []
+        for j in range(G):
+            for pl in (0, 1):
+                if j == rank:
+                    dv[pl][j, s_].copy_(sv[pl][j, s_])  # this rank's own piece
+                else:
+                    p2p.append(dist.P2POp(dist.isend, sv[pl][j, s_], peer(j), group))
+                    p2p.append(dist.P2POp(dist.irecv, dv[pl][j, s_], peer(j), group))
+        rounds.append(dist.batch_isend_irecv(p2p) if p2p else [])
+    for s_ in range(S):
+        for w in rounds[s_]:
+            w.wait()  # device backends: the compute stream waits for the transfer, the host does not
+        if ops:
+            for j in range(G):
+                apply_ops((dv[0][j, s_], dv[1][j, s_]), ops, m - g - sub_bits)
+
+
 # ------------------------------------------------------------------------------------
 # backends
 # ------------------------------------------------------------------------------------
@@ -527,8 +610,14 @@ class ShardedEvolution:
     """n-qubit state sharded by the top g = log2(world) index bits over the process group."""
 
     def __init__(self, n, complex_type='complex64', initial_state=None, qubits=None, backend=None,
-                 group=None):
+                 group=None, overlap=None):
+        """``overlap``: overlap every qubit exchange with the local gates that do not touch the moving bits
+        (:func:`overlap_exchanges`; default: the environment variable HQ_SHARD_OVERLAP, off -- the round-trip on xGMI has
+        not been measured yet).  Overlapped exchanges travel as torch.distributed send / recv
+        rounds (RCCL on the device) instead of through hq_exchange_*."""
+        import os
         import torch.distributed as dist
+        self.overlap = (os.environ.get('HQ_SHARD_OVERLAP', '0') == '1') if overlap is None else bool(overlap)
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -606,6 +695,8 @@ class ShardedEvolution:
                 sched.append(op)
         self._planned_final_pos = final_pos
         sched = fuse_evictions(sched)
+        if self.overlap:
+            sched = overlap_exchanges(sched, self.m, self.g, itemsize=self.float_type.itemsize)
         if blocked and self.m >= 14:
             from .blocking import plan_blocked
             opts = dict(blocked) if isinstance(blocked, dict) else {}
@@ -615,17 +706,19 @@ class ShardedEvolution:
             opts.setdefault('complex_type', self.complex_type)
             out, run = [], []
 
+            def replan(run, n_sub, out):
+                ident = {p: p for p in range(n_sub)}  # "qubits" of the sub-plan are local positions
+                for op in plan_blocked([(U, tuple(int(p) for p in reversed(pos))) for U, pos in run], ident, n_sub, **opts):
+                    if op[0] == 'B':
+                        out.append(('B', op[1], [(np.ascontiguousarray(U, dtype=self.complex_type),
+                                                  np.asarray(p, dtype=np.uint32)) for U, p in op[2]]))
+                    else:
+                        out.append(('G', np.ascontiguousarray(op[1], dtype=self.complex_type),
+                                    np.asarray(op[2], dtype=np.uint32)))
+
             def flush():
                 if run:
-                    ident = {p: p for p in range(self.m)}  # "qubits" of the sub-plan are local positions
-                    for op in plan_blocked([(U, tuple(int(p) for p in reversed(pos))) for U, pos in run], ident,
-                                           self.m, **opts):
-                        if op[0] == 'B':
-                            out.append(('B', op[1], [(np.ascontiguousarray(U, dtype=self.complex_type),
-                                                      np.asarray(p, dtype=np.uint32)) for U, p in op[2]]))
-                        else:
-                            out.append(('G', np.ascontiguousarray(op[1], dtype=self.complex_type),
-                                        np.asarray(op[2], dtype=np.uint32)))
+                    replan(run, self.m, out)
                     run.clear()
 
             for op in sched:
@@ -633,6 +726,10 @@ class ShardedEvolution:
                     run.append((op[1], op[2]))
                 else:
                     flush()
+                    if op[0] == 'XO' and self.m - self.g - op[2] >= 14:  # the attached gates as passes over the pieces
+                        inner = []
+                        replan([(o[1], o[2]) for o in op[3]], self.m - self.g - op[2], inner)
+                        op = ('XO', op[1], op[2], inner)
                     out.append(op)
             flush()
             sched = out
@@ -643,7 +740,7 @@ class ShardedEvolution:
         ``start(op) -> token`` / ``stop(token)`` called around every op on the issuing stream."""
         be = self.backend
         for op in schedule:
-            if op[0] in ('P', 'X', 'XP') and self.bufs[1 - self.cur] is None:
+            if op[0] in ('P', 'X', 'XP', 'XO') and self.bufs[1 - self.cur] is None:
                 self.bufs[1 - self.cur] = be.empty_planes(self.m)
             tok = timer.start(op) if timer is not None else None
             if op[0] == 'G':
@@ -652,6 +749,15 @@ class ShardedEvolution:
                 be.apply_blocked(self.bufs[self.cur], op[1], op[2], self.m)
             elif op[0] == 'P':
                 be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m)
+                self.cur = 1 - self.cur
+            elif op[0] == 'XO':  # exchange in rounds, the attached local ops applied to the pieces as they land
+                if op[1] is not None:  # the eviction permutation as a pass of its own (the rounds move contiguous pieces)
+                    be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m)
+                    self.cur = 1 - self.cur
+                if hasattr(be, 'before_rounds'):
+                    be.before_rounds(self.group)
+                exchange_in_rounds(be, self.dist, self.bufs[self.cur], self.bufs[1 - self.cur], self.m, self.g, op[2], op[3],
+                                   self.group, self.rank, self._apply_local_ops)
                 self.cur = 1 - self.cur
             else:  # 'X' / 'XP': the exchange, with the eviction permutation folded in for 'XP'
                 perm = op[1] if op[0] == 'XP' else None
@@ -669,6 +775,14 @@ class ShardedEvolution:
                 timer.stop(tok)
         if update_map:
             self.pos = dict(self._planned_final_pos)
+
+    def _apply_local_ops(self, planes, ops, n_sub):
+        be = self.backend
+        for o in ops:
+            if o[0] == 'G':
+                be.apply(planes, o[1], o[2], n_sub)
+            else:
+                be.apply_blocked(planes, o[1], o[2], n_sub)
 
     def simulate(self, gates, compress=0, blocked=False):
         self.run(self.plan(gates, compress=compress, blocked=blocked))

@@ -935,7 +935,7 @@ def _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_sch
     info['runtime (s)'] = time.perf_counter() - t0
     info['n_gates'] = sum(1 for op in sched if op[0] in ('G', 'B'))
     info['n_passes'] = info['n_gates']
-    info['n_exchanges'] = sum(1 for op in sched if op[0] in ('X', 'XP'))
+    info['n_exchanges'] = sum(1 for op in sched if op[0] in ('X', 'XP', 'XO'))
     info['n_gates_given'] = len(circuit)
     info['n_qubits'] = n
     info['n_ranks'] = sh.world

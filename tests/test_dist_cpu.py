@@ -147,9 +147,23 @@ def _worker(rank, world, port, n, seed, ct, out_dir):
             nb = sum(1 for op in sched4 if op[0] == 'B')
             sh4.run(sched4)
             psi4 = sh4.state_numpy()
+        # exchange / compute overlap (round 4): exchanges in rounds of one piece per peer, the local gates that touch none
+        # of the moving bits applied to the pieces as they land -- same state, plain and with cache-blocked passes
+        import hybridq_amd.dist as dist_mod
+        dist_mod.OVERLAP_MIN_SUB_QUBITS = 3  # (the product wants >= 12-qubit pieces; the shards here are tiny)
+        sh5 = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, backend=CpuBackend(ft), overlap=True)
+        sched5 = sh5.plan(gates)
+        n_xo = sum(1 for op in sched5 if op[0] == 'XO')
+        n_attached = sum(len(op[3]) for op in sched5 if op[0] == 'XO')
+        sh5.run(sched5)
+        psi5 = sh5.state_numpy()
+        sh6 = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, backend=CpuBackend(ft), overlap=True)
+        sh6.simulate(gates, compress=4)
+        sh6.restore_order()
+        psi6 = sh6.state_numpy()
         if rank == 0:
             np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psi2=psi2, n_x=n_x, n_p=n_p, nrm=nrm, raw=raw,
-                     moved=moved, psi4=psi4, nb=nb)
+                     moved=moved, psi4=psi4, nb=nb, psi5=psi5, psi6=psi6, n_xo=n_xo, n_attached=n_attached)
     finally:
         dist.destroy_process_group()
 
@@ -172,6 +186,11 @@ def test_sharded_matches_single_process(tmp_path, world, n, ct):
     assert np.abs(out['raw'] - exp).max() / np.abs(exp).max() < tol  # fused + restore_order
     assert np.abs(out['psi4'] - exp).max() / np.abs(exp).max() < tol  # blocked local passes
     assert (int(out['nb']) >= 1) == (n - int(np.log2(world)) >= 14)
+    # overlapped exchanges: the same state (the attached gates act on pieces: the same arithmetic per amplitude)
+    assert int(out['n_xo']) >= 1 and int(out['n_attached']) >= 1, (out['n_xo'], out['n_attached'])
+    assert np.abs(out['psi5'] - exp).max() / np.abs(exp).max() < tol
+    assert np.abs(out['psi5'] - out['psi']).max() <= (0 if ct == 'complex128' else 1e-7) + 1e-15
+    assert np.abs(out['psi6'] - exp).max() / np.abs(exp).max() < tol
     g2 = random_dense(n, 25, kmax=3, seed=seed + 2)
     exp2 = oracle.evolve_tensordot(g2, n, initial_state=('-+10+' * n)[:n], qubits=list(range(n)))
     assert np.abs(out['psi2'] - exp2).max() / np.abs(exp2).max() < tol
