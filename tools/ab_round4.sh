@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-4 changes that need a GPU to be judged, back to back on one box (one gpurun call; outputs under gpurun_out/ab_round4/):
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/ab_round4.sh'
+# 1. cache-blocked schedule of the n = 30 benchmark circuit with the barrier-free wave groups (default) and with one workgroup
+#    barrier per inner gate (HQ_BLOCKED_GROUPS=0): each is its own process (the library reads its switches once), twice each
+#    in alternation so that a drifting clock does not decide
+# 2. the same bit for bit: determinism test incl. the GROUPS=0 setting
+# 3. rocprofv3 kernel stats of the blocked pass with groups
+set -u
+out=gpurun_out/ab_round4
+mkdir -p "$out"
+for rep in 1 2; do
+  for g in 1 0; do
+    echo "== rep $rep HQ_BLOCKED_GROUPS=$g"
+    HQ_BLOCKED_GROUPS=$g python tools/ab_blocked.py 30 complex64 2>&1 | tail -3 | tee -a "$out/blocked_groups_$g.txt"
+  done
+done
+python -m pytest -q -m gpu tests/test_gpu_determinism.py 2>&1 | tail -5 | tee "$out/determinism.txt"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/prof" -- python "$OLDPWD/tools/ab_blocked.py" 30 complex64 > "$OLDPWD/$out/prof.log" 2>&1
+cd "$OLDPWD"
+python profiles/extract_stats.py "$out/prof" 2>/dev/null | head -20 | tee "$out/kernel_stats_head.txt"
