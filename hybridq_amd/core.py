@@ -185,6 +185,8 @@ _plan_counts = _define_function(_lib, 'hq_plan_counts', ctypes.c_int, ctypes.c_v
                                 ctypes.POINTER(ctypes.c_uint64), _u32p)
 _plan_read = _define_function(_lib, 'hq_plan_read', ctypes.c_int, ctypes.c_void_p, _u32p, _u32p, _u32p, _u32p, _u32p, ctypes.c_void_p)
 _plan_free = _define_function(_lib, 'hq_plan_free', ctypes.c_int, ctypes.c_void_p)
+_plan_simplify = _define_function(_lib, 'hq_plan_simplify', ctypes.c_int, ctypes.c_uint, ctypes.c_uint, _u32p, _u32p, ctypes.c_void_p,
+                                  ctypes.c_double, ctypes.c_int, ctypes.c_uint, ctypes.c_int, _u32p, _u32p)
 
 #: symbols the C header include/hq_hip.h declares (checked by tests/test_abi.py)
 EXPORTED = [
@@ -202,7 +204,7 @@ EXPORTED = [
     'hq_shard_info', 'hq_shard_free', 'hq_shard_rccl_selftest', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
     'hq_exchange_float32', 'hq_exchange_float64', 'hq_alloc', 'hq_free', 'hq_alloc_mapped', 'hq_alloc_scattered',
     'hq_alloc_state', 'hq_free_state', 'hq_state_info', 'hq_state_pool_trim',
-    'hq_plan_blocked', 'hq_plan_counts', 'hq_plan_read', 'hq_plan_free',
+    'hq_plan_blocked', 'hq_plan_counts', 'hq_plan_read', 'hq_plan_free', 'hq_plan_simplify',
 ]
 
 
@@ -609,6 +611,20 @@ def plan_blocked(n, gates, tile_bits, low_bits, inner_max, min_gates, tries, fus
     finally:
         _plan_free(handle)
     return kind, first, tile, gk, gpos, mats
+
+
+def plan_simplify(n_ids, gates, atol, use_matrix_commutation, max_n_qubits_matrix, remove_id_gates):
+    """``hq_plan_simplify``: indices of the gates of `gates` = [(U, integer qubit ids)] that survive, in their new order."""
+    G = len(gates)
+    k = np.fromiter((len(q) for _, q in gates), dtype=np.uint32, count=G)
+    ids = np.fromiter((int(x) for _, q in gates for x in q), dtype=np.uint32, count=int(k.sum()))
+    U = np.concatenate([np.asarray(u, dtype=np.complex128).reshape(-1) for u, _ in gates]) if G else np.zeros(0, np.complex128)
+    out = np.empty(max(G, 1), np.uint32)
+    cnt = ctypes.c_uint32()
+    _check(_plan_simplify(n_ids, G, k.ctypes.data_as(_u32p), ids.ctypes.data_as(_u32p), U.ctypes.data, float(atol),
+                          int(bool(use_matrix_commutation)), int(max_n_qubits_matrix), int(bool(remove_id_gates)),
+                          out.ctypes.data_as(_u32p), ctypes.byref(cnt)), 'hq_plan_simplify')
+    return out[:cnt.value]
 
 
 def pack_blocked(gates, complex_type='complex64'):

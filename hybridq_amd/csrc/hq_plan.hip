@@ -92,6 +92,86 @@ static bool commute(const std::vector<cd>& U1, const std::vector<unsigned>& q1, 
   return true;
 }
 
+// B == inv(A) within np.allclose(inv(A), B, atol): Gauss-Jordan with partial pivoting (a singular A has no inverse gate)
+static bool is_inverse(const std::vector<cd>& A, const std::vector<cd>& B, size_t D, double atol) {
+  std::vector<cd> M(A), I(D * D, cd(0, 0));
+  for (size_t i = 0; i < D; ++i) I[i * D + i] = cd(1, 0);
+  for (size_t c = 0; c < D; ++c) {
+    size_t piv = c;
+    for (size_t r = c + 1; r < D; ++r)
+      if (std::abs(M[r * D + c]) > std::abs(M[piv * D + c])) piv = r;
+    if (std::abs(M[piv * D + c]) < 1e-300) return false;
+    if (piv != c)
+      for (size_t j = 0; j < D; ++j) { std::swap(M[piv * D + j], M[c * D + j]); std::swap(I[piv * D + j], I[c * D + j]); }
+    const cd inv = cd(1, 0) / M[c * D + c];
+    for (size_t j = 0; j < D; ++j) { M[c * D + j] *= inv; I[c * D + j] *= inv; }
+    for (size_t r = 0; r < D; ++r) {
+      if (r == c) continue;
+      const cd f = M[r * D + c];
+      if (f == cd(0, 0)) continue;
+      for (size_t j = 0; j < D; ++j) { M[r * D + j] -= f * M[c * D + j]; I[r * D + j] -= f * I[c * D + j]; }
+    }
+  }
+  for (size_t e = 0; e < D * D; ++e)
+    if (!(std::abs(I[e] - B[e]) <= atol + 1e-5 * std::abs(B[e]))) return false;
+  return true;
+}
+
+// fusion.simplify (hybridq/circuit/utils.py:825-866 with insert_from_left, :122-208): identity gates dropped, the circuit
+// rebuilt from its last gate backwards, every gate sliding right through the gates it commutes with (no shared qubit, or
+// commuting matrices within the reference's fixed 1e-5) and cancelling against the first gate that is its inverse.
+// Returns the indices of the surviving gates in their new order.
+static std::vector<unsigned> simplify(const std::vector<Gate>& gates, double atol, bool use_mc, unsigned max_nqm, bool remove_id) {
+  std::vector<unsigned> keep;
+  for (unsigned g = 0; g < gates.size(); ++g) {
+    const Gate& G = gates[g];
+    bool drop = false;
+    if (remove_id && G.q.size() <= max_nqm) {
+      const size_t D = (size_t)1 << G.q.size();
+      drop = true;
+      for (size_t i = 0; i < D && drop; ++i)
+        for (size_t j = 0; j < D; ++j) {
+          const cd want = i == j ? cd(1, 0) : cd(0, 0);
+          if (!(std::abs(G.U[i * D + j] - want) <= atol + (i == j ? 1e-5 : 0.0))) { drop = false; break; }
+        }
+    }
+    if (!drop) keep.push_back(g);
+  }
+  std::vector<unsigned> out;  // circuit order; gates are inserted from the left
+  std::vector<uint64_t> qm(gates.size());
+  for (unsigned g : keep) qm[g] = mask_of(gates[g].q);
+  for (size_t r = keep.size(); r-- > 0;) {
+    const unsigned g = keep[r];
+    const Gate& Gg = gates[g];
+    bool placed = false;
+    for (size_t p = 0; p < out.size(); ++p) {
+      const unsigned v = out[p];
+      const Gate& Gv = gates[v];
+      if (qm[v] == qm[g]) {
+        std::vector<unsigned> Q(Gg.q);
+        std::sort(Q.begin(), Q.end());
+        if (is_inverse(embed(Gg.U, Gg.q, Q), embed(Gv.U, Gv.q, Q), (size_t)1 << Q.size(), atol)) {
+          out.erase(out.begin() + (long)p);
+          placed = true;
+          break;
+        }
+      }
+      bool ok = false;
+      if (Gv.q.size() <= max_nqm) {
+        ok = !(qm[g] & qm[v]);
+        if (!ok && use_mc) ok = commute(Gg.U, Gg.q, Gv.U, Gv.q, 1e-5);  // commutes_with's fixed tolerance (property.py:573)
+      }
+      if (!ok) {
+        out.insert(out.begin() + (long)p, g);
+        placed = true;
+        break;
+      }
+    }
+    if (!placed) out.push_back(g);
+  }
+  return out;
+}
+
 struct Layer {
   std::vector<unsigned> q;  // sorted
   std::vector<cd> U;
@@ -389,6 +469,31 @@ int hq_plan_blocked(unsigned int n_qubits, unsigned int n_gates, const unsigned 
   Result* r = new Result();
   plan_blocked(gates, o, *r);
   *plan = r;
+  return 0;
+}
+
+int hq_plan_simplify(unsigned int n_qubits, unsigned int n_gates, const unsigned int* k, const unsigned int* qubits, const double* U,
+                     double atol, int use_matrix_commutation, unsigned int max_n_qubits_matrix, int remove_id_gates,
+                     unsigned int* out_index, unsigned int* out_count) {
+  using namespace hq::plan;
+  if (!out_index || !out_count) return hq::fail("hq_plan_simplify: null output");
+  if (n_gates && (!k || !qubits || !U)) return hq::fail("hq_plan_simplify: null input");
+  if (n_qubits == 0 || n_qubits > 62) return hq::fail("hq_plan_simplify: qubit ids must be below 62");
+  std::vector<Gate> gates(n_gates);
+  size_t po = 0, uo = 0;
+  for (unsigned g = 0; g < n_gates; ++g) {
+    if (k[g] == 0 || k[g] > 12) return hq::fail("hq_plan_simplify: gates act on 1..12 qubits");
+    if (hq::check_positions(qubits + po, n_qubits, k[g])) return hq::fail("hq_plan_simplify: invalid qubit ids");
+    gates[g].q.assign(qubits + po, qubits + po + k[g]);
+    const size_t e = (size_t)1 << (2 * k[g]);
+    gates[g].U.resize(e);
+    for (size_t i = 0; i < e; ++i) gates[g].U[i] = cd(U[2 * (uo + i)], U[2 * (uo + i) + 1]);
+    po += k[g];
+    uo += e;
+  }
+  const std::vector<unsigned> out = simplify(gates, atol, use_matrix_commutation != 0, max_n_qubits_matrix, remove_id_gates != 0);
+  std::copy(out.begin(), out.end(), out_index);
+  *out_count = (unsigned)out.size();
   return 0;
 }
 

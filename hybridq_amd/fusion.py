@@ -242,14 +242,32 @@ def _inverse_of(U1, q1, U2, q2, atol):
         return False
 
 
-def simplify(gates, atol=1e-8, use_matrix_commutation=True, max_n_qubits_matrix=10, remove_id_gates=True):
-    """Counterpart of ``hybridq.circuit.utils.simplify`` (circuit/utils.py:825-866 with
+def simplify(gates, atol=1e-8, use_matrix_commutation=True, max_n_qubits_matrix=10, remove_id_gates=True, native=None):
+    """``native`` (default: whenever the circuit has at most 62 distinct qubits and no gate wider than 10): the same
+    algorithm behind the C ABI (``hq_plan_simplify``, csrc/hq_plan.hip; 24 -> 1.5 ms for the 900-gate benchmark circuit);
+    ``native=False``: the Python statement below, which the live tests hold against the reference itself.
+
+    Counterpart of ``hybridq.circuit.utils.simplify`` (circuit/utils.py:825-866 with
     ``insert_from_left``, :122-208) on ``(U, qubits)`` pairs: drop identity gates, then rebuild the
     circuit from its LAST gate backwards, sliding every gate to the right through the gates it
     commutes with (no shared qubit, or commuting matrices) and cancelling it against the first
     gate that is its inverse.  The circuit's action is unchanged; what changes is the gate
     list the fusion sees (the reference's ``simulate`` runs this by default, simulation.py:304)."""
     gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
+    if native is None or native:
+        labels = {}
+        for _, qs in gates:
+            for q in qs:
+                labels.setdefault(q, len(labels))
+        fits = len(labels) <= 62 and all(len(qs) <= 10 and len(set(qs)) == len(qs) and np.asarray(U).size == 4 ** len(qs)
+                                         for U, qs in gates)
+        if fits and gates:
+            from . import core
+            order = core.plan_simplify(max(1, len(labels)), [(U, [labels[q] for q in qs]) for U, qs in gates], atol,
+                                       use_matrix_commutation, max_n_qubits_matrix, remove_id_gates)
+            return [gates[int(i)] for i in order]
+        if native:
+            raise ValueError('hq_plan_simplify takes at most 62 distinct qubits and gates of at most 10 qubits')
     if remove_id_gates:  # utils.py:841-845
         eyes = {}
 

@@ -823,10 +823,13 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     n_given = len(circuit)
     if remove_id_gates:  # simulation.py:289-291 (named identity gates; matrix identities go in simplify)
         circuit = [g for g in circuit if getattr(g, 'name', None) != 'I']
+    host_ms = {}  # what the caller waits for before the gate loop starts (reported in info['host_ms'])
     if simplify:  # simulation.py:293-305
         from .fusion import single_thread_blas
+        _t = time.perf_counter()
         with single_thread_blas():
             circuit = _simplify_runs(circuit, remove_id_gates, atol, simplify if isinstance(simplify, dict) else {})
+        host_ms['simplify'] = 1e3 * (time.perf_counter() - _t)
         if not kwargs.get('qubits') and all_qubits(circuit) != qubits:
             raise ValueError("Active qubits have changed after simplification. Forcing stop.")
     if not isinstance(initial_state, str):  # simulation.py:270-281 (a flat vector of 2^n amplitudes is accepted as well)
@@ -847,11 +850,15 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     if _wants_shards(kwargs):  # the sharded driver plans for its own local qubit count
         _torch()
         return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule)
+    _t = time.perf_counter()
     with single_thread_blas():  # thousands of tiny matrix products: a threaded BLAS only adds wake-ups
         if auto_schedule:
             gates, schedule_info = choose_schedule(circuit, qubits, n, ctype)
         else:
             gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
+    host_ms['plan'] = 1e3 * (time.perf_counter() - _t)
+    if schedule_info is not None:
+        schedule_info['plan_ms'] = round(host_ms['plan'], 3)
     _torch()
     # Placement of the state: the tuned (VMM draw-and-probe) placement speeds the streaming kernels up by ~10 % but
     # the search itself costs ~2.5 s at n = 30 (8 draws): only worth it when the modelled loop is long enough to
@@ -867,6 +874,7 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
     core.sync()  # the ONLY synchronisation of the loop
     t1 = time.perf_counter()  # simulation.py:666
     info['runtime (s)'] = t1 - t0
+    info['host_ms'] = {k: round(v, 3) for k, v in host_ms.items()}
     if schedule_info is not None:
         info['schedule'] = schedule_info
     info['n_gates'] = len(gates)  # apply_U calls issued (after fusion)

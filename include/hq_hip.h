@@ -309,6 +309,12 @@ int hq_plan_counts(const void *plan, unsigned int *n_ops, unsigned int *n_gates,
 int hq_plan_read(const void *plan, unsigned int *op_kind, unsigned int *op_first_gate, unsigned int *op_tile,
                  unsigned int *gate_k, unsigned int *gate_positions, double *U);
 int hq_plan_free(void *plan);
+/* fusion.simplify (the reference's utils.simplify, hybridq/circuit/utils.py:825-866 + insert_from_left :122-208) on gates
+ * given as in hq_plan_blocked, `qubits` being integer ids below 62: out_index[0 .. *out_count) = the surviving gates in
+ * their new order (out_index holds n_gates entries). */
+int hq_plan_simplify(unsigned int n_qubits, unsigned int n_gates, const unsigned int *k, const unsigned int *qubits,
+                     const double *U, double atol, int use_matrix_commutation, unsigned int max_n_qubits_matrix,
+                     int remove_id_gates, unsigned int *out_index, unsigned int *out_count);
 
 #ifdef __cplusplus
 }

@@ -98,3 +98,35 @@ def test_plan_abi_rejects_bad_input():
         core.plan_blocked(4, [(U, [1])], 4, 2, 'auto', 3, 1, 1, 4, 0, 0.0)
     kind, first, tile, gk, gpos, mats = core.plan_blocked(4, [], 4, 2, 'auto', 3, 1, 1, 4, 0, 1e-12)
     assert len(kind) == 0 and list(first) == [0]
+
+
+def test_native_simplify_equals_the_python_statement():
+    """hq_plan_simplify against fusion.simplify(native=False) -- the statement the live tests hold against the reference
+    itself -- on circuits with planted identities, inverse pairs and commuting diagonal gates, under every option."""
+    from hybridq_amd import fusion
+    rng = np.random.default_rng(0)
+
+    def same(a, b):
+        return len(a) == len(b) and all(x[1] == y[1] and np.array_equal(x[0], y[0]) for x, y in zip(a, b))
+
+    for trial in range(30):
+        n = int(rng.integers(4, 9))
+        g = list(rqc_1q2q(n, depth=int(rng.integers(2, 6)), seed=trial))
+        for _ in range(6):
+            q, i, kind = int(rng.integers(n)), int(rng.integers(len(g) + 1)), int(rng.integers(4))
+            if kind == 0:
+                g.insert(i, (np.eye(2), (q,)))
+            elif kind == 1:
+                U = g[int(rng.integers(len(g)))][0]
+                qs = tuple(int(x) for x in rng.permutation(n)[:int(np.log2(U.shape[0]))])
+                g.insert(i, (U, qs))
+                g.insert(i + 1, (np.linalg.inv(U), qs))
+            elif kind == 2:
+                g.insert(i, (np.diag(np.exp(1j * rng.standard_normal(4))), tuple(int(x) for x in rng.permutation(n)[:2])))
+            else:
+                g.insert(i, (np.diag(np.exp(1j * rng.standard_normal(2))), (q,)))
+        labelled = [(U, tuple(('q', x) if x % 2 else f's{x}' for x in qs)) for U, qs in g]  # labels need not be integers
+        for kw in (dict(), dict(use_matrix_commutation=False), dict(max_n_qubits_matrix=1), dict(remove_id_gates=False), dict(atol=1e-3)):
+            assert same(fusion.simplify(g, native=False, **kw), fusion.simplify(g, native=True, **kw)), (trial, kw)
+            assert same(fusion.simplify(labelled, native=False, **kw), fusion.simplify(labelled, **kw)), (trial, kw)
+    assert len(fusion.simplify([(np.eye(2), (0,))])) == 0 and fusion.simplify([]) == []
