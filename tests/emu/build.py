@@ -10,8 +10,16 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'hybridq_amd', 'csrc')
-OUT = os.path.join(HERE, '_build')
+#: HQ_EMU_ASAN=1: the same build under AddressSanitizer (shared runtime; load with LD_PRELOAD=asan_runtime()): every global
+#: memory access of every kernel body is bounds-checked against the emulated device allocations (malloc) -- the sanitizer
+#: run the GPU boxes could not do (their instrumented code object needs XNACK)
+ASAN = os.environ.get('HQ_EMU_ASAN') == '1'
+OUT = os.path.join(HERE, '_build_asan' if ASAN else '_build')
 LIB = os.path.join(OUT, 'libhq_emu.so')
+
+
+def asan_runtime():
+    return subprocess.run([_cxx(), '-print-file-name=libclang_rt.asan-x86_64.so'], capture_output=True, text=True).stdout.strip()
 UNITS = ['hq_core', 'hq_apply', 'hq_swap', 'hq_shard', 'hq_state', 'hq_plan']
 
 
@@ -36,6 +44,10 @@ def build(force=False, verbose=False):
     cxx = _cxx()
     flags = ['-std=c++17', '-O2', '-g1', '-fPIC', '-DHQ_EMU=1', '-ffp-contract=off', '-Wno-unused-function', '-Wno-unused-value',
              '-Wno-unknown-attributes', '-Wno-ignored-attributes', '-I', os.path.join(HERE, 'shim')]
+    link = []
+    if ASAN:
+        flags += ['-fsanitize=address', '-shared-libasan', '-fno-omit-frame-pointer']
+        link = ['-fsanitize=address', '-shared-libasan']
     jobs, objs = [], []
     for u in UNITS:
         obj = os.path.join(OUT, u + '.o')
@@ -55,7 +67,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(len(jobs)) as pool:
         list(pool.map(run, jobs))
-    run([cxx, '-shared', '-fPIC'] + objs + ['-o', LIB + '.tmp', '-ldl', '-lpthread'])
+    run([cxx, '-shared', '-fPIC'] + link + objs + ['-o', LIB + '.tmp', '-ldl', '-lpthread'])
     os.replace(LIB + '.tmp', LIB)
     return LIB
 

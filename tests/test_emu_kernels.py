@@ -146,3 +146,36 @@ def test_tuned_placement_allocator_on_emulated_granules():
         os.environ.pop('HQ_STATE_TUNED_MIN_BYTES', None)
         os.environ.pop('HQ_STATE_TRIES', None)
         core.state_pool_trim()
+
+
+def test_address_sanitizer_over_the_kernel_families():
+    """The sanitizer run the GPU boxes could not do (their instrumented device code needs XNACK): the
+    emulation build under HOST AddressSanitizer -- every global-memory access of every kernel body checked against the
+    emulated device allocations.  One case per kernel family runs clean; a call that is handed buffers half the size it is
+    told does get reported, with the kernel's source line (so a clean run means something)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+    try:
+        import build as emu_build
+        rt = emu_build.asan_runtime()
+    finally:
+        sys.path.pop(0)
+        sys.modules.pop('build', None)
+    if not os.path.exists(rt):
+        pytest.skip('no AddressSanitizer runtime next to clang++')
+    env = dict(os.environ, HQ_EMU_ASAN='1', LD_PRELOAD=rt, PYTHONPATH=ROOT,
+               ASAN_OPTIONS='detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1')
+    env.pop('HQ_HIP_LIBRARY', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu_order_worker.py')], env=env, capture_output=True, text=True,
+                       timeout=1800)
+    assert r.returncode == 0 and 'AddressSanitizer' not in r.stderr, r.stderr[-3000:]
+    assert len(r.stdout.strip().splitlines()) >= 45
+    bad = ("import sys, ctypes; sys.path[:0] = [%r, %r]\n"
+           "import emu_util\n"
+           "core = emu_util.emu_core()\n"
+           "a, b = ctypes.c_void_p(), ctypes.c_void_p()\n"
+           "assert core._lib.hq_alloc(ctypes.byref(a), ctypes.c_uint64(4 << 12), 0) == 0\n"
+           "assert core._lib.hq_alloc(ctypes.byref(b), ctypes.c_uint64(4 << 12), 0) == 0\n"
+           "perm = (ctypes.c_uint32 * 13)(*range(13))\n"
+           "core._lib.hq_permute_bits_32(a, b, perm, 13)\n" % (os.path.join(ROOT, 'tests'), ROOT))
+    r = subprocess.run([sys.executable, '-c', bad], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'heap-buffer-overflow' in r.stderr and 'bitperm_tile_kernel' in r.stderr, r.stderr[-2000:]
