@@ -811,6 +811,8 @@ def main():
             order8 = np.array([0, 1, 5, 6, 7, 2, 3, 4])  # what the reference driver issues (simulation.py:584-594)
             time_aux('swap_pair_s8_reference_order', lambda: (core.swap(re_, order8, n), core.swap(im_, order8, n)), 4 * P)
             for s_ in (12, 13, 14, 16):
+                if s_ > n:
+                    continue
                 pos_ = rng_a.permutation(s_)
                 time_aux(f'swap_one_plane_s{s_}', lambda: core.swap(re_, pos_, n), 2 * P)
             out_c = torch.empty(1 << n, dtype=torch.complex64 if tdt == torch.float32 else torch.complex128, device='cuda')

@@ -185,6 +185,8 @@ _plan_counts = _define_function(_lib, 'hq_plan_counts', ctypes.c_int, ctypes.c_v
                                 ctypes.POINTER(ctypes.c_uint64), _u32p)
 _plan_read = _define_function(_lib, 'hq_plan_read', ctypes.c_int, ctypes.c_void_p, _u32p, _u32p, _u32p, _u32p, _u32p, ctypes.c_void_p)
 _plan_free = _define_function(_lib, 'hq_plan_free', ctypes.c_int, ctypes.c_void_p)
+_plan_fuse = _define_function(_lib, 'hq_plan_fuse', ctypes.c_int, ctypes.c_uint, ctypes.c_uint, _u32p, _u32p, ctypes.c_void_p, ctypes.c_uint,
+                              ctypes.c_int, ctypes.c_uint, ctypes.c_uint64, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p))
 _plan_simplify = _define_function(_lib, 'hq_plan_simplify', ctypes.c_int, ctypes.c_uint, ctypes.c_uint, _u32p, _u32p, ctypes.c_void_p,
                                   ctypes.c_double, ctypes.c_int, ctypes.c_uint, ctypes.c_int, _u32p, _u32p)
 
@@ -204,7 +206,7 @@ EXPORTED = [
     'hq_shard_info', 'hq_shard_free', 'hq_shard_rccl_selftest', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
     'hq_exchange_float32', 'hq_exchange_float64', 'hq_alloc', 'hq_free', 'hq_alloc_mapped', 'hq_alloc_scattered',
     'hq_alloc_state', 'hq_free_state', 'hq_state_info', 'hq_state_pool_trim',
-    'hq_plan_blocked', 'hq_plan_counts', 'hq_plan_read', 'hq_plan_free', 'hq_plan_simplify',
+    'hq_plan_blocked', 'hq_plan_counts', 'hq_plan_read', 'hq_plan_free', 'hq_plan_simplify', 'hq_plan_fuse',
 ]
 
 
@@ -611,6 +613,40 @@ def plan_blocked(n, gates, tile_bits, low_bits, inner_max, min_gates, tries, fus
     finally:
         _plan_free(handle)
     return kind, first, tile, gk, gpos, mats
+
+
+def _read_plan(handle):
+    n_ops, n_g, tb = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+    n_pos, n_el = ctypes.c_uint64(), ctypes.c_uint64()
+    _check(_plan_counts(handle, ctypes.byref(n_ops), ctypes.byref(n_g), ctypes.byref(n_pos), ctypes.byref(n_el), ctypes.byref(tb)),
+           'hq_plan_counts')
+    kind = np.empty(n_ops.value, np.uint32)
+    first = np.empty(n_ops.value + 1, np.uint32)
+    tile = np.empty((n_ops.value, tb.value), np.uint32)
+    gk = np.empty(n_g.value, np.uint32)
+    gpos = np.empty(n_pos.value, np.uint32)
+    mats = np.empty(n_el.value, np.complex128)
+    _check(_plan_read(handle, kind.ctypes.data_as(_u32p), first.ctypes.data_as(_u32p), tile.ctypes.data_as(_u32p),
+                      gk.ctypes.data_as(_u32p), gpos.ctypes.data_as(_u32p), mats.ctypes.data), 'hq_plan_read')
+    return kind, first, tile, gk, gpos, mats
+
+
+def plan_fuse(n_ids, gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, exclude_mask, commute_tol):
+    """``hq_plan_fuse``: the fused gates of `gates` = [(U, integer qubit ids)] as (gate_k, ids flat (sorted, most
+    significant first), matrices flat complex128)."""
+    G = len(gates)
+    k = np.fromiter((len(q) for _, q in gates), dtype=np.uint32, count=G)
+    ids = np.fromiter((int(x) for _, q in gates for x in q), dtype=np.uint32, count=int(k.sum()))
+    U = np.concatenate([np.asarray(u, dtype=np.complex128).reshape(-1) for u, _ in gates]) if G else np.zeros(0, np.complex128)
+    handle = ctypes.c_void_p()
+    _check(_plan_fuse(n_ids, G, k.ctypes.data_as(_u32p), ids.ctypes.data_as(_u32p), U.ctypes.data, int(max_n_qubits),
+                      int(bool(use_matrix_commutation)), int(max_n_qubits_matrix), int(exclude_mask), float(commute_tol),
+                      ctypes.byref(handle)), 'hq_plan_fuse')
+    try:
+        _, _, _, gk, gpos, mats = _read_plan(handle)
+    finally:
+        _plan_free(handle)
+    return gk, gpos, mats
 
 
 def plan_simplify(n_ids, gates, atol, use_matrix_commutation, max_n_qubits_matrix, remove_id_gates):

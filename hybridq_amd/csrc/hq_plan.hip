@@ -177,19 +177,33 @@ struct Layer {
   std::vector<cd> U;
 };
 
-static std::vector<Layer> build_layers(const std::vector<const Gate*>& gates, unsigned max_n, double tol) {
+struct FuseOptions {
+  unsigned max_n = 4;
+  bool use_mc = true;           // use_matrix_commutation
+  unsigned max_nqm = 10;        // max_n_qubits_matrix
+  uint64_t exclude = 0;         // gates touching these qubits are never compressed (utils.py:615-617)
+  double tol = 1e-5;            // commutes_with's fixed tolerance, or the planner's "commutes to rounding"
+};
+
+static std::vector<Layer> build_layers(const std::vector<const Gate*>& gates, const FuseOptions& o) {
+  struct Meta { bool compress, has_matrix; };
   std::vector<Layer> layers;
+  std::vector<Meta> meta;
   for (const Gate* g : gates) {
     const uint64_t qm = mask_of(g->q);
     const unsigned nq = (unsigned)g->q.size();
+    const bool can = !(qm & o.exclude);
+    const bool gate_matrix = o.use_mc && nq <= o.max_nqm;  // utils.py:606-611
     size_t merge_to = layers.size();
     for (size_t i = layers.size(); i-- > 0;) {
       const Layer& L = layers[i];
       const uint64_t cm = mask_of(L.q);
       const unsigned nu = (unsigned)__builtin_popcountll(qm | cm);
-      if (nu <= std::max<unsigned>(max_n, std::max<unsigned>((unsigned)L.q.size(), nq))) merge_to = i;  // utils.py:626-630
-      if (!(qm & cm)) continue;
-      if (commute(g->U, g->q, L.U, L.q, tol)) continue;  // utils.py:633-646
+      if (can && meta[i].compress && nu <= std::max<unsigned>(o.max_n, std::max<unsigned>((unsigned)L.q.size(), nq))) merge_to = i;  // utils.py:626-630
+      if (o.use_mc) {  // utils.py:633-646
+        if (!(qm & cm)) continue;
+        if (gate_matrix && meta[i].has_matrix && commute(g->U, g->q, L.U, L.q, o.tol)) continue;
+      }
       break;
     }
     if (merge_to < layers.size()) {
@@ -198,13 +212,21 @@ static std::vector<Layer> build_layers(const std::vector<const Gate*>& gates, un
       // the new gate acts AFTER everything already in the layer
       L.U = matmul(embed(g->U, g->q, Q), embed(L.U, L.q, Q), (size_t)1 << Q.size());
       L.q = Q;
+      meta[merge_to].has_matrix = meta[merge_to].has_matrix && gate_matrix && Q.size() <= o.max_nqm;  // utils.py:660-669
     } else {
       std::vector<unsigned> Q(g->q);
       std::sort(Q.begin(), Q.end());
       layers.push_back(Layer{Q, embed(g->U, g->q, Q)});
+      meta.push_back(Meta{can, gate_matrix});
     }
   }
   return layers;
+}
+static std::vector<Layer> build_layers(const std::vector<const Gate*>& gates, unsigned max_n, double tol) {
+  FuseOptions o;
+  o.max_n = max_n;
+  o.tol = tol;
+  return build_layers(gates, o);
 }
 
 // the grouping build_layers would produce on qubit sets alone (sliding through disjoint layers only)
@@ -494,6 +516,46 @@ int hq_plan_simplify(unsigned int n_qubits, unsigned int n_gates, const unsigned
   const std::vector<unsigned> out = simplify(gates, atol, use_matrix_commutation != 0, max_n_qubits_matrix, remove_id_gates != 0);
   std::copy(out.begin(), out.end(), out_index);
   *out_count = (unsigned)out.size();
+  return 0;
+}
+
+int hq_plan_fuse(unsigned int n_qubits, unsigned int n_gates, const unsigned int* k, const unsigned int* qubits, const double* U,
+                 unsigned int max_n_qubits, int use_matrix_commutation, unsigned int max_n_qubits_matrix, uint64_t exclude_mask,
+                 double commute_tol, void** plan) {
+  using namespace hq::plan;
+  if (!plan) return hq::fail("hq_plan_fuse: null output");
+  *plan = nullptr;
+  if (n_gates && (!k || !qubits || !U)) return hq::fail("hq_plan_fuse: null input");
+  if (n_qubits == 0 || n_qubits > 62) return hq::fail("hq_plan_fuse: qubit ids must be below 62");
+  if (!(commute_tol > 0)) return hq::fail("hq_plan_fuse: commute_tol must be positive");
+  std::vector<Gate> gates(n_gates);
+  size_t po = 0, uo = 0;
+  for (unsigned g = 0; g < n_gates; ++g) {
+    if (k[g] == 0 || k[g] > 12) return hq::fail("hq_plan_fuse: gates act on 1..12 qubits");
+    if (hq::check_positions(qubits + po, n_qubits, k[g])) return hq::fail("hq_plan_fuse: invalid qubit ids");
+    gates[g].q.assign(qubits + po, qubits + po + k[g]);
+    const size_t e = (size_t)1 << (2 * k[g]);
+    gates[g].U.resize(e);
+    for (size_t i = 0; i < e; ++i) gates[g].U[i] = cd(U[2 * (uo + i)], U[2 * (uo + i) + 1]);
+    po += k[g];
+    uo += e;
+  }
+  FuseOptions o;
+  o.max_n = max_n_qubits;
+  o.use_mc = use_matrix_commutation != 0;
+  o.max_nqm = max_n_qubits_matrix;
+  o.exclude = exclude_mask;
+  o.tol = commute_tol;
+  std::vector<const Gate*> ptrs;
+  for (const auto& g : gates) ptrs.push_back(&g);
+  Result* r = new Result();
+  r->op_first_gate.push_back(0);
+  for (auto& L : build_layers(ptrs, o)) {
+    r->op_kind.push_back(0);
+    r->gates.push_back(Gate{L.q, L.U});
+    r->op_first_gate.push_back((unsigned)r->gates.size());
+  }
+  *plan = r;
   return 0;
 }
 

@@ -644,7 +644,7 @@ TUNED_PLACEMENT_SEARCH_MS = 2500.0  # what alloc_planes' draw-and-probe search c
 #: n = 16..30: fusion to 4 ~0.04 ms / gate, to 5 ~0.07; the Python blocked planner needed ~0.13 at full search effort).
 #: Round 4: the blocked planner runs behind the C ABI (hq_plan_blocked): 0.02 ms / gate at full search effort (17 ms for
 #: the 900-gate n = 30 circuit; tools/plan_time.py), so the quick search of round 3 is gone
-PLAN_HOST_MS_PER_GATE = {'per_gate': 0.0, 'fused_4': 0.045, 'fused_5': 0.075, 'blocked': 0.02}
+PLAN_HOST_MS_PER_GATE = {'per_gate': 0.0, 'fused_4': 0.006, 'fused_5': 0.011, 'blocked': 0.011}  # all three planners native (hq_plan_*)
 BLOCKED_VS_FUSED5 = 0.55  # modelled time of the cache-blocked plan over the fused-5 plan (0.45 benchmark circuit, 0.63 dense 3q/4q gates)
 PREDICTION_SLACK = 0.85  # a plan may come out this much better than predicted (commuting gates fuse further)
 LAUNCH_FLOOR_MS = 0.011  # Python -> ctypes -> plan -> launch per call (profiles/r01_program_overhead.txt)

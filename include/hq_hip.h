@@ -309,6 +309,12 @@ int hq_plan_counts(const void *plan, unsigned int *n_ops, unsigned int *n_gates,
 int hq_plan_read(const void *plan, unsigned int *op_kind, unsigned int *op_first_gate, unsigned int *op_tile,
                  unsigned int *gate_k, unsigned int *gate_positions, double *U);
 int hq_plan_free(void *plan);
+/* fusion.fuse = the reference's utils.compress + to_matrix_gate (hybridq/circuit/utils.py:467-685, 419-464) with its options;
+ * `qubits` are integer ids below 62 whose ORDER is the order of the labels (a fused gate's qubits come out sorted, most
+ * significant first); commute_tol 1e-5 reproduces the reference.  The plan holds one plain op per fused gate. */
+int hq_plan_fuse(unsigned int n_qubits, unsigned int n_gates, const unsigned int *k, const unsigned int *qubits, const double *U,
+                 unsigned int max_n_qubits, int use_matrix_commutation, unsigned int max_n_qubits_matrix, uint64_t exclude_mask,
+                 double commute_tol, void **plan);
 /* fusion.simplify (the reference's utils.simplify, hybridq/circuit/utils.py:825-866 + insert_from_left :122-208) on gates
  * given as in hq_plan_blocked, `qubits` being integer ids below 62: out_index[0 .. *out_count) = the surviving gates in
  * their new order (out_index holds n_gates entries). */

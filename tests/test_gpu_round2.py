@@ -320,7 +320,8 @@ def test_evolution_hip_chooses_a_schedule(torch_cuda, monkeypatch):
     g20 = rqc_1q2q(20, depth=12, seed=2)
     psi_a, info_a = simulate(g20, initial_state='0' * 20, optimize='evolution', return_info=True, qubits=list(range(20)))
     psi_h, info_h = simulate(g20, initial_state='0' * 20, optimize='evolution-hybridq', return_info=True, qubits=list(range(20)))
-    assert info_a['schedule']['chosen'] == 'per_gate' and 'schedule' not in info_h  # short loop: nothing to win back
+    # a short loop: fusing to 4 pays for its (native, 0.006 ms per gate) planning, the cache-blocked plan does not
+    assert info_a['schedule']['chosen'] == 'fused_4' and 'blocked' in info_a['schedule']['not_planned'] and 'schedule' not in info_h
     assert np.abs(psi_a - psi_h).max() / np.abs(psi_h).max() < 2 * circuit_tol(g20)
     # with planning priced at nothing the schedule predicted to be fastest is planned first: the cache-blocked one, as at n = 30
     from hybridq_amd import simulation

@@ -40,11 +40,12 @@ def test_choose_schedule_cost_model():
     _, small = choose_schedule(rqc_1q2q(10, depth=8, seed=1), list(range(10)), 10, np.dtype('complex64'))
     assert 'blocked' not in small['modelled_ms'] and 'blocked' not in small['not_planned']
     # ... and planning is host time too: a schedule is planned only when its predicted device time plus its planning time
-    # beats the best plan in hand, so short loops run gate by gate at once and n >= 24 plans the cache-blocked schedule
-    # only (round 3, with the Python planner: fusion to 4 at n = 25, blocked from n = 26)
-    assert small['chosen'] == 'per_gate' and small['not_planned'] == ['fused_4', 'fused_5']
+    # beats the best plan in hand.  Round 4: the planners are native (fusion to 4: 0.006 ms per gate), so even the
+    # launch-bound loops of small states pay for fusing (fewer calls), n <= 24 plans fusion to 4 only and n >= 25 the
+    # cache-blocked schedule only (round 3, Python planners: gate by gate up to n = 24, fusion at 25, blocked from 26)
+    assert small['chosen'] == 'fused_4' and small['not_planned'] == ['fused_5']
     _, mid = choose_schedule(rqc_1q2q(20, depth=40, seed=20), list(range(20)), 20, np.dtype('complex64'))
-    assert mid['chosen'] == 'per_gate' and mid['not_planned'] == ['fused_4', 'fused_5', 'blocked']
+    assert mid['chosen'] == 'fused_4' and mid['not_planned'] == ['fused_5', 'blocked']
     _, m25 = choose_schedule(rqc_1q2q(25, depth=40, seed=25), list(range(25)), 25, np.dtype('complex64'))
     assert m25['chosen'] == 'blocked' and m25['not_planned'] == ['fused_4', 'fused_5']
     _, m28 = choose_schedule(rqc_1q2q(28, depth=40, seed=28), list(range(28)), 28, np.dtype('complex64'))

@@ -130,3 +130,29 @@ def test_native_simplify_equals_the_python_statement():
             assert same(fusion.simplify(g, native=False, **kw), fusion.simplify(g, native=True, **kw)), (trial, kw)
             assert same(fusion.simplify(labelled, native=False, **kw), fusion.simplify(labelled, **kw)), (trial, kw)
     assert len(fusion.simplify([(np.eye(2), (0,))])) == 0 and fusion.simplify([]) == []
+
+
+def test_native_fuse_equals_the_python_statement():
+    """hq_plan_fuse against fusion.fuse(native=False) (the statement the live tests hold against the reference's
+    compress + to_matrix_gate) under the reference's options and the planner's exact commutation."""
+    from hybridq_amd import fusion
+    rng = np.random.default_rng(1)
+
+    def same(a, b):
+        return len(a) == len(b) and all(x[1] == y[1] and x[0].dtype == y[0].dtype and np.abs(x[0] - y[0]).max() < 1e-12
+                                        for x, y in zip(a, b))
+
+    for trial in range(25):
+        n = int(rng.integers(4, 10))
+        g = list(rqc_1q2q(n, depth=int(rng.integers(2, 8)), seed=trial)) + random_dense(n, int(rng.integers(0, 10)), kmax=3, seed=trial)
+        for _ in range(5):  # commuting diagonal gates: the matrix-commutation branch
+            i = int(rng.integers(len(g) + 1))
+            qs = tuple(int(x) for x in rng.permutation(n)[:int(rng.integers(1, 4))])
+            g.insert(i, (np.diag(np.exp(1j * rng.standard_normal(1 << len(qs)))), qs))
+        labelled = [(U, tuple(f'q{x:02d}' for x in qs)) for U, qs in g]
+        for kw in (dict(max_n_qubits=2), dict(max_n_qubits=4), dict(max_n_qubits=5, complex_type='complex128'),
+                   dict(max_n_qubits=4, use_matrix_commutation=False), dict(max_n_qubits=4, max_n_qubits_matrix=2),
+                   dict(max_n_qubits=3, exclude_qubits=[0, 2]), dict(max_n_qubits=3, exact_commutation=True),
+                   dict(max_n_qubits=6, max_n_qubits_matrix=3)):
+            assert same(fusion.fuse(g, native=False, **kw), fusion.fuse(g, native=True, **kw)), (trial, kw)
+        assert same(fusion.fuse(labelled, 4, native=False), fusion.fuse(labelled, 4)), trial
