@@ -729,6 +729,31 @@ def choose_schedule(circuit, qubits, n, ctype):
                          'not_planned': [k for k in cands if k not in plans]}
 
 
+#: schedules of the last PLAN_CACHE_SIZE distinct circuits (content-addressed; 0 switches the cache off)
+PLAN_CACHE_SIZE = 16
+_PLAN_CACHE = __import__('collections').OrderedDict()
+
+
+def _plan_key(circuit, qubits, n, ctype, auto_schedule, compress, blocked):
+    """Digest of everything a plan depends on, or None when the circuit holds objects a digest cannot speak for
+    (FunctionalGates: user code)."""
+    if PLAN_CACHE_SIZE <= 0:
+        return None
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    h.update(repr((n, str(ctype), bool(auto_schedule), compress if not isinstance(compress, dict) else sorted(compress.items(), key=str),
+                   blocked if not isinstance(blocked, dict) else sorted(blocked.items(), key=str), tuple(qubits),
+                   sorted(PLAN_HOST_MS_PER_GATE.items()) if auto_schedule else None)).encode())
+    for g in circuit:
+        if _is_functional(g):
+            return None
+        qs, U = _gate_qubits_matrix(g)
+        U = np.ascontiguousarray(U)
+        h.update(repr((qs, U.dtype.str, U.shape)).encode())
+        h.update(U.tobytes())
+    return h.digest()
+
+
 def _execute_ops(state, gates):
     """The gate loop (simulation.py:522-646); returns the number of passes over the state."""
     n = state.n
@@ -851,11 +876,23 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
         _torch()
         return _simulate_sharded(circuit, qubits, n, ctype, initial_state, kwargs, auto_schedule)
     _t = time.perf_counter()
-    with single_thread_blas():  # thousands of tiny matrix products: a threaded BLAS only adds wake-ups
-        if auto_schedule:
-            gates, schedule_info = choose_schedule(circuit, qubits, n, ctype)
-        else:
-            gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
+    # plans are kept by circuit content (qubits + matrices + options): a sampling loop or a parameter scan that comes back
+    # with the same circuit pays for its schedule once
+    key = _plan_key(circuit, qubits, n, ctype, auto_schedule, kwargs['compress'], kwargs.get('blocked', False))
+    hit = _PLAN_CACHE.get(key) if key is not None else None
+    if hit is not None:
+        _PLAN_CACHE.move_to_end(key)
+        gates, schedule_info = hit[0], (dict(hit[1], from_cache=True) if hit[1] is not None else None)
+    else:
+        with single_thread_blas():  # thousands of tiny matrix products: a threaded BLAS only adds wake-ups
+            if auto_schedule:
+                gates, schedule_info = choose_schedule(circuit, qubits, n, ctype)
+            else:
+                gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
+        if key is not None:
+            _PLAN_CACHE[key] = (gates, dict(schedule_info) if schedule_info is not None else None)
+            while len(_PLAN_CACHE) > PLAN_CACHE_SIZE:
+                _PLAN_CACHE.popitem(last=False)
     host_ms['plan'] = 1e3 * (time.perf_counter() - _t)
     if schedule_info is not None:
         schedule_info['plan_ms'] = round(host_ms['plan'], 3)

@@ -35,3 +35,32 @@ def test_gpu_tests_pass_against_the_emulated_library():
     assert m and int(m.group(1)) >= (150 if full else 95), tail
     if full or os.environ.get('HQ_EMU_SHOW') == '1':
         print(tail)
+
+
+def test_bench_line_end_to_end_against_the_emulated_library():
+    """bench.py itself -- the file the driver runs for the round's record -- on a small state against the emulation: every
+    block of the line is produced (no `*_error` keys), the contract fields are there, the config-4 / config-5 legs and the
+    parity block carry what DESIGN section 6 says.  The numbers mean nothing; the code paths are the real ones."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop('HQ_HIP_LIBRARY', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'tests', 'emu', 'run_emulated.py'), 'bench.py', '--qubits', '14', '--depth', '3',
+           '--steps', '1', '--warmup', '1', '--parity-qubits', '10', '--leg-parity-qubits', '10', '--cpu-seconds', '0.5']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert not [k for k in line if k.endswith('_error')], [k for k in line if k.endswith('_error')]
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity_check', 'cfg4_dense_k34', 'cfg5_noisy_dm', 'blocked',
+                'fused', 'per_k', 'aux'):
+        assert key in line, key
+    assert line['n_gpus'] == 1 and line['dtype'] == 'f32' and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert 'workload' in line['config'] and 'model' not in line['config']
+    r = line['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert line['cpu_baseline']['kind'] in ('reference', 'port') and line['cpu_baseline']['cores'] >= 1
+    for leg in ('cfg4_dense_k34', 'cfg5_noisy_dm'):
+        assert line[leg]['roofline']['kernel'] and line[leg]['gate_apps_per_s'] > 0 and line[leg]['parity_small_n']['pass'] is True
+    pc = line['parity_check']
+    assert pc['pass'] is True and pc['literal_bar_depth'] == pc['literal_bar_depth_of'] and len(pc['prefixes']) >= 8
+    assert 'l2_rel_diff_per_gate' in pc and 'reference_vs_f64_leaves_bar_after' in pc

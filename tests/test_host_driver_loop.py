@@ -202,3 +202,27 @@ def test_device_functional_gates_in_the_loop(numpy_device):
         simulate(g1 + [m], initial_state='0' * n, complex_type='complex128', qubits=q, compress=0, return_numpy_array=False)
         counts[m.outcome] += 1
     assert np.abs(counts / 300 - marg).max() < 0.1
+
+
+def test_plans_are_cached_by_circuit_content(numpy_device):
+    """simulate() keeps the schedules of the last circuits by content: the same circuit again skips planning
+    (info['schedule']['from_cache']), a circuit that differs in one matrix entry does not, FunctionalGates switch it off."""
+    from hybridq_amd import simulation as sim
+    from hybridq_amd.circuits import rqc_1q2q
+    sim._PLAN_CACHE.clear()
+    n = 12
+    gates = rqc_1q2q(n, depth=6, seed=3)
+    kw = dict(initial_state='0' * n, optimize='evolution', return_info=True, qubits=list(range(n)))
+    psi1, info1 = sim.simulate(gates, **kw)
+    psi2, info2 = sim.simulate(gates, **kw)
+    assert not info1['schedule'].get('from_cache') and info2['schedule'].get('from_cache') is True
+    assert np.array_equal(psi1, psi2) and info2['host_ms']['plan'] <= info1['host_ms']['plan']
+    other = list(gates)
+    other[3] = (other[3][0] * np.exp(0.25j), other[3][1])
+    _, info3 = sim.simulate(other, **kw)
+    assert not info3['schedule'].get('from_cache') and len(sim._PLAN_CACHE) == 2
+    fn = sim.FunctionalGate((0,), lambda psi, order: (psi, order))
+    sim.simulate(gates[:5] + [fn] + gates[5:], **kw)
+    assert len(sim._PLAN_CACHE) == 2
+    _, info5 = sim.simulate(gates, compress=4, **{k: v for k, v in kw.items() if k != 'optimize'}, optimize='evolution-hybridq')
+    assert 'schedule' not in info5 and len(sim._PLAN_CACHE) == 3
