@@ -11,6 +11,12 @@ Context& ctx() {
 
 int fail(const std::string& msg) {
   ctx().last_error = msg;
+  // A failed runtime call leaves its code in the thread's "last error" until somebody reads it, and the launch checks
+  // (hipGetLastError() after every kernel launch) would report it as THEIR failure -- after the caller has already taken
+  // its fallback (tuned placement -> plain memory, IPC export refused -> another transport).  Whoever reports a failure
+  // through here has consumed the runtime's error with it.  (Round 4, found twice by running against the host emulation:
+  // hq_alloc_state without VMM, hq_ipc_export on memory IPC cannot export.)
+  (void)hipGetLastError();
   return 1;
 }
 

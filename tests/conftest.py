@@ -48,9 +48,6 @@ def pytest_configure(config):
 EMU_SKIP = (
     ('test_gpu_fullsize.py', 'BASELINE-size states (n = 30...) are hours of emulation'),
     ('test_gpu_determinism.py', 'run-to-run determinism of the hardware; the emulation has tests/test_emu_kernels.py::test_wave_order'),
-    ('two_ranks_one_gpu', 'several processes sharing one real GPU'),
-    ('eight_ranks_sharing', 'several processes sharing one real GPU'),
-    ('sharded_api', 'several processes sharing one real GPU'),
     ('rccl', 'needs the real RCCL on a real device'),
     ('c_abi_demo_without_python', 'a C program linked against the real HIP runtime'),
     ('c_abi_state_demo_without_python', 'a C program linked against the real HIP runtime'),
@@ -78,7 +75,8 @@ EMU_SKIP = (
 EMU_SLOW = ('apply_U_mfma_kernels', 'randomized_differential', 'apply_U_gemm_kernel', 'simulate_blocked_matches_oracle',
             'evolution_hip_chooses', 'compiled_program', 'exchange_pack_one_pass', 'simulation_large_like_reference',
             'state_allocator_behind', 'restore_order_hip_backend', 'simulate_matches_reference_protocol',
-            'permute_bits_many_moved_bits', 'initialize_state[', 'guard_bands')
+            'permute_bits_many_moved_bits', 'initialize_state[', 'guard_bands', 'two_ranks_one_gpu', 'eight_ranks_sharing',
+            'sharded_api')
 
 
 def pytest_collection_modifyitems(config, items):
