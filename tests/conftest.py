@@ -35,6 +35,7 @@ if EMU_SUITE:
     import emu_util  # noqa: E402
     os.environ['HQ_HIP_LIBRARY'] = emu_util.emu_library()
     os.environ['HQ_EMU_HOST_IS_DEVICE'] = '1'
+    os.environ['HQ_RCCL_LIBRARY'] = emu_util.emu_rccl_library()  # tests/emu/rccl_emu.cpp: grouped send / recv between processes
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
     import fake_cuda  # noqa: E402
     fake_cuda.install()
@@ -48,7 +49,6 @@ def pytest_configure(config):
 EMU_SKIP = (
     ('test_gpu_fullsize.py', 'BASELINE-size states (n = 30...) are hours of emulation'),
     ('test_gpu_determinism.py', 'run-to-run determinism of the hardware; the emulation has tests/test_emu_kernels.py::test_wave_order'),
-    ('rccl', 'needs the real RCCL on a real device'),
     ('c_abi_demo_without_python', 'a C program linked against the real HIP runtime'),
     ('c_abi_state_demo_without_python', 'a C program linked against the real HIP runtime'),
     ('many_tiles_per_workgroup[complex', 'n = 23...25: minutes of emulation per case'),

@@ -16,6 +16,7 @@ CSRC = os.path.join(ROOT, 'hybridq_amd', 'csrc')
 ASAN = os.environ.get('HQ_EMU_ASAN') == '1'
 OUT = os.path.join(HERE, '_build_asan' if ASAN else '_build')
 LIB = os.path.join(OUT, 'libhq_emu.so')
+RCCL = os.path.join(OUT, 'librccl_emu.so')
 
 
 def asan_runtime():
@@ -32,7 +33,7 @@ def _cxx():
 
 def _deps():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
-    deps += [os.path.join(ROOT, 'include', 'hq_hip.h'), os.path.join(HERE, 'hip_emu.cpp'), os.path.join(HERE, 'emu_selftest.cpp'), os.path.abspath(__file__),
+    deps += [os.path.join(ROOT, 'include', 'hq_hip.h'), os.path.join(HERE, 'hip_emu.cpp'), os.path.join(HERE, 'emu_selftest.cpp'), os.path.join(HERE, 'rccl_emu.cpp'), os.path.abspath(__file__),
              os.path.join(HERE, 'shim', 'hip', 'hip_runtime.h'), os.path.join(HERE, 'shim', 'rccl', 'rccl.h')]
     return deps
 
@@ -67,8 +68,11 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(len(jobs)) as pool:
         list(pool.map(run, jobs))
-    run([cxx, '-shared', '-fPIC'] + link + objs + ['-o', LIB + '.tmp', '-ldl', '-lpthread'])
+    run([cxx, '-shared', '-fPIC'] + link + objs + ['-o', LIB + '.tmp', '-ldl', '-lpthread', '-lrt'])
     os.replace(LIB + '.tmp', LIB)
+    # the stand-in for librccl (HQ_RCCL_LIBRARY): its own shared object, like the real one
+    run([cxx, '-shared', '-fPIC', '-std=c++17', '-O1', os.path.join(HERE, 'rccl_emu.cpp'), '-o', RCCL + '.tmp'])
+    os.replace(RCCL + '.tmp', RCCL)
     return LIB
 
 

@@ -85,6 +85,44 @@ def _from_cuda_array_interface(obj):
     return t
 
 
+class _Owner:
+    """Frees an emulated device allocation when the last view of it is gone."""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.hq_free(ctypes.c_void_p(self.ptr))
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+_LIB = []
+#: "device" tensors of at least this many bytes made by torch.empty(..., device='cuda') live in EMULATED DEVICE MEMORY
+#: (hq_alloc of the emulated library: a shared-memory object), so that they can be exported through the emulated HIP IPC to
+#: the other ranks of a multi-process test -- the shard buffers of the peer-to-peer exchange
+DEVICE_ALLOC_MIN_BYTES = 1 << 12
+
+
+def _device_empty(torch, shape, dtype):
+    import os
+    if not _LIB:
+        _LIB.append(ctypes.CDLL(os.environ['HQ_HIP_LIBRARY']))
+        _LIB[0].hq_alloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64, ctypes.c_int]
+        _LIB[0].hq_free.argtypes = [ctypes.c_void_p]
+    lib = _LIB[0]
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    numel = int(np.prod(shape))
+    ptr = ctypes.c_void_p()
+    if lib.hq_alloc(ctypes.byref(ptr), ctypes.c_uint64(numel * itemsize), 0) != 0:
+        raise MemoryError('emulated hq_alloc failed')
+    buf = (ctypes.c_char * (numel * itemsize)).from_address(ptr.value)
+    buf._hq_owner = _Owner(lib, ptr.value)  # the numpy view below keeps `buf` alive, `buf` the allocation
+    flat = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
+    return flat.view(dtype).reshape(shape)
+
+
 def install():
     import torch
     if getattr(torch, '_hq_fake_cuda', False):
@@ -111,9 +149,16 @@ def install():
         orig = getattr(torch, name)
 
         def f(*args, **kw):
+            on_device = 'device' in kw and str(kw['device']).startswith('cuda')
             if 'device' in kw:
                 kw['device'] = _to_cpu_device(kw['device'])
             kw.pop('pin_memory', None)
+            if name == 'empty' and on_device and kw.get('dtype') is not None and not kw.get('requires_grad'):
+                shape = args[0] if len(args) == 1 and isinstance(args[0], (tuple, list, torch.Size)) else args
+                if all(isinstance(d, int) for d in shape):
+                    nbytes = int(np.prod(shape)) * torch.empty((), dtype=kw['dtype']).element_size()
+                    if nbytes >= DEVICE_ALLOC_MIN_BYTES:
+                        return _device_empty(torch, tuple(shape), kw['dtype'])
             if name in ('as_tensor', 'tensor') and args and hasattr(args[0], '__cuda_array_interface__'):
                 return _from_cuda_array_interface(args[0])
             return orig(*args, **kw)

@@ -2,7 +2,9 @@
 // workgroup scheduler, wave-level exchanges with the gfx950 lane layouts, and a malloc-backed HIP memory / stream API.
 // Nothing in hybridq_amd loads this; see the header for what the model covers and what it does not.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -333,10 +335,43 @@ hipError_t hipGetLastError() { hipError_t e = g_last; g_last = hipSuccess; retur
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
+// Device allocations are POSIX shared-memory objects mapped MAP_SHARED, so that hipIpcGetMemHandle / hipIpcOpenMemHandle can
+// hand them to ANOTHER PROCESS of the test (the peer-to-peer exchange stores into the other ranks' planes).  Under
+// AddressSanitizer they are plain heap blocks instead (bounds-checked; no IPC there).
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HQ_EMU_HEAP_ALLOC 1
+#endif
+#endif
+namespace {
+struct Shm { std::string name; size_t len; };
+std::map<uintptr_t, Shm>& shm_blocks() { static std::map<uintptr_t, Shm> m; return m; }
+std::map<uintptr_t, size_t>& ipc_views() { static std::map<uintptr_t, size_t> m; return m; }
+void unlink_all() {
+  for (auto& kv : shm_blocks()) shm_unlink(kv.second.name.c_str());
+}
+}  // namespace
 hipError_t hipMalloc(void** p, size_t n) {
+  const size_t want = n ? n : 1;
+#ifdef HQ_EMU_HEAP_ALLOC
   void* q = nullptr;
-  if (posix_memalign(&q, 4096, n ? n : 1)) return ret(hipErrorOutOfMemory);
-  allocs()[(uintptr_t)q] = n ? n : 1;
+  if (posix_memalign(&q, 4096, want)) return ret(hipErrorOutOfMemory);
+#else
+  static unsigned long counter = 0;
+  static bool hooked = false;
+  if (!hooked) { atexit(unlink_all); hooked = true; }
+  const size_t len = (want + 4095) & ~(size_t)4095;
+  char name[64];
+  snprintf(name, sizeof(name), "/hq_emu_%d_%lu", (int)getpid(), counter++);
+  const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) return ret(hipErrorOutOfMemory);
+  if (ftruncate(fd, (off_t)len)) { close(fd); shm_unlink(name); return ret(hipErrorOutOfMemory); }
+  void* q = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (q == MAP_FAILED) { shm_unlink(name); return ret(hipErrorOutOfMemory); }
+  shm_blocks()[(uintptr_t)q] = Shm{name, len};
+#endif
+  allocs()[(uintptr_t)q] = want;
   *p = q;
   return hipSuccess;
 }
@@ -344,7 +379,16 @@ hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { return hipMallo
 hipError_t hipFree(void* p) {
   if (!p) return hipSuccess;
   if (!allocs().erase((uintptr_t)p)) return ret(hipErrorInvalidValue);
+#ifdef HQ_EMU_HEAP_ALLOC
   free(p);
+#else
+  auto it = shm_blocks().find((uintptr_t)p);
+  if (it != shm_blocks().end()) {
+    munmap(p, it->second.len);
+    shm_unlink(it->second.name.c_str());
+    shm_blocks().erase(it);
+  }
+#endif
   return hipSuccess;
 }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return posix_memalign(p, 4096, n ? n : 1) ? ret(hipErrorOutOfMemory) : hipSuccess; }
@@ -475,6 +519,39 @@ hipError_t hipMemSetAccess(void* p, size_t n, const hipMemAccessDesc*, size_t) {
   if (!inside_reservation(p, n)) return ret(hipErrorInvalidValue);
   return mprotect(p, n, PROT_READ | PROT_WRITE) ? ret(hipErrorInvalidValue) : hipSuccess;
 }
-hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return ret(hipErrorNotSupported); }
-hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return ret(hipErrorNotSupported); }
-hipError_t hipIpcCloseMemHandle(void*) { return ret(hipErrorNotSupported); }
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+#ifdef HQ_EMU_HEAP_ALLOC
+  (void)h; (void)p;
+  return ret(hipErrorNotSupported);
+#else
+  auto it = shm_blocks().find((uintptr_t)p);  // the BASE of an allocation, as on the device
+  if (it == shm_blocks().end()) return ret(hipErrorInvalidValue);
+  memset(h->reserved, 0, sizeof(h->reserved));
+  snprintf(h->reserved, sizeof(h->reserved), "%s", it->second.name.c_str());
+  return hipSuccess;
+#endif
+}
+hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+  char name[65];
+  memcpy(name, h.reserved, 64);
+  name[64] = 0;
+  const int fd = shm_open(name, O_RDWR, 0600);
+  if (fd < 0) return ret(hipErrorInvalidValue);
+  struct stat st;
+  if (fstat(fd, &st)) { close(fd); return ret(hipErrorInvalidValue); }
+  void* q = mmap(nullptr, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (q == MAP_FAILED) return ret(hipErrorOutOfMemory);
+  ipc_views()[(uintptr_t)q] = (size_t)st.st_size;
+  allocs()[(uintptr_t)q] = (size_t)st.st_size;  // a peer's memory is device memory here too
+  *p = q;
+  return hipSuccess;
+}
+hipError_t hipIpcCloseMemHandle(void* p) {
+  auto it = ipc_views().find((uintptr_t)p);
+  if (it == ipc_views().end()) return ret(hipErrorInvalidValue);
+  munmap(p, it->second);
+  allocs().erase((uintptr_t)p);
+  ipc_views().erase(it);
+  return hipSuccess;
+}

@@ -16,6 +16,7 @@ import emu_util  # noqa: E402
 
 os.environ['HQ_HIP_LIBRARY'] = emu_util.emu_library()
 os.environ['HQ_EMU_HOST_IS_DEVICE'] = '1'
+os.environ.setdefault('HQ_RCCL_LIBRARY', emu_util.emu_rccl_library())
 os.environ['HQ_EMU_GPU_SUITE'] = '1'
 import fake_cuda  # noqa: E402
 

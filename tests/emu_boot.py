@@ -15,6 +15,7 @@ def maybe_install():
     import emu_util
     os.environ.setdefault('HQ_HIP_LIBRARY', emu_util.emu_library())
     os.environ['HQ_EMU_HOST_IS_DEVICE'] = '1'
+    os.environ.setdefault('HQ_RCCL_LIBRARY', emu_util.emu_rccl_library())
     import fake_cuda
     fake_cuda.install()
     return True

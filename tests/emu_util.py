@@ -28,6 +28,11 @@ def emu_library():
         sys.modules.pop('build', None)
 
 
+def emu_rccl_library():
+    """The stand-in for librccl (tests/emu/rccl_emu.cpp), built next to the emulated library."""
+    return os.path.join(os.path.dirname(emu_library()), 'librccl_emu.so')
+
+
 def emu_core():
     global _CORE
     if _CORE is None:

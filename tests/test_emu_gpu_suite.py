@@ -64,3 +64,27 @@ def test_bench_line_end_to_end_against_the_emulated_library():
     pc = line['parity_check']
     assert pc['pass'] is True and pc['literal_bar_depth'] == pc['literal_bar_depth_of'] and len(pc['prefixes']) >= 8
     assert 'l2_rel_diff_per_gate' in pc and 'reference_vs_f64_leaves_bar_after' in pc
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('transport', ['p2p', 'rccl'])
+def test_multi_rank_gpu_tests_against_the_emulated_library(transport):
+    """The multi-rank `-m gpu` tests -- 2 and 4 ranks on the real HipBackend, the sharded simulate() / dm.simulate() API,
+    `bench.py --gpus 8` for both sharded workloads -- as real PROCESSES against the emulation, once per transport of the
+    library's own exchange (hq_exchange_*):
+      p2p   the pack kernel stores straight into the other ranks' planes, mapped through HIP IPC (emulated over POSIX
+            shared memory: tests/emu/hip_emu.cpp);
+      rccl  communicator from a unique id, grouped ncclSend / ncclRecv of one chunk per peer and plane around the pack
+            (tests/emu/rccl_emu.cpp stands in for librccl: unix sockets between the processes).
+    The tests assert the transport that ran, states against the oracle, and bit-identity with the host-staged path."""
+    env = dict(os.environ, HQ_EMU_GPU_SUITE='1', HQ_EMU_QUICK='0', HQ_SHARD_TRANSPORT=transport, PYTHONPATH=ROOT)
+    env.pop('HQ_HIP_LIBRARY', None)
+    env.pop('HQ_RCCL_LIBRARY', None)
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_dist.py'), '-m', 'gpu', '-q', '-p', 'no:cacheprovider',
+           '--timeout', '900', '-x']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=3600, cwd=ROOT)
+    tail = out.stdout[-3000:]
+    assert out.returncode == 0, tail + out.stderr[-2000:]
+    assert re.search(r'\b8 passed', tail), tail

@@ -26,7 +26,9 @@ def _free_port():
 
 
 EMU = os.environ.get('HQ_EMU_GPU_SUITE') == '1'  # host emulation: no HIP IPC, the exchange falls back to torch.distributed
-WANT_TRANSPORT = 'torch' if EMU else 'p2p'
+# 'p2p' on the device and under the emulation alike (HIP IPC is emulated over POSIX shared memory); the emulated run can also
+# force the RCCL transport (HQ_SHARD_TRANSPORT=rccl: tests/emu/rccl_emu.cpp stands in for librccl between the processes)
+WANT_TRANSPORT = os.environ.get('HQ_SHARD_TRANSPORT', 'p2p') if EMU else 'p2p'
 
 
 def _worker(rank, world, port, n, ct, out_dir):
