@@ -80,8 +80,21 @@ def _worker(rank, world, port, n, ct, out_dir):
         shb.run(schedb)
         psib = shb.state_numpy()
         nb = sum(1 for op in schedb if op[0] == 'B')
+        # exchange / compute overlap (round 4): exchanges in rounds of torch.distributed send / recv with the attached gates
+        # applied to the pieces by the REAL backend.  Needs point-to-point operations on device tensors: RCCL on a
+        # multi-GPU node, gloo on the emulated device; ranks sharing one real GPU over gloo cannot do it
+        n_xo, psi_o = -1, psi
+        if EMU or dist.get_backend() == 'nccl':
+            import hybridq_amd.dist as dist_mod
+            dist_mod.OVERLAP_MIN_SUB_QUBITS = 8
+            sho = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, overlap=True)
+            scho = sho.plan(gates)
+            n_xo = sum(1 for op in scho if op[0] == 'XO')
+            sho.run(scho)
+            psi_o = sho.state_numpy()
         if rank == 0:
             np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psib=psib, nb=nb, raw=raw, psi_h=psi_h, transport=transport,
+                     n_xo=n_xo, psi_o=psi_o,
                      n_x=sum(1 for op in sched if op[0] in ('X', 'XP')), n_p=sum(1 for op in sched if op[0] in ('P', 'XP')))
     finally:
         dist.destroy_process_group()
@@ -105,6 +118,10 @@ def test_sharded_hip_backend_two_ranks_one_gpu(torch_cuda, tmp_path, world, n, c
     expb = oracle.evolve_tensordot(rqc_1q2q(n + 2, depth=8, seed=13), n + 2)
     assert np.abs(out['psib'] - expb).max() / np.abs(expb).max() < 5 * tol
     assert int(out['nb']) >= 1  # blocked passes were really used
+    if int(out['n_xo']) >= 0:  # overlapped exchanges ran (the pieces may dispatch to other kernels than the whole shard: to rounding)
+        assert int(out['n_xo']) >= 1
+        assert np.abs(out['psi_o'] - exp).max() / np.abs(exp).max() < tol, np.abs(out['psi_o'] - exp).max() / np.abs(exp).max()
+        assert np.abs(out['psi_o'] - out['psi']).max() / np.abs(exp).max() < tol
 
 
 def test_exchange_one_rank_is_the_permutation(torch_cuda):
