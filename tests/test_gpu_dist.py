@@ -29,6 +29,8 @@ EMU = os.environ.get('HQ_EMU_GPU_SUITE') == '1'  # host emulation: no HIP IPC, t
 # 'p2p' on the device and under the emulation alike (HIP IPC is emulated over POSIX shared memory); the emulated run can also
 # force the RCCL transport (HQ_SHARD_TRANSPORT=rccl: tests/emu/rccl_emu.cpp stands in for librccl between the processes)
 WANT_TRANSPORT = os.environ.get('HQ_SHARD_TRANSPORT', 'p2p') if EMU else 'p2p'
+if EMU and os.environ.get('HQ_EMU_ASAN') == '1' and WANT_TRANSPORT == 'p2p':
+    WANT_TRANSPORT = 'torch'  # the sanitizer build keeps device memory on the (checked) heap: nothing to export through IPC
 
 
 def _worker(rank, world, port, n, ct, out_dir):
