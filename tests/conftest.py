@@ -48,7 +48,6 @@ def pytest_configure(config):
 #: -m gpu tests that cannot (or need not) run against the host emulation, with the reason; everything else does
 EMU_SKIP = (
     ('test_gpu_fullsize.py', 'BASELINE-size states (n = 30...) are hours of emulation'),
-    ('test_gpu_determinism.py', 'run-to-run determinism of the hardware; the emulation has tests/test_emu_kernels.py::test_wave_order'),
     ('c_abi_demo_without_python', 'a C program linked against the real HIP runtime'),
     ('c_abi_state_demo_without_python', 'a C program linked against the real HIP runtime'),
     ('many_tiles_per_workgroup[complex', 'n = 23...25: minutes of emulation per case'),
@@ -76,7 +75,7 @@ EMU_SLOW = ('apply_U_mfma_kernels', 'randomized_differential', 'apply_U_gemm_ker
             'evolution_hip_chooses', 'compiled_program', 'exchange_pack_one_pass', 'simulation_large_like_reference',
             'state_allocator_behind', 'restore_order_hip_backend', 'simulate_matches_reference_protocol',
             'permute_bits_many_moved_bits', 'initialize_state[', 'guard_bands', 'two_ranks_one_gpu', 'eight_ranks_sharing',
-            'sharded_api')
+            'sharded_api', 'test_gpu_determinism')
 
 
 def pytest_collection_modifyitems(config, items):

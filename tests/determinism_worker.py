@@ -6,7 +6,13 @@ import os
 import sys
 
 import numpy as np
-import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import emu_boot  # noqa: E402
+
+EMU = emu_boot.maybe_install()  # host emulation (HQ_EMU_GPU_SUITE=1): small states, few repetitions, RANDOM wave schedules --
+#                                 there a repetition that differs means a race, not a hardware hiccup
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +20,8 @@ from hybridq_amd import core  # noqa: E402
 from hybridq_amd.blocking import plan_blocked  # noqa: E402
 from hybridq_amd.circuits import haar_unitary, rqc_1q2q  # noqa: E402
 
-REPS = int(os.environ.get('HQ_DET_REPS', '30'))
+REPS = int(os.environ.get('HQ_DET_REPS', '3' if EMU else '30'))
+N32, N64 = (15, 14) if EMU else (22, 21)
 core.use_torch_stream()
 rng = np.random.default_rng(17)
 
@@ -38,7 +45,7 @@ def check(name, make_input, run):
     print(f'{name} {digest(first)}', flush=True)
 
 
-for ct, ft, n in (('complex64', torch.float32, 22), ('complex128', torch.float64, 21)):
+for ct, ft, n in (('complex64', torch.float32, N32), ('complex128', torch.float64, N64)):
     base = torch.from_numpy(rng.standard_normal((2, 1 << n))).to(ft).cuda()
     base /= base.norm()
 
