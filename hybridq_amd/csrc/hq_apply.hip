@@ -802,6 +802,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   for (unsigned b = 0; b < CB; ++b)
     if (tile_pos[b] != b) return fail("apply_blocked: the tile must contain the vector-component index bits (0,1 for f32; 0 for f64)");
   std::vector<BlockedGate> gates(n_gates);
+  std::vector<unsigned> touched(n_gates, 0u);  // tile-local positions a gate acts on
   std::vector<T> Atab;
   const T* Up = U_all;
   const unsigned* pp = pos_all;
@@ -812,6 +813,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     for (unsigned j = 0; j < k; ++j) {
       if (pp[j] >= 64 || local_of[pp[j]] < 0) return fail("apply_blocked: gate target outside the tile");
       lp[j] = (unsigned)local_of[pp[j]];
+      touched[g] |= 1u << lp[j];
     }
     if (check_positions(lp, tb, k)) return fail("apply_blocked: duplicate targets");
     // largest k that takes the register butterfly on the LDS tile (blocked_inner_gate_valu) instead
@@ -862,11 +864,16 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
                          (const void*)apply_blocked_kernel<double, 256, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false>,
                          (const void*)apply_blocked_kernel<float, 512, true, false>, (const void*)apply_blocked_kernel<double, 512, true, false>,
                          (const void*)apply_blocked_kernel<float, 512, true, true>, (const void*)apply_blocked_kernel<float, 512, false, true>,
-                         (const void*)apply_blocked_kernel<double, 512, true, true>};
+                         (const void*)apply_blocked_kernel<double, 512, true, true>,
+                         (const void*)apply_blocked_direct_kernel<float, 512>, (const void*)apply_blocked_direct_kernel<double, 512>};
     for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
+  // HQ_BLOCKED_GRID (a power of two) caps the resident workgroups: small states then walk several tiles per workgroup, which
+  // is how the tile loop of the prefetching kernels is exercised by tests without a 2^22-amplitude state
+  static int grid_cap = env_int("HQ_BLOCKED_GRID", 0);
+  unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
+  if (grid_cap > 0 && (grid_cap & (grid_cap - 1)) == 0) grid = std::min<unsigned>(grid, (unsigned)grid_cap);
   static int block_threads = env_int("HQ_BLOCKED_THREADS", 512);
   static int a_in_lds = env_int("HQ_BLOCKED_ALDS", 1);
   // LDS left per workgroup behind the tile when `per_cu` workgroups share a CU
@@ -879,6 +886,32 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
   static int use_pref = env_int("HQ_BLOCKED_PREF", 1);
   const bool pref = use_pref && block_threads != 256 && tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits);
+  // Tile movement folded into the first gate (apply_blocked_direct_kernel; opt-in until measured): the pass needs a
+  // k <= 3 matrix-core gate (KBITS = 4) whose register digits lie above tile-local vector bit 2 -- every wave-level HBM
+  // access of the gate's own addressing is then a set of whole 128-byte lines -- that may run first: the earliest such gate
+  // that shares no position with the gates in front of it is moved to the front (disjoint gates commute exactly).
+  static int use_direct = env_int("HQ_BLOCKED_DIRECT", 0);
+  bool direct = false;
+  if (use_direct && pref && n_gates >= 2 && a_in_lds &&
+      Atab.size() * sizeof(T) + tab_bytes + kBlockedGTabWords * sizeof(uint64_t) <= a_budget) {
+    auto eligible = [&](const BlockedGate& G) {
+      if (G.kv < 16 || G.kv > 19) return false;
+      const unsigned nr = 2u - (unsigned)__builtin_popcount(G.kv & 3u);
+      for (unsigned b = 0; b < nr; ++b)
+        if (G.ro.r_plane != (int)b && G.ro.r_off[b] < 8u) return false;
+      return true;
+    };
+    unsigned before = 0;
+    for (unsigned g = 0; g < n_gates; ++g) {
+      if (eligible(gates[g]) && !(touched[g] & before)) {
+        std::rotate(gates.begin(), gates.begin() + g, gates.begin() + g + 1);
+        std::rotate(touched.begin(), touched.begin() + g, touched.begin() + g + 1);
+        direct = true;
+        break;
+      }
+      before |= touched[g];
+    }
+  }
   unsigned n_barriers = n_gates;
   static int elide = env_int("HQ_BLOCKED_GROUPS", 1);
   if (fits && elide) {
@@ -924,8 +957,11 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     void *dG = nullptr, *dA = nullptr;
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
     if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
-    const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes;
-    if (pref) {
+    const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes + (direct ? kBlockedGTabWords * sizeof(uint64_t) : 0);
+    if (direct) {
+      HQ_LAUNCH(c, (apply_blocked_direct_kernel<T, 512>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
+                n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+    } else if (pref) {
       HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
                 n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
     } else {
@@ -949,7 +985,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   c.last_kernel = "blocked";
   c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
                 std::to_string(block_threads == 256 ? 256 : 512) + "> tb=" + std::to_string(tb) + " gates=" +
-                std::to_string(n_gates) + " barriers=" + std::to_string(n_barriers);
+                std::to_string(n_gates) + " barriers=" + std::to_string(n_barriers) + (direct ? " direct" : "");
   return 0;
 }
 

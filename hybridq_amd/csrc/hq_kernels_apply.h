@@ -556,6 +556,26 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
 typedef unsigned BlockedTabT;  // 16-bit entries were tried: more passes fit their tables, each gate 7 % slower
 constexpr unsigned kBlockedTabLane = 0, kBlockedTabIter = 64, kBlockedTabOff = 128, kBlockedTabWords = 136;
 
+// bits of (iteration << 4 | slot) -> the tile-local vector bits that are not address digits of a gate, in ascending
+// order; with `wmask` (BlockedGate::wave_bits) the three bits that number the waves (iteration bits 0..2) go to those
+// positions instead, so that every gate of a barrier-free group gives wave w the SAME part of the tile
+__device__ __forceinline__ unsigned blocked_digits(const MfmaRoles& ro) {
+  unsigned digits = 0;
+  for (int m = 0; m < 4; ++m)
+    if (ro.pos[m] < 31) digits |= 1u << ro.pos[m];
+  return digits;
+}
+__device__ __forceinline__ unsigned blocked_deposit(const unsigned v, const unsigned digits, const unsigned wmask,
+                                                    const unsigned tile_vec_bits) {
+  unsigned rest = ~(digits | wmask) & ((1u << tile_vec_bits) - 1), out = 0, b = 0;
+  if (wmask) {
+    for (int i = 0; i < 4 && rest; ++i, ++b) { out |= ((v >> b) & 1u) << __builtin_ctz(rest); rest &= rest - 1; }
+    for (unsigned w = wmask; w; w &= w - 1, ++b) out |= ((v >> b) & 1u) << __builtin_ctz(w);
+  }
+  for (; rest; rest &= rest - 1, ++b) out |= ((v >> b) & 1u) << __builtin_ctz(rest);
+  return out;
+}
+
 template <typename T, int BLOCK>
 __device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ tabs, const BlockedGate* __restrict__ gates,
                                                      const unsigned ngates, const unsigned tile_vec_bits,
@@ -567,21 +587,8 @@ __device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ t
   for (unsigned g = 0; g < ngates; ++g) {
     const MfmaRoles& ro = gates[g].ro;
     const unsigned wmask = gates[g].wave_bits & ~kBlockedNoBarrier;
-    unsigned digits = 0;
-    for (int m = 0; m < 4; ++m)
-      if (ro.pos[m] < 31) digits |= 1u << ro.pos[m];
-    // bits of (iteration << 4 | slot) -> the tile-local vector bits that are not address digits of this gate, in ascending
-    // order; with `wave_bits` the three bits that number the waves (iteration bits 0..2) go to those positions instead,
-    // so that every gate of a barrier-free group gives wave w the SAME part of the tile
-    auto deposit = [&](unsigned v) {
-      unsigned rest = ~(digits | wmask) & ((1u << tile_vec_bits) - 1), out = 0, b = 0;
-      if (wmask) {
-        for (int i = 0; i < 4 && rest; ++i, ++b) { out |= ((v >> b) & 1u) << __builtin_ctz(rest); rest &= rest - 1; }
-        for (unsigned w = wmask; w; w &= w - 1, ++b) out |= ((v >> b) & 1u) << __builtin_ctz(w);
-      }
-      for (; rest; rest &= rest - 1, ++b) out |= ((v >> b) & 1u) << __builtin_ctz(rest);
-      return out;
-    };
+    const unsigned digits = blocked_digits(ro);
+    auto deposit = [&](unsigned v) { return blocked_deposit(v, digits, wmask, tile_vec_bits); };
     BlockedTabT* tb = tabs + g * kBlockedTabWords;
     for (unsigned e = tid; e < kBlockedTabWords; e += BLOCK) {
       unsigned val;
@@ -748,6 +755,49 @@ __device__ __forceinline__ void blocked_inner_gate_valu(T* __restrict__ xr, T* _
   }
 }
 
+// One inner gate of a pass by its kind (G.kv: KBITS * 4 + VMASK for the matrix-core form, 64 + k * 4 + VMASK for the
+// register butterflies).
+template <typename T, int BLOCK, bool ALDS>
+__device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, const unsigned gi, T* __restrict__ xr,
+                                                      T* __restrict__ xi, const T* __restrict__ als,
+                                                      const T* __restrict__ Atab, const BlockedTabT* __restrict__ tabs,
+                                                      const unsigned tvb) {
+  constexpr unsigned CB = Vec<T>::VB;
+  const T* A = ALDS ? als + G.a_off : Atab + G.a_off;
+#define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
+  do {                                                                                                  \
+    if constexpr (ALDS)                                                                                 \
+      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * kBlockedTabWords, (1u << (tvb - G.n_addr)) >> 4);       \
+    else                                                                                                \
+      blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
+  } while (0)
+  switch (G.kv) {
+    case 16: HQ_BLOCKED_MFMA_GATE(4, 0); break;
+    case 17: HQ_BLOCKED_MFMA_GATE(4, 1); break;
+    case 20: HQ_BLOCKED_MFMA_GATE(5, 0); break;
+    case 21: HQ_BLOCKED_MFMA_GATE(5, 1); break;
+    case 64 + 4 + 0: blocked_inner_gate_valu<T, 1, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+    case 64 + 4 + 1: blocked_inner_gate_valu<T, 1, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+    case 64 + 8 + 0: blocked_inner_gate_valu<T, 2, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+    case 64 + 8 + 1: blocked_inner_gate_valu<T, 2, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+    default:
+      if constexpr (CB == 2) {
+        switch (G.kv) {
+          case 18: HQ_BLOCKED_MFMA_GATE(4, 2); break;
+          case 19: HQ_BLOCKED_MFMA_GATE(4, 3); break;
+          case 22: HQ_BLOCKED_MFMA_GATE(5, 2); break;
+          case 23: HQ_BLOCKED_MFMA_GATE(5, 3); break;
+          case 64 + 4 + 2: blocked_inner_gate_valu<T, 1, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+          case 64 + 8 + 2: blocked_inner_gate_valu<T, 2, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+          case 64 + 8 + 3: blocked_inner_gate_valu<T, 2, 3, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+          default: break;
+        }
+      }
+      break;
+  }
+#undef HQ_BLOCKED_MFMA_GATE
+}
+
 // ALDS: the A-operand tables of all gates of the pass (a_elems elements) are staged once per
 // (persistent) workgroup in LDS behind the tile; a table read from global memory puts an L2 round
 // trip (~1500 clk, as long as the gate's MFMAs) in front of every gate of every tile.
@@ -857,38 +907,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     __syncthreads();
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedGate& G = gates[gi];
-      const T* A = ALDS ? als + G.a_off : Atab + G.a_off;
-#define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
-  do {                                                                                                  \
-    if constexpr (ALDS)                                                                                 \
-      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * kBlockedTabWords, (1u << (tvb - G.n_addr)) >> 4);       \
-    else                                                                                                \
-      blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
-  } while (0)
-      switch (G.kv) {
-        case 16: HQ_BLOCKED_MFMA_GATE(4, 0); break;
-        case 17: HQ_BLOCKED_MFMA_GATE(4, 1); break;
-        case 20: HQ_BLOCKED_MFMA_GATE(5, 0); break;
-        case 21: HQ_BLOCKED_MFMA_GATE(5, 1); break;
-        case 64 + 4 + 0: blocked_inner_gate_valu<T, 1, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-        case 64 + 4 + 1: blocked_inner_gate_valu<T, 1, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-        case 64 + 8 + 0: blocked_inner_gate_valu<T, 2, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-        case 64 + 8 + 1: blocked_inner_gate_valu<T, 2, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-        default:
-          if constexpr (CB == 2) {
-            switch (G.kv) {
-              case 18: HQ_BLOCKED_MFMA_GATE(4, 2); break;
-              case 19: HQ_BLOCKED_MFMA_GATE(4, 3); break;
-              case 22: HQ_BLOCKED_MFMA_GATE(5, 2); break;
-              case 23: HQ_BLOCKED_MFMA_GATE(5, 3); break;
-              case 64 + 4 + 2: blocked_inner_gate_valu<T, 1, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-              case 64 + 8 + 2: blocked_inner_gate_valu<T, 2, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-              case 64 + 8 + 3: blocked_inner_gate_valu<T, 2, 3, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-              default: break;
-            }
-          }
-          break;
-      }
+      blocked_dispatch_gate<T, BLOCK, ALDS>(G, gi, xr, xi, als, Atab, tabs, tvb);
       // gates of one barrier-free group touch, wave by wave, the same part of the tile (same `wave_bits`): a wave only
       // needs its OWN stores to have landed (LDS operations of a wave complete in order; the gate ends with lgkmcnt(0))
       if (!(ALDS && (G.wave_bits & kBlockedNoBarrier))) __syncthreads();
@@ -924,6 +943,231 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
       base_cur = next_base(base);
       prefetch(tile + 2 * stride < ntiles ? next_base(base_cur) : base);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// apply_blocked_direct_kernel: the cache-blocked pass with the tile movement folded into its FIRST gate (round 4;
+// opt-in through HQ_BLOCKED_DIRECT until it has been measured).
+//
+// apply_blocked_kernel<.., PREF> moves a tile HBM -> registers -> LDS (fill), runs the gates LDS -> registers -> LDS and
+// streams it back LDS -> registers -> HBM (store phase): per tile that is two LDS passes, two workgroup barriers and a
+// BURST of 8 stores + 8 loads per lane issued into a memory system that is already saturated -- the waves stall at
+// issue and the matrix cores see only the other workgroup of the CU meanwhile (~1.3 ms of every 4.9 ms pass at
+// n = 30).  Here the first gate of the pass (a k <= 3 matrix-core gate: KBITS = 4) does the movement in ITS OWN
+// addressing:
+//   * the prefetch requests the next tile's vectors from HBM as that gate's B operands (lane (q, j), wave-iteration,
+//     register digit -> global address through two 64-bit tables built once per kernel: GLANE[lane] ^ GWAVE[wave][i]);
+//   * the gate multiplies straight from the prefetch registers and writes its results into the LDS tile -- no fill pass;
+//   * just before it overwrites a part of the LDS tile, the wave reads what is there -- the finished amplitudes of the
+//     PREVIOUS tile -- and stores them to HBM through the same tables: the stores trickle out between the gate's
+//     MFMA groups, wave by wave, instead of in one burst, and the store phase with its barrier is gone.
+// Every wave-level access stays a set of whole 128-byte lines (the host only takes a first gate whose register digits
+// lie above tile-local vector bit 2; q digits and slot bits fill the lines).  The other gates of the pass are the ones
+// of apply_blocked_kernel, barrier-free groups included; the last tile of a workgroup leaves through a linear store.
+// ---------------------------------------------------------------------------------
+constexpr unsigned kBlockedGTabLane = 0, kBlockedGTabWave = 64, kBlockedGTabWords = 128;  // 64-bit words
+constexpr uint64_t kBlockedPlaneBit = 1ull << 63;  // of a table entry: the vector lives in the imaginary plane
+
+template <typename T, int BLOCK>
+__device__ __forceinline__ void blocked_build_direct_tables(uint64_t* __restrict__ gt, const BlockedGate& G,
+                                                            const BlockedArg& ba, const unsigned tile_vec_bits) {
+  constexpr unsigned CB = Vec<T>::VB;
+  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
+  const MfmaRoles& ro = G.ro;
+  const unsigned digits = blocked_digits(ro), wmask = G.wave_bits & ~kBlockedNoBarrier;
+  const unsigned nr = 2u - (unsigned)__builtin_popcount(G.kv & 3u);  // register digits of a KBITS = 4 gate
+  auto vec_off = [&](unsigned e) {  // tile-local vector index -> global vector offset (OR-linear)
+    uint64_t g = 0;
+    for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+    return g;
+  };
+  for (unsigned e = threadIdx.x; e < kBlockedGTabWords; e += BLOCK) {
+    uint64_t val;
+    if (e < kBlockedGTabWave) {  // lane part: slot bits j, q digits, plane
+      const unsigned q = e >> 4, j = e & 15;
+      const unsigned lane_off = ((q & 1) ? ro.q_off[0] : 0u) | ((q & 2) ? ro.q_off[1] : 0u);
+      const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
+      val = vec_off(blocked_deposit(j, digits, wmask, tile_vec_bits) | lane_off) | (lane_plane ? kBlockedPlaneBit : 0ull);
+    } else {  // wave w, prefetch register i = (local iteration, register digit)
+      const unsigned w = (e - kBlockedGTabWave) >> 3, i = (e - kBlockedGTabWave) & 7;
+      const unsigned it = w + ((i >> nr) << WB), ld = i & ((1u << nr) - 1);
+      unsigned o = 0;
+      for (unsigned b = 0; b < nr; ++b)
+        if ((ld >> b) & 1) o |= ro.r_off[b];
+      const unsigned pl = ro.r_plane >= 0 ? ((ld >> ro.r_plane) & 1u) : 0u;
+      val = vec_off(blocked_deposit(it << 4, digits, wmask, tile_vec_bits) | o) | (pl ? kBlockedPlaneBit : 0ull);
+    }
+    gt[e] = val;
+  }
+}
+
+// The first gate of a direct pass: blocked_inner_gate_tab<T, 4, VMASK, BLOCK> with its B operands in `pf` and the
+// store-out of the previous tile in front of every overwrite.
+template <typename T, int VMASK, int BLOCK>
+__device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, const BlockedTabT* __restrict__ tab,
+                                                     const uint64_t* __restrict__ gt,
+                                                     typename Vec<T>::type (&pf)[8], const bool have_prev,
+                                                     const uint64_t base_prev,
+                                                     typename Vec<T>::type* __restrict__ vre,
+                                                     typename Vec<T>::type* __restrict__ vim) {
+  using V = typename Vec<T>::type;
+  using Acc = typename Mfma<T>::acc;
+  constexpr int KBITS = 4;
+  constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;
+  constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
+  constexpr int NCB = 1 << (CB - KV), NSTEP = 1 << NS, NITL = 8 / NL;
+  constexpr int FMASK = ~VMASK & (NCOMP - 1);
+  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  T a[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) a[s] = A[s * 64 + lane];
+  const unsigned L = tab[kBlockedTabLane + lane];
+  unsigned OFF[NL];
+#pragma unroll
+  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
+  const uint64_t gl = gt[kBlockedGTabLane + lane];
+  typedef __attribute__((address_space(3))) V LdsV;
+#pragma unroll
+  for (int itl = 0; itl < NITL; ++itl) {
+    const unsigned Lt = L ^ tab[kBlockedTabIter + wave + ((unsigned)itl << WB)];
+    unsigned addr[NL];
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) addr[ld] = Lt ^ OFF[ld];
+    if (have_prev) {  // uniform: the finished amplitudes of the previous tile leave from the slots this iteration overwrites
+      V t[NL];
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld) t[ld] = *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]);
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld) {
+        const uint64_t o = gl ^ gt[kBlockedGTabWave + wave * 8 + itl * NL + ld];
+        V* const p = (o & kBlockedPlaneBit) ? vim : vre;
+        __builtin_nontemporal_store(t[ld], p + (base_prev | (o & ~kBlockedPlaneBit)));
+      }
+    }
+    Acc acc[NCB];
+#pragma unroll
+    for (int cf = 0; cf < NCB; ++cf) acc[cf] = Acc{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const int ck = s & ((1 << KV) - 1), ld = s >> KV;
+#pragma unroll
+      for (int cf = 0; cf < NCB; ++cf) {
+        const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+        acc[cf] = Mfma<T>::run(a[s], pf[itl * NL + ld][comp], acc[cf]);
+      }
+    }
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) {
+      V y;
+#pragma unroll
+      for (int comp = 0; comp < NCOMP; ++comp) {
+        const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
+        const int so = ck | (ld << KV);
+        y[comp] = acc[cf][so & 3];
+      }
+      *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]) = y;
+    }
+  }
+  // the prefetch registers stay allocated to the end of the gate: were the store-out data of a later iteration to reuse
+  // them, the next prefetch (which overwrites them right after this gate) would have to wait for those stores to drain
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(pf[i]));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <typename T, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
+apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* __restrict__ gates,
+                            const unsigned ngates, const T* __restrict__ Atab, const unsigned a_elems,
+                            const BlockedArg ba, const uint64_t ntiles) {
+  using V = typename Vec<T>::type;
+  constexpr unsigned CB = Vec<T>::VB;
+  HQ_DYN_LDS(smem);
+  T* xr = reinterpret_cast<T*>(smem);
+  T* xi = xr + (1u << ba.tb);
+  T* als = xi + (1u << ba.tb);
+  const unsigned tid = threadIdx.x;
+  const unsigned tvb = ba.tb - CB, nvec = 1u << tvb;  // host: nvec == 4 * BLOCK
+  BlockedTabT* const tabs = reinterpret_cast<BlockedTabT*>(als + a_elems);
+  // host: the address tables end on a 16-byte boundary
+  uint64_t* const gt = reinterpret_cast<uint64_t*>(tabs + ((ngates * kBlockedTabWords + 3u) & ~3u));
+  for (unsigned i = tid; i < a_elems; i += BLOCK) als[i] = Atab[i];
+  blocked_build_tables<T, BLOCK>(tabs, gates, ngates, tvb, (unsigned)reinterpret_cast<uintptr_t>(xr));
+  blocked_build_direct_tables<T, BLOCK>(gt, gates[0], ba, tvb);
+  __syncthreads();
+  if (blockIdx.x >= ntiles) return;
+  V* __restrict__ vre = reinterpret_cast<V*>(re);
+  V* __restrict__ vim = reinterpret_cast<V*>(im);
+  auto tile_base = [&](uint64_t tile) {  // in 16-byte vector units: exactly 11 vector bits inside the tile
+    uint64_t base = tile;
+#pragma unroll
+    for (unsigned m = CB; m < CB + 11u; ++m) {
+      const uint64_t lo = (1ull << (ba.apos[m] - CB)) - 1;
+      base = ((base & ~lo) << 1) | (base & lo);
+    }
+    return base;
+  };
+  const unsigned lane = tid & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  V pf[8];
+  auto prefetch = [&](uint64_t b) {  // unconditional (see apply_blocked_kernel); b = tile_base(tile), wave-uniform
+    HQ_PIN_SGPR(b);
+    const uint64_t gl = gt[kBlockedGTabLane + lane];
+#pragma unroll
+    for (unsigned i = 0; i < 8; ++i) {
+      const uint64_t o = gl ^ gt[kBlockedGTabWave + wave * 8 + i];
+      const V* const p = (o & kBlockedPlaneBit) ? vim : vre;
+      pf[i] = __builtin_nontemporal_load(p + (b | (o & ~kBlockedPlaneBit)));
+    }
+  };
+  const uint64_t stride = gridDim.x;  // a power of two (host)
+  const uint64_t dep_mask = tile_base(~0ull), dep_stride = tile_base(stride);
+  auto next_base = [&](uint64_t b) { return ((b | ~dep_mask) + dep_stride) & dep_mask; };
+  const BlockedGate& G0 = gates[0];
+  const T* const A0 = als + G0.a_off;
+  uint64_t base = tile_base(blockIdx.x), base_prev = 0;
+  bool have_prev = false;
+  prefetch(base);
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += stride) {
+    // every wave is past the last gate of the previous tile here (that gate ends with a workgroup barrier)
+    // The prefetched operands were requested a whole tile ago: one wait for ALL of them, here and on every path, costs
+    // nothing -- and keeps the compiler from placing its own waits for the individual registers further down, behind the
+    // first gate's stores (vmcnt counts loads and stores in order: on the path without stores -- the first tile -- the wait
+    // for the last prefetched register is vmcnt(0), and merged over both paths that drained the eight stores just issued;
+    // a wait in front of the NEXT prefetch, for the old contents of its registers, would do the same).  A real S_WAITCNT
+    // (not inline assembly), so that the compiler's wait-count insertion sees the queue empty.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt, lgkmcnt untouched
+    switch (G0.kv) {
+      case 16: blocked_gate0_direct<T, 0, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim); break;
+      case 17: blocked_gate0_direct<T, 1, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim); break;
+      default:
+        if constexpr (CB == 2) {
+          if (G0.kv == 18) blocked_gate0_direct<T, 2, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim);
+          else blocked_gate0_direct<T, 3, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim);
+        }
+        break;
+    }
+    const uint64_t nb = next_base(base);
+    prefetch(tile + stride < ntiles ? nb : base);  // past the end: a repeat of this tile, never used
+    if (!(G0.wave_bits & kBlockedNoBarrier)) __syncthreads();
+    for (unsigned gi = 1; gi < ngates; ++gi) {
+      const BlockedGate& G = gates[gi];
+      blocked_dispatch_gate<T, BLOCK, true>(G, gi, xr, xi, als, Atab, tabs, tvb);
+      if (!(G.wave_bits & kBlockedNoBarrier)) __syncthreads();
+    }
+    base_prev = base;
+    have_prev = true;
+    base = nb;
+  }
+  // the last tile of this workgroup: linear store (16-byte vectors of contiguous runs)
+  for (unsigned e = tid; e < nvec; e += BLOCK) {
+    uint64_t g = base_prev;
+    for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
+    __builtin_nontemporal_store(reinterpret_cast<V*>(xr)[blocked_swz(e)], vre + g);
+    __builtin_nontemporal_store(reinterpret_cast<V*>(xi)[blocked_swz(e)], vim + g);
   }
 }
 

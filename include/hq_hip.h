@@ -22,7 +22,10 @@
  * HQ_PROGRAM_GRAPH (0: replay programs as a launch loop instead of a hipGraph);
  * measurement switches: HQ_GEMM_TB (tile bits of the k >= 7 kernel),
  * HQ_BLOCKED_THREADS (256|512), HQ_BLOCKED_ALDS (0: operand and address tables of
- * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_PREF,
+ * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_GROUPS
+ * (0: a workgroup barrier after every inner gate), HQ_BLOCKED_DIRECT (1: tile
+ * movement of a blocked pass folded into its first gate), HQ_BLOCKED_GRID (cap,
+ * a power of two, on the resident workgroups of a blocked pass), HQ_BLOCKED_PREF,
  * HQ_GEMM_PREF, HQ_SWAP_PREF (0: no register prefetch of the next tile in the
  * cache-blocked / k >= 7 / low-bit-swap kernels), HQ_BIG_PHASED, HQ_BIG_GRID (k = 5, 6
  * kernel), HQ_SWAP_TWO_PASS (0: one 128 KiB-tile pass or gather + copy for s > 13),

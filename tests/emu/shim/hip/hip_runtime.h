@@ -158,6 +158,7 @@ inline unsigned char* lds_at(unsigned a) { return reinterpret_cast<unsigned char
 #define __builtin_amdgcn_s_barrier() hq_emu::block_barrier()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) hq_emu::readfirstlane(x)
 #define __popcll(x) __builtin_popcountll(x)
 

@@ -104,6 +104,38 @@ def test_wave_order():
     assert blk and int(blk[0].rsplit('barriers', 1)[1]) < 7, blk
 
 
+def test_blocked_direct_pass():
+    """apply_blocked_direct_kernel (HQ_BLOCKED_DIRECT=1: the first gate of a pass multiplies straight from the prefetch
+    registers and streams the previous tile out of the LDS slots it is about to overwrite) against numpy and against the
+    staged kernel, several tiles per workgroup, under forward / greedy-reverse / random-burst wave schedules: the results
+    must not depend on the schedule (the only synchronisation between the last gate of one tile and the first gate of the
+    next is ONE workgroup barrier), and wherever the host did not have to move another gate to the front they are
+    bit-identical to the staged kernel's."""
+    def run(direct, order):
+        env = dict(os.environ, HQ_BLOCKED_DIRECT=direct, HQ_BLOCKED_GRID='2', HQ_EMU_ORDER=order, PYTHONPATH=ROOT)
+        env.pop('HQ_HIP_LIBRARY', None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu_direct_worker.py')], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return [ln.split() for ln in r.stdout.strip().splitlines()]
+    staged = run('0', 'forward')
+    direct = {o: run('1', o) for o in ('forward', 'reverse', 'random')}
+    assert len(staged) == 8 and not any('direct' in ln[1] for ln in staged)
+    n_direct = 0
+    for i, (case, desc, err, h) in enumerate(direct['forward']):
+        assert float(err) < (3e-6 if 'float32' in case else 1e-13), (case, desc, err)
+        assert float(staged[i][2]) < (3e-6 if 'float32' in case else 1e-13)
+        for o in ('reverse', 'random'):
+            assert direct[o][i][3] == h, (case, o)
+        if desc.endswith('direct'):
+            n_direct += 1
+            if case.endswith('_0') or case.endswith('_3'):  # the first gate was eligible where it stood: same arithmetic
+                assert h == staged[i][3], (case, desc)
+        else:
+            assert h == staged[i][3]
+    assert n_direct >= 5, direct['forward']
+
+
 def test_tuned_placement_allocator_on_emulated_granules():
     """hq_alloc_state's draw-and-probe search, the re-probe of the winner's granules in creation order (vmm_remap: the
     same physical granules mapped into a fresh range -- contents and usability must survive), the per-size pool and the

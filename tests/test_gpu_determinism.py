@@ -21,6 +21,7 @@ SETTINGS = [
     {'HQ_BIG_PHASED': '1', 'HQ_PERM_TB': '12', 'HQ_PERM_INPLACE_TB': '14'},
     {'HQ_PERM_TILE': '0'},  # round-2 paths: table-driven swap, two tile passes, gather kernels
     {'HQ_BLOCKED_GROUPS': '0'},  # round 4: a workgroup barrier after EVERY inner gate (default: barrier-free wave groups)
+    {'HQ_BLOCKED_DIRECT': '1', 'HQ_BLOCKED_GRID': '64'},  # round 4: tile movement folded into the first gate, 8 tiles per workgroup
 ]
 _seen = {}
 _blocked = {}

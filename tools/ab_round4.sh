@@ -14,9 +14,18 @@ for rep in 1 2; do
     echo "== rep $rep HQ_BLOCKED_GROUPS=$g"
     HQ_BLOCKED_GROUPS=$g python tools/ab_blocked.py 30 complex64 2>&1 | tail -3 | tee -a "$out/blocked_groups_$g.txt"
   done
+  # 1b. the tile movement folded into the first gate of a pass (apply_blocked_direct_kernel, opt-in: 24 of the 30 passes
+  #     of the benchmark plan are eligible), with and without the barrier-free groups
+  for g in 1 0; do
+    echo "== rep $rep HQ_BLOCKED_DIRECT=1 HQ_BLOCKED_GROUPS=$g"
+    HQ_BLOCKED_DIRECT=1 HQ_BLOCKED_GROUPS=$g python tools/ab_blocked.py 30 complex64 2>&1 | tail -3 | tee -a "$out/blocked_direct_groups_$g.txt"
+  done
 done
+python -m pytest -q -m gpu tests/test_gpu_round4.py -s 2>&1 | tail -8 | tee "$out/direct_parity.txt"
 python -m pytest -q -m gpu tests/test_gpu_determinism.py 2>&1 | tail -5 | tee "$out/determinism.txt"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/prof" -- python "$OLDPWD/tools/ab_blocked.py" 30 complex64 > "$OLDPWD/$out/prof.log" 2>&1
+HQ_BLOCKED_DIRECT=1 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/prof_direct" -- python "$OLDPWD/tools/ab_blocked.py" 30 complex64 > "$OLDPWD/$out/prof_direct.log" 2>&1
 cd "$OLDPWD"
 python profiles/extract_stats.py "$out/prof" 2>/dev/null | head -20 | tee "$out/kernel_stats_head.txt"
+python profiles/extract_stats.py "$out/prof_direct" 2>/dev/null | head -20 | tee "$out/kernel_stats_direct_head.txt"

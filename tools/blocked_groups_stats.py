@@ -2,7 +2,9 @@
 No GPU needed: every pass of the n = 30 plan is replayed on a one-tile state (its tile bits renumbered 0..12) through the
 host EMULATION of the library (tests/emu), whose apply_blocked entry reports `barriers=` in last_kernel_desc -- the
 grouping itself is host code of the product (hq_apply.hip).
-    python tools/blocked_groups_stats.py [n] [depth]"""
+    python tools/blocked_groups_stats.py [n] [depth]
+With HQ_BLOCKED_DIRECT=1 in the environment the same replay also counts the passes that take apply_blocked_direct_kernel
+(a k <= 3 matrix-core gate that may run first and whose register digits lie above tile-local vector bit 2)."""
 import os
 import sys
 
@@ -21,7 +23,7 @@ gates = rqc_1q2q(n, depth=depth, seed=n)
 ops = plan_blocked(gates, {q: n - 1 - q for q in range(n)}, n)
 tb = 13
 re, im, free = emu_util.device_planes(core, tb, np.float32)
-tot_g = tot_b = passes = 0
+tot_g = tot_b = passes = n_direct = 0
 hist = {}
 for op in ops:
     if op[0] != 'B':
@@ -37,8 +39,11 @@ for op in ops:
     tot_g += g
     tot_b += b
     passes += 1
+    n_direct += core.last_kernel_desc().endswith('direct')
     hist[(g, b)] = hist.get((g, b), 0) + 1
 free()
 print(f'n = {n}, depth {depth}: {passes} blocked passes, {tot_g} inner gates, {tot_b} workgroup barriers after gates '
       f'({tot_g - tot_b} removed = {100.0 * (tot_g - tot_b) / max(1, tot_g):.0f} %)')
 print('  (gates, barriers) per pass:', dict(sorted(hist.items())))
+if os.environ.get('HQ_BLOCKED_DIRECT') == '1':
+    print(f'  passes with the tile movement folded into their first gate (HQ_BLOCKED_DIRECT=1): {n_direct} of {passes}')
