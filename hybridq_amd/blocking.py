@@ -35,9 +35,20 @@ INNER_COST = {1: 1.0, 2: 1.0, 3: 1.0, 4: 1.9}
 LDS_TABLE_BUDGET = 15 * 1024
 
 
-def lds_bytes(gate_list, complex_type='complex64'):
+def _big_tile(tile_bits, complex_type):
+    """128 KiB tiles (2^14 complex64 / 2^13 complex128 amplitudes): one 1024-thread workgroup per CU (HQ_BLOCKED_BIG=1),
+    800-byte address tables per gate, 31 KiB of LDS beside the tile."""
+    return tile_bits is not None and (2 << tile_bits) * (4 if np.dtype(complex_type) == np.dtype('complex64') else 8) == 128 * 1024
+
+
+def lds_bytes(gate_list, complex_type='complex64', tile_bits=None):
     elem = 4 if np.dtype(complex_type) == np.dtype('complex64') else 8
-    return sum({1: 0, 2: 256, 3: 256, 4: 1024}[len(qs)] * elem + 544 for _, qs in gate_list)
+    tab = 800 if _big_tile(tile_bits, complex_type) else 544
+    return sum({1: 0, 2: 256, 3: 256, 4: 1024}[len(qs)] * elem + tab for _, qs in gate_list)
+
+
+def lds_budget(tile_bits, complex_type='complex64'):
+    return 31 * 1024 if _big_tile(tile_bits, complex_type) else LDS_TABLE_BUDGET
 
 
 def _dry_layers(qsets, kmax):
@@ -223,7 +234,7 @@ def plan_blocked(gates, pos_of, n, tile_bits=13, low_bits=5, inner_max='auto', m
 
             def cost(gl):  # a pass whose operand + address tables overflow the LDS left beside the tile runs the
                 c = sum(INNER_COST[len(qs)] for _, qs in gl)  # slower global-memory variant of every gate
-                return c * (1.0 if lds_bytes(gl, complex_type) <= LDS_TABLE_BUDGET else 1.25)
+                return c * (1.0 if lds_bytes(gl, complex_type, tile_bits) <= lds_budget(tile_bits, complex_type) else 1.25)
             if cost(wider) < cost(inner):
                 inner = wider
         elif inner_max:

@@ -865,7 +865,9 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
                          (const void*)apply_blocked_kernel<float, 512, true, false>, (const void*)apply_blocked_kernel<double, 512, true, false>,
                          (const void*)apply_blocked_kernel<float, 512, true, true>, (const void*)apply_blocked_kernel<float, 512, false, true>,
                          (const void*)apply_blocked_kernel<double, 512, true, true>,
-                         (const void*)apply_blocked_direct_kernel<float, 512>, (const void*)apply_blocked_direct_kernel<double, 512>};
+                         (const void*)apply_blocked_direct_kernel<float, 512>, (const void*)apply_blocked_direct_kernel<double, 512>,
+                         (const void*)apply_blocked_kernel<float, 1024, true, true>, (const void*)apply_blocked_kernel<double, 1024, true, true>,
+                         (const void*)apply_blocked_direct_kernel<float, 1024>, (const void*)apply_blocked_direct_kernel<double, 1024>};
     for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -880,12 +882,21 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   const size_t a_budget = (160 * 1024) / per_cu - tile_bytes > 2048 ? (160 * 1024) / per_cu - tile_bytes - 1024 : 0;
   // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
   // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
-  const size_t tab_bytes = (((size_t)n_gates * kBlockedTabWords * sizeof(BlockedTabT)) + 15) & ~(size_t)15;  // per-gate address tables (built in-kernel)
+  // HQ_BLOCKED_BIG=1 (opt-in until measured): tiles of 2^14 (f32) / 2^13 (f64) amplitudes = 128 KiB, ONE workgroup of
+  // 1024 threads per CU (16 waves: the same four per SIMD as two 512-thread workgroups) with the register prefetch, the
+  // barrier-free groups (four wave bits) and the direct first gate -- 25 instead of 28 passes on the n = 30 benchmark plan
+  static int use_big = env_int("HQ_BLOCKED_BIG", 0);
+  static int use_pref = env_int("HQ_BLOCKED_PREF", 1);
+  auto table_bytes = [&](unsigned words) { return (((size_t)n_gates * words * sizeof(BlockedTabT)) + 15) & ~(size_t)15; };
+  // all or nothing: the 1024-thread kernel exists only with the tables in LDS and the register prefetch
+  const bool big = use_big && use_pref && block_threads != 256 && a_in_lds && tb == (sizeof(T) == 4 ? 14u : 13u) &&
+                   Atab.size() * sizeof(T) + table_bytes(BlockedTab<1024>::kWords) <= a_budget;
+  const unsigned wave_bits_n = big ? 4u : 3u;
+  const size_t tab_bytes = table_bytes(big ? BlockedTab<1024>::kWords : BlockedTab<512>::kWords);  // per-gate address tables (built in-kernel)
   const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
   // register prefetch of the next tile (512 threads, 4 vectors per thread and plane = 13 (f32) / 12 (f64) tile bits;
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
-  static int use_pref = env_int("HQ_BLOCKED_PREF", 1);
-  const bool pref = use_pref && block_threads != 256 && tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits);
+  const bool pref = use_pref && block_threads != 256 && ((tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits)) || big);
   // Tile movement folded into the first gate (apply_blocked_direct_kernel; opt-in until measured): the pass needs a
   // k <= 3 matrix-core gate (KBITS = 4) whose register digits lie above tile-local vector bit 2 -- every wave-level HBM
   // access of the gate's own addressing is then a set of whole 128-byte lines -- that may run first: the earliest such gate
@@ -893,7 +904,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   static int use_direct = env_int("HQ_BLOCKED_DIRECT", 0);
   bool direct = false;
   if (use_direct && pref && n_gates >= 2 && a_in_lds &&
-      Atab.size() * sizeof(T) + tab_bytes + kBlockedGTabWords * sizeof(uint64_t) <= a_budget) {
+      Atab.size() * sizeof(T) + tab_bytes + blocked_gtab_words<1024>() * sizeof(uint64_t) <= a_budget) {
     auto eligible = [&](const BlockedGate& G) {
       if (G.kv < 16 || G.kv > 19) return false;
       const unsigned nr = 2u - (unsigned)__builtin_popcount(G.kv & 3u);
@@ -922,12 +933,12 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     // than 8 wave-iterations keep their barriers.
     const unsigned tvb = tb - CB, all = (1u << tvb) - 1;
     auto free_bits = [&](const BlockedGate& G) -> unsigned {
-      if (G.kv >= 64 || ((1u << (tvb - G.n_addr)) >> 4) < 8) return 0;
+      if (G.kv >= 64 || ((1u << (tvb - G.n_addr)) >> 4) < (1u << wave_bits_n)) return 0;
       unsigned d = 0;
       for (int m = 0; m < 4; ++m)
         if (G.ro.pos[m] < 31) d |= 1u << G.ro.pos[m];
       const unsigned f = all & ~d;
-      return __builtin_popcount(f) >= 7 ? f : 0;  // 4 slot bits + 3 wave bits
+      return (unsigned)__builtin_popcount(f) >= 4 + wave_bits_n ? f : 0;  // 4 slot bits + the wave bits
     };
     unsigned g0 = 0;
     while (g0 < n_gates) {
@@ -935,14 +946,14 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
       if (common) {
         while (g1 < n_gates) {
           const unsigned f = free_bits(gates[g1]);
-          if (!f || __builtin_popcount(common & f) < 3) break;
+          if (!f || (unsigned)__builtin_popcount(common & f) < wave_bits_n) break;
           common &= f;
           ++g1;
         }
       }
       if (g1 - g0 >= 2) {
         unsigned w = 0, rest = common;
-        for (int i = 0; i < 3; ++i) {  // the three HIGHEST common bits: the slot bits stay the lowest free ones (bank behaviour)
+        for (unsigned i = 0; i < wave_bits_n; ++i) {  // the HIGHEST common bits: the slot bits stay the lowest free ones (bank behaviour)
           const unsigned top = 31 - (unsigned)__builtin_clz(rest);
           w |= 1u << top;
           rest &= ~(1u << top);
@@ -957,8 +968,15 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     void *dG = nullptr, *dA = nullptr;
     if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
     if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
-    const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes + (direct ? kBlockedGTabWords * sizeof(uint64_t) : 0);
-    if (direct) {
+    const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes + (direct ? blocked_gtab_words<1024>() * sizeof(uint64_t) : 0);
+    if (big) {
+      if (direct)
+        HQ_LAUNCH(c, (apply_blocked_direct_kernel<T, 1024>), dim3(grid), dim3(1024), lds, re, im, (const BlockedGate*)dG,
+                  n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+      else
+        HQ_LAUNCH(c, (apply_blocked_kernel<T, 1024, true, true>), dim3(grid), dim3(1024), lds, re, im, (const BlockedGate*)dG,
+                  n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+    } else if (direct) {
       HQ_LAUNCH(c, (apply_blocked_direct_kernel<T, 512>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
                 n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
     } else if (pref) {
@@ -984,7 +1002,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   HQ_HIP_CHECK(hipGetLastError());
   c.last_kernel = "blocked";
   c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
-                std::to_string(block_threads == 256 ? 256 : 512) + "> tb=" + std::to_string(tb) + " gates=" +
+                std::to_string(block_threads == 256 ? 256 : (big ? 1024 : 512)) + "> tb=" + std::to_string(tb) + " gates=" +
                 std::to_string(n_gates) + " barriers=" + std::to_string(n_barriers) + (direct ? " direct" : "");
   return 0;
 }

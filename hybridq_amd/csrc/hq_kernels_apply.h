@@ -554,7 +554,12 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
 // ONCE per kernel: address(lane, iteration it, register digit ld) = LANE[lane] ^ ITER[it] ^ OFF[ld] (see the XOR
 // argument in blocked_inner_gate), one ds_read_b32 + one v_xor3 per vector.
 typedef unsigned BlockedTabT;  // 16-bit entries were tried: more passes fit their tables, each gate 7 % slower
-constexpr unsigned kBlockedTabLane = 0, kBlockedTabIter = 64, kBlockedTabOff = 128, kBlockedTabWords = 136;
+// Layout of a gate's table: LANE[64], ITER[number of wave-iterations a gate can have: 64 for tiles of 2^11 vectors, 128 for
+// the 2^12-vector tiles of the 1024-thread kernels], OFF[8].
+template <int BLOCK> struct BlockedTab {
+  static constexpr unsigned kLane = 0, kIter = 64, kNIter = BLOCK == 1024 ? 128 : 64, kOff = kIter + kNIter, kWords = kOff + 8;
+};
+constexpr unsigned kBlockedTabWords = BlockedTab<512>::kWords;
 
 // bits of (iteration << 4 | slot) -> the tile-local vector bits that are not address digits of a gate, in ascending
 // order; with `wmask` (BlockedGate::wave_bits) the three bits that number the waves (iteration bits 0..2) go to those
@@ -589,18 +594,18 @@ __device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ t
     const unsigned wmask = gates[g].wave_bits & ~kBlockedNoBarrier;
     const unsigned digits = blocked_digits(ro);
     auto deposit = [&](unsigned v) { return blocked_deposit(v, digits, wmask, tile_vec_bits); };
-    BlockedTabT* tb = tabs + g * kBlockedTabWords;
-    for (unsigned e = tid; e < kBlockedTabWords; e += BLOCK) {
+    BlockedTabT* tb = tabs + g * BlockedTab<BLOCK>::kWords;
+    for (unsigned e = tid; e < BlockedTab<BLOCK>::kWords; e += BLOCK) {
       unsigned val;
-      if (e < kBlockedTabIter) {  // lane part: slot bits j, q digits, plane
+      if (e < BlockedTab<BLOCK>::kIter) {  // lane part: slot bits j, q digits, plane
         const unsigned q = e >> 4, j = e & 15;
         const unsigned lane_off = ((q & 1) ? ro.q_off[0] : 0u) | ((q & 2) ? ro.q_off[1] : 0u);
         const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
         val = ((blocked_swz(deposit(j) | lane_off) | (lane_plane << tile_vec_bits)) << 4) | lds_base;
-      } else if (e < kBlockedTabOff) {  // wave-iteration part
-        val = blocked_swz(deposit((e - kBlockedTabIter) << 4)) << 4;
+      } else if (e < BlockedTab<BLOCK>::kOff) {  // wave-iteration part
+        val = blocked_swz(deposit((e - BlockedTab<BLOCK>::kIter) << 4)) << 4;
       } else {  // register-digit part
-        const unsigned ld = e - kBlockedTabOff;
+        const unsigned ld = e - BlockedTab<BLOCK>::kOff;
         unsigned o = 0;
         for (int b = 0; b < 3; ++b)
           if ((ld >> b) & 1) o |= ro.r_off[b];
@@ -631,12 +636,12 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
   for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
-  L = tab[kBlockedTabLane + lane];
+  L = tab[BlockedTab<BLOCK>::kLane + lane];
 #pragma unroll
-  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
+  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[BlockedTab<BLOCK>::kOff + ld];
   typedef __attribute__((address_space(3))) V LdsV;  // addresses are absolute LDS byte addresses (base folded in LANE)
   for (unsigned it = wave; it < niter; it += 1u << WB) {
-    const unsigned Lt = L ^ tab[kBlockedTabIter + it];
+    const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + it];
     unsigned addr[NL];
     V x[NL];
 #pragma unroll
@@ -767,7 +772,7 @@ __device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, cons
 #define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
   do {                                                                                                  \
     if constexpr (ALDS)                                                                                 \
-      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * kBlockedTabWords, (1u << (tvb - G.n_addr)) >> 4);       \
+      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * BlockedTab<BLOCK>::kWords, (1u << (tvb - G.n_addr)) >> 4);       \
     else                                                                                                \
       blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
   } while (0)
@@ -834,7 +839,7 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
   auto tile_base = [&](uint64_t tile) {
     uint64_t base = tile;  // in 16-byte vector units: tile positions minus the component bits
 #pragma unroll
-    for (unsigned m = CB; m < (PREF ? CB + 11u : (unsigned)kBlockedMaxTileBits); ++m) {  // PREF: exactly 4 * 512 vectors
+    for (unsigned m = CB; m < (PREF ? CB + (BLOCK == 1024 ? 12u : 11u) : (unsigned)kBlockedMaxTileBits); ++m) {  // PREF: exactly 4 * BLOCK vectors
       const uint64_t lo = (PREF || m < ba.tb) ? (1ull << (ba.apos[m] - CB)) - 1 : ~0ull;  // ~0: no-op
       base = ((base & ~lo) << 1) | (base & lo);
     }
@@ -966,7 +971,9 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 // lie above tile-local vector bit 2; q digits and slot bits fill the lines).  The other gates of the pass are the ones
 // of apply_blocked_kernel, barrier-free groups included; the last tile of a workgroup leaves through a linear store.
 // ---------------------------------------------------------------------------------
-constexpr unsigned kBlockedGTabLane = 0, kBlockedGTabWave = 64, kBlockedGTabWords = 128;  // 64-bit words
+constexpr unsigned kBlockedGTabLane = 0, kBlockedGTabWave = 64;  // 64-bit words: GLANE[64], GWAVE[waves][8]
+template <int BLOCK> constexpr unsigned blocked_gtab_words() { return kBlockedGTabWave + (BLOCK / 64) * 8; }
+constexpr unsigned kBlockedGTabWords = blocked_gtab_words<512>();
 constexpr uint64_t kBlockedPlaneBit = 1ull << 63;  // of a table entry: the vector lives in the imaginary plane
 
 template <typename T, int BLOCK>
@@ -982,7 +989,7 @@ __device__ __forceinline__ void blocked_build_direct_tables(uint64_t* __restrict
     for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
     return g;
   };
-  for (unsigned e = threadIdx.x; e < kBlockedGTabWords; e += BLOCK) {
+  for (unsigned e = threadIdx.x; e < blocked_gtab_words<BLOCK>(); e += BLOCK) {
     uint64_t val;
     if (e < kBlockedGTabWave) {  // lane part: slot bits j, q digits, plane
       const unsigned q = e >> 4, j = e & 15;
@@ -1024,15 +1031,15 @@ __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, co
   T a[NSTEP];
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) a[s] = A[s * 64 + lane];
-  const unsigned L = tab[kBlockedTabLane + lane];
+  const unsigned L = tab[BlockedTab<BLOCK>::kLane + lane];
   unsigned OFF[NL];
 #pragma unroll
-  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[kBlockedTabOff + ld];
+  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[BlockedTab<BLOCK>::kOff + ld];
   const uint64_t gl = gt[kBlockedGTabLane + lane];
   typedef __attribute__((address_space(3))) V LdsV;
 #pragma unroll
   for (int itl = 0; itl < NITL; ++itl) {
-    const unsigned Lt = L ^ tab[kBlockedTabIter + wave + ((unsigned)itl << WB)];
+    const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + wave + ((unsigned)itl << WB)];
     unsigned addr[NL];
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) addr[ld] = Lt ^ OFF[ld];
@@ -1093,7 +1100,7 @@ apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const Blocke
   const unsigned tvb = ba.tb - CB, nvec = 1u << tvb;  // host: nvec == 4 * BLOCK
   BlockedTabT* const tabs = reinterpret_cast<BlockedTabT*>(als + a_elems);
   // host: the address tables end on a 16-byte boundary
-  uint64_t* const gt = reinterpret_cast<uint64_t*>(tabs + ((ngates * kBlockedTabWords + 3u) & ~3u));
+  uint64_t* const gt = reinterpret_cast<uint64_t*>(tabs + ((ngates * BlockedTab<BLOCK>::kWords + 3u) & ~3u));
   for (unsigned i = tid; i < a_elems; i += BLOCK) als[i] = Atab[i];
   blocked_build_tables<T, BLOCK>(tabs, gates, ngates, tvb, (unsigned)reinterpret_cast<uintptr_t>(xr));
   blocked_build_direct_tables<T, BLOCK>(gt, gates[0], ba, tvb);
@@ -1101,10 +1108,10 @@ apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const Blocke
   if (blockIdx.x >= ntiles) return;
   V* __restrict__ vre = reinterpret_cast<V*>(re);
   V* __restrict__ vim = reinterpret_cast<V*>(im);
-  auto tile_base = [&](uint64_t tile) {  // in 16-byte vector units: exactly 11 vector bits inside the tile
+  auto tile_base = [&](uint64_t tile) {  // in 16-byte vector units: exactly log2(4 * BLOCK) vector bits inside the tile
     uint64_t base = tile;
 #pragma unroll
-    for (unsigned m = CB; m < CB + 11u; ++m) {
+    for (unsigned m = CB; m < CB + (BLOCK == 1024 ? 12u : 11u); ++m) {
       const uint64_t lo = (1ull << (ba.apos[m] - CB)) - 1;
       base = ((base & ~lo) << 1) | (base & lo);
     }

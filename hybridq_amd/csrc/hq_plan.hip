@@ -272,14 +272,19 @@ struct Options {
   double tol;
 };
 
-static size_t lds_bytes(const std::vector<Layer>& gl, unsigned elem) {
+// LDS a pass's operand and address tables need, and what is left beside the tile (hq_apply.hip: a_budget).  128 KiB
+// tiles (2^14 complex64 / 2^13 complex128 amplitudes: one 1024-thread workgroup per CU) have 128 wave-iterations per
+// gate instead of 64 in their address tables and 31 KiB instead of 15 KiB beside them.
+static bool big_tile(const Options& o) { return ((size_t)2 << o.tile_bits) * o.elem_bytes == 128 * 1024; }
+static size_t lds_bytes(const std::vector<Layer>& gl, const Options& o) {
   size_t b = 0;
   for (const auto& L : gl) {
     static const size_t a_elems[5] = {0, 0, 256, 256, 1024};
-    b += a_elems[std::min<size_t>(L.q.size(), 4)] * elem + 544;
+    b += a_elems[std::min<size_t>(L.q.size(), 4)] * o.elem_bytes + (big_tile(o) ? 800 : 544);
   }
   return b;
 }
+static size_t lds_budget(const Options& o) { return (big_tile(o) ? 31 : 15) * 1024; }
 
 static void plan_blocked(const std::vector<Gate>& gates, const Options& o, Result& out) {
   const size_t G = gates.size();
@@ -392,7 +397,7 @@ static void plan_blocked(const std::vector<Gate>& gates, const Options& o, Resul
     auto cost = [&](const std::vector<Layer>& gl) {
       double c = 0;
       for (const auto& L : gl) c += inner_cost((unsigned)L.q.size());
-      return c * (lds_bytes(gl, o.elem_bytes) <= 15 * 1024 ? 1.0 : 1.25);
+      return c * (lds_bytes(gl, o) <= lds_budget(o) ? 1.0 : 1.25);
     };
     auto widen = [&](const std::vector<Layer>& in, unsigned kmax) {
       std::vector<Gate> tmp;

@@ -31,7 +31,7 @@ def rand_u(k, ct, rng):
 CASES = [(3, 3, 2, 4, 3), (4, 2, 3, 3), (1, 3, 3), (3, 3)]
 for ft in (np.float32, np.float64):
     ct = np.complex64 if ft == np.float32 else np.complex128
-    tb = 13 if ft == np.float32 else 12
+    tb = (13 if ft == np.float32 else 12) + (os.environ.get('HQ_BLOCKED_BIG') == '1')  # BIG: 128 KiB tiles, 1024 threads
     n = tb + 4  # 16 tiles
     re, im, free = emu_util.device_planes(core, n, ft)
     for case, ks in enumerate(CASES):

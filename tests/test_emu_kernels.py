@@ -111,8 +111,8 @@ def test_blocked_direct_pass():
     must not depend on the schedule (the only synchronisation between the last gate of one tile and the first gate of the
     next is ONE workgroup barrier), and wherever the host did not have to move another gate to the front they are
     bit-identical to the staged kernel's."""
-    def run(direct, order):
-        env = dict(os.environ, HQ_BLOCKED_DIRECT=direct, HQ_BLOCKED_GRID='2', HQ_EMU_ORDER=order, PYTHONPATH=ROOT)
+    def run(direct, order, big='0'):
+        env = dict(os.environ, HQ_BLOCKED_DIRECT=direct, HQ_BLOCKED_BIG=big, HQ_BLOCKED_GRID='2', HQ_EMU_ORDER=order, PYTHONPATH=ROOT)
         env.pop('HQ_HIP_LIBRARY', None)
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu_direct_worker.py')], env=env, capture_output=True,
                            text=True, timeout=900)
@@ -134,6 +134,16 @@ def test_blocked_direct_pass():
         else:
             assert h == staged[i][3]
     assert n_direct >= 5, direct['forward']
+    # HQ_BLOCKED_BIG=1: 128 KiB tiles (2^14 / 2^13 amplitudes), one 1024-thread workgroup, four wave bits -- staged and
+    # direct, forward and random schedules; the plain 512-thread kernel (no prefetch at this tile size) is the reference
+    plain = run('0', 'forward', big='0')
+    for d in ('0', '1'):
+        got = {o: run(d, o, big='1') for o in ('forward', 'random')}
+        assert all('1024' in ln[1] for ln in got['forward']), got['forward']
+        assert sum(ln[1].endswith('direct') for ln in got['forward']) >= (5 if d == '1' else 0)
+        for i, (case, desc, err, h) in enumerate(got['forward']):
+            assert float(err) < (3e-6 if 'float32' in case else 1e-13), (case, desc, err)
+            assert got['random'][i][3] == h, (case, desc)
 
 
 def test_tuned_placement_allocator_on_emulated_granules():

@@ -1,4 +1,5 @@
-"""A/B of the cache-blocked schedule of the n = 30 benchmark circuit (HQ_HIP_LIBRARY selects the build)."""
+"""A/B of the cache-blocked schedule of the n = 30 benchmark circuit (HQ_HIP_LIBRARY selects the build).
+    python tools/ab_blocked.py [n] [complex64|complex128] [tile bits: 13 / 12 by default; 14 / 13 with HQ_BLOCKED_BIG=1 = 128 KiB tiles]"""
 import os
 import sys
 import time
@@ -15,11 +16,11 @@ from hybridq_amd.simulation import EvolutionState  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 ctype = sys.argv[2] if len(sys.argv) > 2 else 'complex64'
-tb = 13 if ctype == 'complex64' else 12
+tb = int(sys.argv[3]) if len(sys.argv) > 3 else (13 if ctype == 'complex64' else 12)
 gates = rqc_1q2q(n, depth=40, seed=n)
 state = EvolutionState(list(range(n)), complex_type=ctype, initial_state='0' * n)
 for kw in (dict(), dict(inner_max=0)):
-    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=tb - 8, complex_type=ctype), **kw})
+    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=5 if ctype == 'complex64' else 4, complex_type=ctype), **kw})
     packed = [('B', op[1], core.pack_blocked(op[2], ctype)) if op[0] == 'B' else op for op in ops]
 
     def run():
@@ -37,5 +38,5 @@ for kw in (dict(), dict(inner_max=0)):
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     st = blocked_stats(ops)
-    print(os.path.basename(os.environ.get('HQ_HIP_LIBRARY', 'in-tree')), kw, f"passes {st['blocked_passes']} + {st['plain_gates']} plain, inner {st['inner_gates']}:",
+    print(os.path.basename(os.environ.get('HQ_HIP_LIBRARY', 'in-tree')), f'tb={tb}', core.last_kernel_desc().split('>')[0].split('<')[-1], kw, f"passes {st['blocked_passes']} + {st['plain_gates']} plain, inner {st['inner_gates']}:",
           ' '.join('%.1f' % t for t in ts), 'ms', flush=True)

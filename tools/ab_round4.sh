@@ -21,6 +21,13 @@ for rep in 1 2; do
     HQ_BLOCKED_DIRECT=1 HQ_BLOCKED_GROUPS=$g python tools/ab_blocked.py 30 complex64 2>&1 | tail -3 | tee -a "$out/blocked_direct_groups_$g.txt"
   done
 done
+# 1c. 128 KiB tiles (2^14 amplitudes, one 1024-thread workgroup per CU, HQ_BLOCKED_BIG=1: 25 instead of 28 passes), staged and direct
+for rep in 1 2; do
+  for d in 0 1; do
+    echo "== rep $rep HQ_BLOCKED_BIG=1 HQ_BLOCKED_DIRECT=$d tile bits 14"
+    HQ_BLOCKED_BIG=1 HQ_BLOCKED_DIRECT=$d python tools/ab_blocked.py 30 complex64 14 2>&1 | tail -3 | tee -a "$out/blocked_big_direct_$d.txt"
+  done
+done
 python -m pytest -q -m gpu tests/test_gpu_round4.py -s 2>&1 | tail -8 | tee "$out/direct_parity.txt"
 python -m pytest -q -m gpu tests/test_gpu_determinism.py 2>&1 | tail -5 | tee "$out/determinism.txt"
 cd /tmp && export TMPDIR=/tmp
