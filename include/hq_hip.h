@@ -24,7 +24,8 @@
  * HQ_BLOCKED_THREADS (256|512), HQ_BLOCKED_ALDS (0: operand and address tables of
  * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_GROUPS
  * (0: a workgroup barrier after every inner gate), HQ_BLOCKED_DIRECT (1: tile
- * movement of a blocked pass folded into its first gate), HQ_BLOCKED_GRID (cap,
+ * movement of a blocked pass folded into its first gate), HQ_BLOCKED_BIG (1: 128 KiB
+ * tiles run on one 1024-thread workgroup per CU), HQ_BLOCKED_GRID (cap,
  * a power of two, on the resident workgroups of a blocked pass), HQ_BLOCKED_PREF,
  * HQ_GEMM_PREF, HQ_SWAP_PREF (0: no register prefetch of the next tile in the
  * cache-blocked / k >= 7 / low-bit-swap kernels), HQ_BIG_PHASED, HQ_BIG_GRID (k = 5, 6
