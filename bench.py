@@ -75,6 +75,8 @@ def parse_args():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-events', action='store_true', help='skip per-gate HIP events in the timed region')
     ap.add_argument('--overlap', action='store_true', help='N > 1: exchanges in rounds with the independent local gates applied to the pieces as they land (hybridq_amd.dist.overlap_exchanges; default off until measured on xGMI)')
+    ap.add_argument('--variants-min-qubits', type=int, default=26, help='the blocked_variants leg runs from this size on')
+    ap.add_argument('--no-variants', action='store_true', help='skip the blocked_variants leg (the cache-blocked step under the opt-in kernel switches of round 4, one subprocess each)')
     ap.add_argument('--no-config-legs', action='store_true', help='skip the short BASELINE config 4 / config 5 legs after the timed region')
     ap.add_argument('--parity-qubits', type=int, default=24, help='size of the parity_check circuit (the CPU reference runs all of it)')
     ap.add_argument('--leg-parity-qubits', type=int, default=16, help='size of the small-n parity runs of the config legs (even)')
@@ -229,6 +231,29 @@ def parity_check(complex_type, depth, n=24):
         out['reference_vs_f64_leaves_bar_after'] = next((r['gates'] for r in rows if r['reference_vs_f64'] > bar), None)
     out['pass'] = bool(ok)
     out['literal_bar_met'] = bool(all(v for k, v in out.items() if k.startswith('literal_bar_met_')))
+    return out
+
+
+def blocked_variants(n, complex_type):
+    """tools/ab_blocked.py (plan + 1 warm-up + 3 timed cache-blocked steps of the depth-40 generator circuit at n qubits) once
+    per switch setting: the default (barrier-free wave groups), one barrier per inner gate, the tile movement folded into
+    the first gate, 128 KiB tiles on one 1024-thread workgroup, and both.  Never raises."""
+    import subprocess
+    tb = 13 if complex_type == 'complex64' else 12
+    settings = [('default', {}, tb), ('groups_off', {'HQ_BLOCKED_GROUPS': '0'}, tb), ('direct', {'HQ_BLOCKED_DIRECT': '1'}, tb),
+                ('big_tiles', {'HQ_BLOCKED_BIG': '1'}, tb + 1), ('big_tiles_direct', {'HQ_BLOCKED_BIG': '1', 'HQ_BLOCKED_DIRECT': '1'}, tb + 1)]
+    out = {}
+    for name, env, bits in settings:
+        try:
+            cmd = [sys.executable, os.path.join(ROOT, 'tools', 'ab_blocked.py'), str(n), complex_type, str(bits), 'json']
+            if os.environ.get('HQ_EMU_GPU_SUITE') == '1':  # the CPU suite's end-to-end run of this file (tests/emu): same launcher
+                cmd[1:1] = [os.path.join(ROOT, 'tests', 'emu', 'run_emulated.py')]
+            r = subprocess.run(cmd,
+                               env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            out[name] = dict(json.loads(line[-1]), env=env) if line else {'error': (r.stderr or r.stdout)[-300:]}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {'error': repr(e)}
     return out
 
 
@@ -716,6 +741,10 @@ def main():
                 torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
             result['blocked_error'] = repr(e)
+    if rank == 0 and not sharded_path and not args.no_fused and not args.no_variants and n >= args.variants_min_qubits:
+        # The cache-blocked step under the kernel switches built without a GPU in round 4 (the library reads them once, so
+        # each runs in its own process, after the timed region): whoever runs this line on hardware gets the A/B with it.
+        result['blocked_variants'] = blocked_variants(n, args.dtype)
     if rank == 0 and not sharded_path and not args.no_fused:
         try:  # a reported extra: a failure here must never cost the headline line
             # the same 900-gate step through the VALU register-butterfly kernels only (no matrix cores):

@@ -893,7 +893,13 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
                    Atab.size() * sizeof(T) + table_bytes(BlockedTab<1024>::kWords) <= a_budget;
   const unsigned wave_bits_n = big ? 4u : 3u;
   const size_t tab_bytes = table_bytes(big ? BlockedTab<1024>::kWords : BlockedTab<512>::kWords);  // per-gate address tables (built in-kernel)
-  const bool fits = a_in_lds && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
+  // a gate's wave-iterations must fit the ITER part of its address table: 128 KiB tiles reach 128 of them (complex64 k <= 3
+  // gate with both vector-component bits among its targets); the 512-thread kernel's tables hold 64 -- such a pass computes
+  // its addresses (found under emulation in round 4: the table read ran into the next gate's entries)
+  bool iter_ok = true;
+  for (const BlockedGate& G : gates)
+    if (G.kv < 64 && ((1u << (tb - CB - G.n_addr)) >> 4) > (big ? BlockedTab<1024>::kNIter : BlockedTab<512>::kNIter)) iter_ok = false;
+  const bool fits = a_in_lds && iter_ok && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
   // register prefetch of the next tile (512 threads, 4 vectors per thread and plane = 13 (f32) / 12 (f64) tile bits;
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
   const bool pref = use_pref && block_threads != 256 && ((tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits)) || big);

@@ -28,10 +28,10 @@ def rand_u(k, ct, rng):
     return ((rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) / np.sqrt(2.0 * d)).astype(ct)
 
 
-CASES = [(3, 3, 2, 4, 3), (4, 2, 3, 3), (1, 3, 3), (3, 3)]
+CASES = [(3, 3, 2, 4, 3), (4, 2, 3, 3), (1, 3, 3), (3, 3), (3, 3, 2)]
 for ft in (np.float32, np.float64):
     ct = np.complex64 if ft == np.float32 else np.complex128
-    tb = (13 if ft == np.float32 else 12) + (os.environ.get('HQ_BLOCKED_BIG') == '1')  # BIG: 128 KiB tiles, 1024 threads
+    tb = (13 if ft == np.float32 else 12) + (os.environ.get('HQ_TEST_BIG_TILES', os.environ.get('HQ_BLOCKED_BIG')) == '1')  # 128 KiB tiles
     n = tb + 4  # 16 tiles
     re, im, free = emu_util.device_planes(core, n, ft)
     for case, ks in enumerate(CASES):
@@ -40,6 +40,9 @@ for ft in (np.float32, np.float64):
         gates = [(rand_u(k, ct, rng), rng.permutation(tile)[:k]) for k in ks]
         if case == 3:  # a first gate with a target among the vector-component bits and one on a low vector bit
             gates[0] = (gates[0][0], np.array([1, 3, int(tile[-1])], dtype=np.uint32))
+        if case == 4:  # both vector-component bits among the targets: the most wave-iterations a gate can have (128 on 128 KiB tiles)
+            gates[1] = (gates[1][0], np.array([0, int(tile[-2]), 1], dtype=np.uint32))
+            gates[2] = (gates[2][0], np.array([1, 0], dtype=np.uint32))
         psi = (rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)).astype(ct)
         re[:], im[:] = psi.real, psi.imag
         core.apply_blocked(re, im, tile, gates, n)

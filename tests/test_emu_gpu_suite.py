@@ -45,7 +45,7 @@ def test_bench_line_end_to_end_against_the_emulated_library():
     env = dict(os.environ, PYTHONPATH=ROOT)
     env.pop('HQ_HIP_LIBRARY', None)
     cmd = [sys.executable, os.path.join(ROOT, 'tests', 'emu', 'run_emulated.py'), 'bench.py', '--qubits', '14', '--depth', '3',
-           '--steps', '1', '--warmup', '1', '--parity-qubits', '10', '--leg-parity-qubits', '10', '--cpu-seconds', '0.5']
+           '--steps', '1', '--warmup', '1', '--parity-qubits', '10', '--leg-parity-qubits', '10', '--cpu-seconds', '0.5', '--variants-min-qubits', '14']
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
@@ -61,6 +61,9 @@ def test_bench_line_end_to_end_against_the_emulated_library():
     assert line['cpu_baseline']['kind'] in ('reference', 'port') and line['cpu_baseline']['cores'] >= 1
     for leg in ('cfg4_dense_k34', 'cfg5_noisy_dm'):
         assert line[leg]['roofline']['kernel'] and line[leg]['gate_apps_per_s'] > 0 and line[leg]['parity_small_n']['pass'] is True
+    bv = line['blocked_variants']  # the opt-in kernel switches of round 4, one subprocess each
+    assert set(bv) == {'default', 'groups_off', 'direct', 'big_tiles', 'big_tiles_direct'} and not [k for k, v in bv.items() if 'error' in v], bv
+    assert all(len(v['ms_per_step']) == 3 and v['passes'] >= 1 for v in bv.values()), bv  # (which kernels a 14-qubit circuit takes says nothing)
     pc = line['parity_check']
     assert pc['pass'] is True and pc['literal_bar_depth'] == pc['literal_bar_depth_of'] and len(pc['prefixes']) >= 8
     assert 'l2_rel_diff_per_gate' in pc and 'reference_vs_f64_leaves_bar_after' in pc

@@ -111,8 +111,9 @@ def test_blocked_direct_pass():
     must not depend on the schedule (the only synchronisation between the last gate of one tile and the first gate of the
     next is ONE workgroup barrier), and wherever the host did not have to move another gate to the front they are
     bit-identical to the staged kernel's."""
-    def run(direct, order, big='0'):
-        env = dict(os.environ, HQ_BLOCKED_DIRECT=direct, HQ_BLOCKED_BIG=big, HQ_BLOCKED_GRID='2', HQ_EMU_ORDER=order, PYTHONPATH=ROOT)
+    def run(direct, order, big='0', big_tiles=None):
+        env = dict(os.environ, HQ_BLOCKED_DIRECT=direct, HQ_BLOCKED_BIG=big, HQ_TEST_BIG_TILES=big_tiles or big, HQ_BLOCKED_GRID='2',
+                   HQ_EMU_ORDER=order, PYTHONPATH=ROOT)
         env.pop('HQ_HIP_LIBRARY', None)
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu_direct_worker.py')], env=env, capture_output=True,
                            text=True, timeout=900)
@@ -120,7 +121,7 @@ def test_blocked_direct_pass():
         return [ln.split() for ln in r.stdout.strip().splitlines()]
     staged = run('0', 'forward')
     direct = {o: run('1', o) for o in ('forward', 'reverse', 'random')}
-    assert len(staged) == 8 and not any('direct' in ln[1] for ln in staged)
+    assert len(staged) == 10 and not any('direct' in ln[1] for ln in staged)
     n_direct = 0
     for i, (case, desc, err, h) in enumerate(direct['forward']):
         assert float(err) < (3e-6 if 'float32' in case else 1e-13), (case, desc, err)
@@ -136,7 +137,10 @@ def test_blocked_direct_pass():
     assert n_direct >= 5, direct['forward']
     # HQ_BLOCKED_BIG=1: 128 KiB tiles (2^14 / 2^13 amplitudes), one 1024-thread workgroup, four wave bits -- staged and
     # direct, forward and random schedules; the plain 512-thread kernel (no prefetch at this tile size) is the reference
-    plain = run('0', 'forward', big='0')
+    # (the same 128 KiB tiles on the 512-thread kernel: a gate with 128 wave-iterations does not fit its 64-entry address
+    # table there and must take the computed addresses -- the table read used to run into the next gate's entries)
+    plain = run('0', 'forward', big='0', big_tiles='1')
+    assert all('512' in ln[1] and float(ln[2]) < (3e-6 if 'float32' in ln[0] else 1e-13) for ln in plain), plain
     for d in ('0', '1'):
         got = {o: run(d, o, big='1') for o in ('forward', 'random')}
         assert all('1024' in ln[1] for ln in got['forward']), got['forward']

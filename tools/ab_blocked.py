@@ -19,7 +19,8 @@ ctype = sys.argv[2] if len(sys.argv) > 2 else 'complex64'
 tb = int(sys.argv[3]) if len(sys.argv) > 3 else (13 if ctype == 'complex64' else 12)
 gates = rqc_1q2q(n, depth=40, seed=n)
 state = EvolutionState(list(range(n)), complex_type=ctype, initial_state='0' * n)
-for kw in (dict(), dict(inner_max=0)):
+as_json = len(sys.argv) > 4 and sys.argv[4] == 'json'  # bench.py's blocked_variants leg: the planner's own fusion only, one JSON line
+for kw in ((dict(),) if as_json else (dict(), dict(inner_max=0))):
     ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=5 if ctype == 'complex64' else 4, complex_type=ctype), **kw})
     packed = [('B', op[1], core.pack_blocked(op[2], ctype)) if op[0] == 'B' else op for op in ops]
 
@@ -38,5 +39,16 @@ for kw in (dict(), dict(inner_max=0)):
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     st = blocked_stats(ops)
+    if as_json:
+        import json
+        n_direct = 0
+        for op in packed:  # how many passes took the direct first gate (the library reports the last launch)
+            if op[0] == 'B':
+                core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
+                n_direct += core.last_kernel_desc().endswith('direct')
+        torch.cuda.synchronize()
+        print(json.dumps({'tile_bits': tb, 'passes': st['blocked_passes'], 'plain_gates': st['plain_gates'], 'inner_gates': st['inner_gates'],
+                          'direct_passes': n_direct, 'kernel': core.last_kernel_desc().split(' tb=')[0], 'ms_per_step': [round(t, 3) for t in ts]}), flush=True)
+        continue
     print(os.path.basename(os.environ.get('HQ_HIP_LIBRARY', 'in-tree')), f'tb={tb}', core.last_kernel_desc().split('>')[0].split('<')[-1], kw, f"passes {st['blocked_passes']} + {st['plain_gates']} plain, inner {st['inner_gates']}:",
           ' '.join('%.1f' % t for t in ts), 'ms', flush=True)
