@@ -150,6 +150,17 @@ def test_blocked_direct_pass():
             assert got['random'][i][3] == h, (case, desc)
 
 
+def test_fuzz_campaign_smoke():
+    """tools/emu_fuzz.py (random sizes, tiles, gate lists, permutations against numpy on the emulated device) for a few
+    seconds under the opt-in cache-blocked kernels and random wave schedules; the long campaigns are in
+    profiles/r04_emu_fuzz.txt."""
+    env = dict(os.environ, HQ_BLOCKED_DIRECT='1', HQ_BLOCKED_BIG='1', HQ_BLOCKED_GRID='2', HQ_EMU_ORDER='random', PYTHONPATH=ROOT)
+    env.pop('HQ_HIP_LIBRARY', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'emu_fuzz.py'), '12', '77'], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and 'failures: 0' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_tuned_placement_allocator_on_emulated_granules():
     """hq_alloc_state's draw-and-probe search, the re-probe of the winner's granules in creation order (vmm_remap: the
     same physical granules mapped into a fresh range -- contents and usability must survive), the per-size pool and the
