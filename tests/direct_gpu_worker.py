@@ -29,21 +29,22 @@ for ct, ft, n, inner in CASES:
     rng = np.random.default_rng(5)
     gates = rqc_1q2q(n, depth=6 if EMU else 16, seed=9)
     ident = {q: n - 1 - q for q in range(n)}
-    tb = 13 if ct == 'complex64' else 12
-    ops = plan_blocked(gates, ident, n, tile_bits=tb, low_bits=tb - 8, complex_type=ct, inner_max=inner)
+    tb = (13 if ct == 'complex64' else 12) + (os.environ.get('HQ_BLOCKED_BIG') == '1')  # BIG: 128 KiB tiles, 1024 threads
+    ops = plan_blocked(gates, ident, n, tile_bits=min(tb, n), low_bits=5 if ct == 'complex64' else 4, complex_type=ct, inner_max=inner)
     base = torch.from_numpy(rng.standard_normal((2, 1 << n))).to(ft).cuda()
     base /= base.norm()
     ref = base.clone()
     for U, qs in gates:
         core.apply_U(ref[0], ref[1], np.ascontiguousarray(U, dtype=ct), [ident[q] for q in reversed(qs)], n)
     got = base.clone()
-    kinds = []
+    kinds, big = [], []
     for op in ops:
         if op[0] == 'G':
             core.apply_U(got[0], got[1], np.ascontiguousarray(op[1], dtype=ct), op[2], n)
         else:
             core.apply_blocked(got[0], got[1], op[1], op[2], n)
             kinds.append(core.last_kernel_desc().endswith('direct'))
+            big.append('1024' in core.last_kernel_desc())
     core.sync()
     err = float(((got - ref).abs().max() / ref.abs().max()).item())
     again = base.clone()
@@ -54,7 +55,7 @@ for ct, ft, n, inner in CASES:
             core.apply_blocked(again[0], again[1], op[1], op[2], n)
     core.sync()
     import hashlib
-    out[f'{ct} inner_max={inner}'] = {'n': n, 'passes': len(kinds), 'direct_passes': int(sum(kinds)), 'err_vs_per_gate': err,
+    out[f'{ct} inner_max={inner}'] = {'n': n, 'passes': len(kinds), 'direct_passes': int(sum(kinds)), 'passes_1024_threads': int(sum(big)), 'err_vs_per_gate': err,
                'tol': circuit_tol(gates, gates, complex_type=ct), 'repeatable': bool(torch.equal(got, again)),
                'sha': hashlib.sha256(got.cpu().numpy().tobytes()).hexdigest()[:24]}
 print(json.dumps(out))

@@ -1,6 +1,7 @@
 """Round-4 device code that no earlier GPU test reaches: apply_blocked_direct_kernel (HQ_BLOCKED_DIRECT=1, the tile
-movement folded into the first gate of a cache-blocked pass).  The staged kernel is the default until the two have been
-timed against each other (tools/ab_round4.sh); this test makes sure the opt-in path is RIGHT on the device."""
+movement folded into the first gate of a cache-blocked pass) and the 1024-thread kernels for 128 KiB tiles
+(HQ_BLOCKED_BIG=1).  The staged 512-thread kernel is the default until they have been timed against each other
+(tools/ab_round4.sh, bench.py's blocked_variants); these tests make sure the opt-in paths are RIGHT on the device."""
 import json
 import os
 import subprocess
@@ -34,3 +35,18 @@ def test_blocked_direct_pass_on_the_device(torch_cuda, capsys):
             assert r['repeatable'], (ct, grid)
             assert staged[ct]['direct_passes'] == 0 and staged[ct]['err_vs_per_gate'] <= staged[ct]['tol']
         assert res['complex64 inner_max=3']['direct_passes'] >= res['complex64 inner_max=3']['passes'] // 2, res
+
+
+def test_blocked_128k_tiles_on_the_device(torch_cuda, capsys):
+    """128 KiB tiles (2^14 complex64 / 2^13 complex128 amplitudes) on one 1024-thread workgroup per CU, staged and with the
+    direct first gate, four and sixteen tiles per workgroup, against the per-gate kernels; two runs bit-identical."""
+    for direct in ('0', '1'):
+        for grid in ('0', '64'):
+            res = _worker(HQ_BLOCKED_BIG='1', HQ_BLOCKED_DIRECT=direct, HQ_BLOCKED_GRID=grid)
+            with capsys.disabled():
+                print(f'\n  HQ_BLOCKED_DIRECT={direct} HQ_BLOCKED_GRID={grid}: {res}')
+            for ct, r in res.items():
+                assert r['err_vs_per_gate'] <= r['tol'] and r['repeatable'], (ct, direct, grid, r)
+            assert res['complex64 inner_max=3']['passes_1024_threads'] >= 1, res
+            if direct == '1':
+                assert res['complex64 inner_max=3']['direct_passes'] >= 1, res
