@@ -237,11 +237,14 @@ def parity_check(complex_type, depth, n=24):
 def blocked_variants(n, complex_type):
     """tools/ab_blocked.py (plan + 1 warm-up + 3 timed cache-blocked steps of the depth-40 generator circuit at n qubits) once
     per switch setting: the default (barrier-free wave groups), one barrier per inner gate, the tile movement folded into
-    the first gate, 128 KiB tiles on one 1024-thread workgroup, and both.  Never raises."""
+    the first gate, 128 KiB tiles on one 1024-thread workgroup, both, and (a planner setting, not a kernel) one forced low
+    tile bit less.  Never raises."""
     import subprocess
     tb = 13 if complex_type == 'complex64' else 12
     settings = [('default', {}, tb), ('groups_off', {'HQ_BLOCKED_GROUPS': '0'}, tb), ('direct', {'HQ_BLOCKED_DIRECT': '1'}, tb),
-                ('big_tiles', {'HQ_BLOCKED_BIG': '1'}, tb + 1), ('big_tiles_direct', {'HQ_BLOCKED_BIG': '1', 'HQ_BLOCKED_DIRECT': '1'}, tb + 1)]
+                ('big_tiles', {'HQ_BLOCKED_BIG': '1'}, tb + 1), ('big_tiles_direct', {'HQ_BLOCKED_BIG': '1', 'HQ_BLOCKED_DIRECT': '1'}, tb + 1),
+                # one forced low tile bit less = 64-byte runs per plane instead of whole 128-byte lines: 26 instead of 28 passes
+                ('low_bits_minus_1', {'HQ_AB_LOW_BITS': str(4 if complex_type == 'complex64' else 3)}, tb)]
     out = {}
     for name, env, bits in settings:
         try:

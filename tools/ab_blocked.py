@@ -22,7 +22,7 @@ gates = rqc_1q2q(n, depth=40, seed=n)
 state = EvolutionState(list(range(n)), complex_type=ctype, initial_state='0' * n, placement=os.environ.get('HQ_AB_PLACEMENT', 'plain'))
 as_json = len(sys.argv) > 4 and sys.argv[4] == 'json'  # bench.py's blocked_variants leg: the planner's own fusion only, one JSON line
 for kw in ((dict(),) if as_json else (dict(), dict(inner_max=0))):
-    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=5 if ctype == 'complex64' else 4, complex_type=ctype), **kw})
+    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=int(os.environ.get('HQ_AB_LOW_BITS', 5 if ctype == 'complex64' else 4)), complex_type=ctype), **kw})
     packed = [('B', op[1], core.pack_blocked(op[2], ctype)) if op[0] == 'B' else op for op in ops]
 
     def run():
@@ -48,7 +48,7 @@ for kw in ((dict(),) if as_json else (dict(), dict(inner_max=0))):
                 core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
                 n_direct += core.last_kernel_desc().endswith('direct')
         torch.cuda.synchronize()
-        print(json.dumps({'tile_bits': tb, 'passes': st['blocked_passes'], 'plain_gates': st['plain_gates'], 'inner_gates': st['inner_gates'],
+        print(json.dumps({'tile_bits': tb, 'low_bits': int(os.environ.get('HQ_AB_LOW_BITS', 5 if ctype == 'complex64' else 4)), 'passes': st['blocked_passes'], 'plain_gates': st['plain_gates'], 'inner_gates': st['inner_gates'],
                           'direct_passes': n_direct, 'kernel': core.last_kernel_desc().split(' tb=')[0], 'ms_per_step': [round(t, 3) for t in ts]}), flush=True)
         continue
     print(os.path.basename(os.environ.get('HQ_HIP_LIBRARY', 'in-tree')), f'tb={tb}', core.last_kernel_desc().split('>')[0].split('<')[-1], kw, f"passes {st['blocked_passes']} + {st['plain_gates']} plain, inner {st['inner_gates']}:",
