@@ -640,15 +640,30 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
 #pragma unroll
   for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[BlockedTab<BLOCK>::kOff + ld];
   typedef __attribute__((address_space(3))) V LdsV;  // addresses are absolute LDS byte addresses (base folded in LANE)
-  for (unsigned it = wave; it < niter; it += 1u << WB) {
-    const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + it];
-    unsigned addr[NL];
-    V x[NL];
+  // multiply-accumulate of one wave-iteration whose vectors are in x, results to the slots they came from (Lt ^ OFF[ld]).
+  // Component c of vector ld sits in accumulator block (cf, so >> 2), register so & 3: a 16-byte store wants 4
+  // consecutive registers, i.e. a transpose by ~14 v_mov per iteration.
+  auto store_results = [&](Acc (&acc)[NCB][NRB], const unsigned Lt) {
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
-      addr[ld] = Lt ^ OFF[ld];
-      x[ld] = *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]);
+      V y;
+#pragma unroll
+      for (int comp = 0; comp < NCOMP; ++comp) {
+        const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
+        const int so = ck | (ld << KV);
+        y[comp] = acc[cf][so >> 2][so & 3];
+      }
+      *reinterpret_cast<LdsV*>((uintptr_t)(Lt ^ OFF[ld])) = y;
     }
+  };
+#ifdef HQ_BLOCKED_NOPIPE
+  // (the loop of rounds 2-4a, kept for A/B builds: the compiler sinks every ds_read_b128 to just in front of the MFMAs
+  // that consume it and waits for it there -- 4 to 8 exposed LDS latencies per wave-iteration)
+  for (unsigned it = wave; it < niter; it += 1u << WB) {
+    const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + it];
+    V x[NL];
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) x[ld] = *reinterpret_cast<LdsV*>((uintptr_t)(Lt ^ OFF[ld]));
     Acc acc[NCB][NRB];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf)
@@ -664,23 +679,117 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
         for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Mfma<T>::run(a[rb][s], x[ld][comp], acc[cf][rb]);
       }
     }
-    // component c of vector ld sits in accumulator block (cf, so >> 2), register so & 3.  A 16-byte store wants 4
-    // consecutive registers, i.e. a transpose by 15 v_mov per iteration (and the compiler re-vectorises element
-    // stores into exactly that); ds_write2 takes its two elements from any two registers.  Inline assembly: the
-    // compiler neither counts these stores (lgkmcnt is drained by hand after the loop) nor pads the
-    // MFMA-result -> LDS-read hazard in front of them (s_nop by hand: 8-pass MFMA, 16 wait states cover it).
+    store_results(acc, Lt);
+  }
+#else
+  // LDS reads ahead of the matrix cores (round 4, from the assembly: left to itself the compiler sinks every
+  // ds_read_b128 to just in front of the 4-8 MFMAs that consume it, `s_waitcnt lgkmcnt(0)` in between -- a wave then
+  // feeds the matrix pipe for 128-256 cycles, waits ~100+ for LDS, feeds it again: the 1276 cycles that the 16 MFMAs
+  // (512 cycles of pipe) of one iteration took in round 2's s_memtime timeline).  Now the vectors of the NEXT
+  // wave-iteration are requested before the MFMAs of the current one start (two register sets, ping-pong; a
+  // scheduling barrier keeps the requests where they are written), so that only the first iteration of a gate waits
+  // for LDS; the one shape without registers for a second set (k = 4 without a component target: 8 vectors) runs its
+  // requests one vector ahead of the MFMAs inside the iteration.  Same LDS operations, same arithmetic, same order of
+  // every accumulation: results are bit-identical to the loop above.
+  constexpr unsigned STEP = 1u << WB;
+  auto request = [&](V (&x)[NL], const unsigned Lt) {
 #pragma unroll
-    for (int ld = 0; ld < NL; ++ld) {
-      V y;
+    for (int ld = 0; ld < NL; ++ld) x[ld] = *reinterpret_cast<LdsV*>((uintptr_t)(Lt ^ OFF[ld]));
+  };
+  auto multiply = [&](V (&x)[NL], const unsigned Lt) {
+    Acc acc[NCB][NRB];
 #pragma unroll
-      for (int comp = 0; comp < NCOMP; ++comp) {
-        const int ck = pext_c(comp, VMASK), cf = pext_c(comp, FMASK);
-        const int so = ck | (ld << KV);
-        y[comp] = acc[cf][so >> 2][so & 3];
+    for (int cf = 0; cf < NCB; ++cf)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Acc{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const int ck = s & ((1 << KV) - 1), ld = s >> KV;
+#pragma unroll
+      for (int cf = 0; cf < NCB; ++cf) {
+        const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Mfma<T>::run(a[rb][s], x[ld][comp], acc[cf][rb]);
       }
-      *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]) = y;
+    }
+    store_results(acc, Lt);
+  };
+  // (k = 4: 16 operand + 32 accumulator registers beside the 32 of the tile prefetch leave no room for a second set)
+  constexpr bool kTwoSets = NL <= 4 && KBITS == 4;
+  if constexpr (kTwoSets) {
+    unsigned it = wave;
+    if (it < niter) {
+      // the table entry of an iteration is read one phase before the requests that need it (its latency used to sit in
+      // front of every iteration's first request); the index is clamped, an entry read past the last iteration is unused
+      auto entry = [&](const unsigned i) { return tab[BlockedTab<BLOCK>::kIter + (i < niter ? i : wave)]; };
+      V x0[NL], x1[NL];
+      unsigned Lt0 = L ^ entry(it), Lt1 = 0, t_next = entry(it + STEP);
+      request(x0, Lt0);
+      // The requests of the next iteration are UNCONDITIONAL: on a path without them the compiler's wait counts for the
+      // set being multiplied are those of "nothing requested since" (lgkmcnt counts in order), and merged over both
+      // paths the multiply would wait for the requests just issued -- the latency this loop is there to hide.  Past the
+      // last iteration every lane requests the same 16 bytes (the head of this gate's table: a broadcast, no bank
+      // traffic to speak of) into the set that is never multiplied.
+      const unsigned idle = (unsigned)reinterpret_cast<uintptr_t>(tab);
+      auto request_next = [&](V (&x)[NL], const unsigned Lt, const bool more) {
+#pragma unroll
+        for (int ld = 0; ld < NL; ++ld) x[ld] = *reinterpret_cast<LdsV*>((uintptr_t)(more ? (Lt ^ OFF[ld]) : idle));
+      };
+      for (;;) {
+        bool more = it + STEP < niter;  // wave-uniform
+        Lt1 = L ^ t_next;
+        request_next(x1, Lt1, more);
+        t_next = entry(it + 2 * STEP);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(x0, Lt0);
+        if (!more) break;
+        it += STEP;
+        more = it + STEP < niter;
+        Lt0 = L ^ t_next;
+        request_next(x0, Lt0, more);
+        t_next = entry(it + 2 * STEP);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(x1, Lt1);
+        if (!more) break;
+        it += STEP;
+      }
+    }
+  } else if constexpr (NL <= 4) {  // all requests of the iteration in front of its first MFMA
+    for (unsigned it = wave; it < niter; it += STEP) {
+      V x[NL];
+      const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + it];
+      request(x, Lt);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(x, Lt);
+    }
+  } else {
+    static_assert(KV == 0, "eight vectors per wave-iteration: no component target");
+    for (unsigned it = wave; it < niter; it += STEP) {
+      const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + it];
+      Acc acc[NCB][NRB];
+#pragma unroll
+      for (int cf = 0; cf < NCB; ++cf)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Acc{0, 0, 0, 0};
+      V xa = *reinterpret_cast<LdsV*>((uintptr_t)(Lt ^ OFF[0]));
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld) {  // step s = ld
+        V xb = xa;
+        if (ld + 1 < NL) xb = *reinterpret_cast<LdsV*>((uintptr_t)(Lt ^ OFF[ld + 1]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cf = 0; cf < NCB; ++cf) {
+          const int comp = pdep_c(0, VMASK) | pdep_c(cf, FMASK);
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb) acc[cf][rb] = Mfma<T>::run(a[rb][ld], xa[comp], acc[cf][rb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        xa = xb;
+      }
+      store_results(acc, Lt);
     }
   }
+#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 

@@ -9,6 +9,20 @@
 set -u
 out=gpurun_out/ab_round4
 mkdir -p "$out"
+# 0. LDS reads ahead of the matrix cores in the inner gates (default since the third session of round 4) against the old loop:
+#    a second build of the library with -DHQ_BLOCKED_NOPIPE (tools/_ab/, ~1 min of hipcc on the box), same circuit, alternating
+python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+from hybridq_amd import build
+os.makedirs('tools/_ab/nopipe', exist_ok=True)
+print(build.build(force=True, extra_flags=['-DHQ_BLOCKED_NOPIPE'], lib=os.path.abspath('tools/_ab/libhq_hip_nopipe.so'), objdir=os.path.abspath('tools/_ab/nopipe')))
+PY
+for rep in 1 2 3; do
+  echo "== rep $rep pipelined (in-tree) / old loop (nopipe build)"
+  python tools/ab_blocked.py 30 complex64 2>&1 | tail -2 | tee -a "$out/blocked_pipelined.txt"
+  HQ_HIP_LIBRARY=$PWD/tools/_ab/libhq_hip_nopipe.so python tools/ab_blocked.py 30 complex64 2>&1 | tail -2 | tee -a "$out/blocked_nopipe.txt"
+done
 for rep in 1 2; do
   for g in 1 0; do
     echo "== rep $rep HQ_BLOCKED_GROUPS=$g"
