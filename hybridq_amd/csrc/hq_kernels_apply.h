@@ -1432,31 +1432,119 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
     for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
       for (int c = 0; c < CBW; ++c) { accr[rb][c] = Acc{0, 0, 0, 0}; acci[rb][c] = Acc{0, 0, 0, 0}; }
+    // the loop of rounds 1-4a: still what complex128 with 128 accumulator registers runs (no registers for a second
+    // operand set), and what -DHQ_GEMM_NOPIPE builds everywhere for A/B
+    auto plain_loop = [&]() {
     for (unsigned sg = 0; sg < a.nsg; ++sg) {
-      V ur[RBW], ui[RBW];
+        V ur[RBW], ui[RBW];
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) {
+          const V* __restrict__ pA = Av + ((size_t)((wr * RBW + rb) * a.nsg + sg) * 2) * 64;
+          ur[rb] = pA[0];
+          ui[rb] = pA[64];
+        }
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+          const unsigned to = toff[sg * G + s];
+#pragma unroll
+          for (int c = 0; c < CBW; ++c) {
+            const unsigned e = lane_cb[c] ^ to;
+            const T br = xr[e], bi = xi[e], nbi = -bi;
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) accr[rb][c] = Mfma<T>::run(ur[rb][s], br, accr[rb][c]);
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) acci[rb][c] = Mfma<T>::run(ui[rb][s], br, acci[rb][c]);
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) accr[rb][c] = Mfma<T>::run(ui[rb][s], nbi, accr[rb][c]);
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) acci[rb][c] = Mfma<T>::run(ur[rb][s], bi, acci[rb][c]);
+          }
+        }
+      }
+    };
+#ifdef HQ_GEMM_NOPIPE
+    constexpr bool kPipe = false;
+#else
+    constexpr bool kPipe = !(sizeof(T) == 8 && RBW * CBW >= 8);
+#endif
+    if constexpr (!kPipe) {
+      plain_loop();
+    } else {
+    // Operands ahead of the matrix cores (round 4, from the assembly of the loop above: the B operands of a K-step were
+    // requested from LDS right in front of the step's 4 RBW CBW MFMAs and the A operands of a step group from L2 at its
+    // top -- one LDS round trip per K-step and one L2 round trip per step group in front of the matrix pipe, most of
+    // the 23-29 % this kernel stayed below the MFMA peak).  Two register sets each: the A operands of step group
+    // sg + 1 are requested before the MFMAs of group sg start, the B operands of K-step s + 1 before those of step s;
+    // requests are unconditional (past the end: a repeat of the last one) and scheduling barriers keep them where
+    // they are written.  Same MFMAs in the same order on every accumulator: bit-identical results.
+    auto request_a = [&](V (&ur)[RBW], V (&ui)[RBW], const unsigned sg) {
 #pragma unroll
       for (int rb = 0; rb < RBW; ++rb) {
         const V* __restrict__ pA = Av + ((size_t)((wr * RBW + rb) * a.nsg + sg) * 2) * 64;
         ur[rb] = pA[0];
         ui[rb] = pA[64];
       }
+    };
+    auto request_b = [&](T (&br)[CBW], T (&bi)[CBW], const unsigned step) {
+      const unsigned to = toff[step];
 #pragma unroll
-      for (int s = 0; s < G; ++s) {
-        const unsigned to = toff[sg * G + s];
-#pragma unroll
-        for (int c = 0; c < CBW; ++c) {
-          const unsigned e = lane_cb[c] ^ to;
-          const T br = xr[e], bi = xi[e], nbi = -bi;
-#pragma unroll
-          for (int rb = 0; rb < RBW; ++rb) accr[rb][c] = Mfma<T>::run(ur[rb][s], br, accr[rb][c]);
-#pragma unroll
-          for (int rb = 0; rb < RBW; ++rb) acci[rb][c] = Mfma<T>::run(ui[rb][s], br, acci[rb][c]);
-#pragma unroll
-          for (int rb = 0; rb < RBW; ++rb) accr[rb][c] = Mfma<T>::run(ui[rb][s], nbi, accr[rb][c]);
-#pragma unroll
-          for (int rb = 0; rb < RBW; ++rb) acci[rb][c] = Mfma<T>::run(ur[rb][s], bi, acci[rb][c]);
-        }
+      for (int c = 0; c < CBW; ++c) {
+        const unsigned e = lane_cb[c] ^ to;
+        br[c] = xr[e];
+        bi[c] = xi[e];
       }
+    };
+    auto multiply = [&](V (&ur)[RBW], V (&ui)[RBW], const int s, T (&br)[CBW], T (&bi)[CBW]) {
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) {
+        const T nbi = -bi[c];
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) accr[rb][c] = Mfma<T>::run(ur[rb][s], br[c], accr[rb][c]);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acci[rb][c] = Mfma<T>::run(ui[rb][s], br[c], acci[rb][c]);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) accr[rb][c] = Mfma<T>::run(ui[rb][s], nbi, accr[rb][c]);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acci[rb][c] = Mfma<T>::run(ur[rb][s], bi[c], acci[rb][c]);
+      }
+    };
+    static_assert(G % 2 == 0, "the B sets alternate by K-step parity");
+    const unsigned last_step = a.nsg * G - 1;
+    V ua0[RBW], ub0[RBW], ua1[RBW], ub1[RBW];
+    T br0[CBW], bi0[CBW], br1[CBW], bi1[CBW];
+    request_a(ua0, ub0, 0);
+    request_b(br0, bi0, 0);
+    // one step group: its K-steps alternate between the two B sets, each step requesting the next one's operands first
+    auto group = [&](V (&ur)[RBW], V (&ui)[RBW], const unsigned sg) {
+#pragma unroll
+      for (int s = 0; s < G; s += 2) {
+        const unsigned st = sg * G + s;
+        request_b(br1, bi1, st + 1);  // st + 1 <= last_step: G is even
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(ur, ui, s, br0, bi0);
+        request_b(br0, bi0, st + 2 <= last_step ? st + 2 : last_step);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(ur, ui, s + 1, br1, bi1);
+      }
+    };
+    // the second A set only where the registers are there (512 threads = two waves per SIMD = 256 registers: the widest
+    // wave tiles hold 64 / 128 of them in accumulators and run the A requests of a group at its top as before)
+    constexpr int kAccRegs = RBW * CBW * 2 * (sizeof(T) == 4 ? 4 : 8) + (NPV > 0 ? NPV * 8 : 0);
+    constexpr bool kTwoA = kAccRegs < (sizeof(T) == 4 ? 64 : 128);
+    if constexpr (kTwoA) {
+      for (unsigned sg = 0; sg < a.nsg; sg += 2) {
+        request_a(ua1, ub1, sg + 1 < a.nsg ? sg + 1 : sg);
+        group(ua0, ub0, sg);
+        if (sg + 1 >= a.nsg) break;
+        request_a(ua0, ub0, sg + 2 < a.nsg ? sg + 2 : sg + 1);
+        group(ua1, ub1, sg + 1);
+      }
+    } else {
+      for (unsigned sg = 0; sg < a.nsg; ++sg) {
+        if (sg) request_a(ua0, ub0, sg);
+        group(ua0, ub0, sg);
+      }
+    }
     }
     __syncthreads();  // every wave is done reading the tile: replace it with the results
 #pragma unroll

@@ -150,6 +150,23 @@ def test_blocked_direct_pass():
             assert got['random'][i][3] == h, (case, desc)
 
 
+def test_pipelined_loops_are_bit_identical():
+    """The operand-ahead loops of round 4 (cache-blocked inner gates: LDS requests one wave-iteration / one vector ahead of
+    the MFMAs; tile GEMM: B operands one K-step, A operands one step group ahead) change the ORDER OF REQUESTS only: every
+    shape of inner gate and k = 4..10 through the GEMM kernel give the same bits as the loops they replaced, which an
+    A/B build of the emulated library (-DHQ_BLOCKED_NOPIPE -DHQ_GEMM_NOPIPE) still contains."""
+    outs = {}
+    for name, extra in (('default', ''), ('old_loops', '-DHQ_BLOCKED_NOPIPE -DHQ_GEMM_NOPIPE')):
+        env = dict(os.environ, PYTHONPATH=ROOT, HQ_EMU_EXTRA_FLAGS=extra)
+        env.pop('HQ_HIP_LIBRARY', None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu_ab_worker.py')], env=env, capture_output=True, text=True,
+                           timeout=1800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = [ln.split() for ln in r.stdout.strip().splitlines()]
+    assert len(outs['default']) == 20 and outs['default'] == outs['old_loops'], [(a, b) for a, b in zip(outs['default'], outs['old_loops']) if a != b]
+    assert sum('gemm' in ln[1] for ln in outs['default']) >= 8 and sum('blocked' in ln[1] for ln in outs['default']) == 6
+
+
 def test_fuzz_campaign_smoke():
     """tools/emu_fuzz.py (random sizes, tiles, gate lists, permutations against numpy on the emulated device) for a few
     seconds under the opt-in cache-blocked kernels and random wave schedules; the long campaigns are in

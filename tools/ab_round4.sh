@@ -16,13 +16,16 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 from hybridq_amd import build
 os.makedirs('tools/_ab/nopipe', exist_ok=True)
-print(build.build(force=True, extra_flags=['-DHQ_BLOCKED_NOPIPE'], lib=os.path.abspath('tools/_ab/libhq_hip_nopipe.so'), objdir=os.path.abspath('tools/_ab/nopipe')))
+print(build.build(force=True, extra_flags=['-DHQ_BLOCKED_NOPIPE', '-DHQ_GEMM_NOPIPE'], lib=os.path.abspath('tools/_ab/libhq_hip_nopipe.so'), objdir=os.path.abspath('tools/_ab/nopipe')))
 PY
 for rep in 1 2 3; do
   echo "== rep $rep pipelined (in-tree) / old loop (nopipe build)"
   python tools/ab_blocked.py 30 complex64 2>&1 | tail -2 | tee -a "$out/blocked_pipelined.txt"
   HQ_HIP_LIBRARY=$PWD/tools/_ab/libhq_hip_nopipe.so python tools/ab_blocked.py 30 complex64 2>&1 | tail -2 | tee -a "$out/blocked_nopipe.txt"
 done
+# 0b. the same for the k = 7..10 tile GEMM (B operands one K-step, A operands one step group ahead of the MFMAs)
+python tools/sweep_gemm.py 2>&1 | tail -12 | tee "$out/gemm_pipelined.txt"
+HQ_HIP_LIBRARY=$PWD/tools/_ab/libhq_hip_nopipe.so python tools/sweep_gemm.py 2>&1 | tail -12 | tee "$out/gemm_nopipe.txt"
 for rep in 1 2; do
   for g in 1 0; do
     echo "== rep $rep HQ_BLOCKED_GROUPS=$g"
