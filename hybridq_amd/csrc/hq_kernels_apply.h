@@ -1146,23 +1146,25 @@ __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, co
   for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[BlockedTab<BLOCK>::kOff + ld];
   const uint64_t gl = gt[kBlockedGTabLane + lane];
   typedef __attribute__((address_space(3))) V LdsV;
+  // The store-out reads run one wave-iteration AHEAD of the MFMAs (left in program order -- read, store, multiply -- every
+  // iteration had an LDS round trip in front of its MFMAs; see blocked_inner_gate_tab): the slots of iteration i + 1 are
+  // requested before the MFMAs of iteration i, the stores of iteration i are issued behind its MFMAs.
+  unsigned Ltv[NITL];
+#pragma unroll
+  for (int itl = 0; itl < NITL; ++itl) Ltv[itl] = L ^ tab[BlockedTab<BLOCK>::kIter + wave + ((unsigned)itl << WB)];
+  V t[2][NL];
+  if (have_prev) {  // uniform
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) t[0][ld] = *reinterpret_cast<LdsV*>((uintptr_t)(Ltv[0] ^ OFF[ld]));
+  }
 #pragma unroll
   for (int itl = 0; itl < NITL; ++itl) {
-    const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + wave + ((unsigned)itl << WB)];
-    unsigned addr[NL];
+    const unsigned Lt = Ltv[itl];
+    if (have_prev && itl + 1 < NITL) {
 #pragma unroll
-    for (int ld = 0; ld < NL; ++ld) addr[ld] = Lt ^ OFF[ld];
-    if (have_prev) {  // uniform: the finished amplitudes of the previous tile leave from the slots this iteration overwrites
-      V t[NL];
-#pragma unroll
-      for (int ld = 0; ld < NL; ++ld) t[ld] = *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]);
-#pragma unroll
-      for (int ld = 0; ld < NL; ++ld) {
-        const uint64_t o = gl ^ gt[kBlockedGTabWave + wave * 8 + itl * NL + ld];
-        V* const p = (o & kBlockedPlaneBit) ? vim : vre;
-        __builtin_nontemporal_store(t[ld], p + (base_prev | (o & ~kBlockedPlaneBit)));
-      }
+      for (int ld = 0; ld < NL; ++ld) t[(itl + 1) & 1][ld] = *reinterpret_cast<LdsV*>((uintptr_t)(Ltv[itl + 1] ^ OFF[ld]));
     }
+    __builtin_amdgcn_sched_barrier(0);
     Acc acc[NCB];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf) acc[cf] = Acc{0, 0, 0, 0};
@@ -1175,6 +1177,15 @@ __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, co
         acc[cf] = Mfma<T>::run(a[s], pf[itl * NL + ld][comp], acc[cf]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (have_prev) {  // the finished amplitudes of the previous tile leave from the slots this iteration overwrites
+#pragma unroll
+      for (int ld = 0; ld < NL; ++ld) {
+        const uint64_t o = gl ^ gt[kBlockedGTabWave + wave * 8 + itl * NL + ld];
+        V* const p = (o & kBlockedPlaneBit) ? vim : vre;
+        __builtin_nontemporal_store(t[itl & 1][ld], p + (base_prev | (o & ~kBlockedPlaneBit)));
+      }
+    }
 #pragma unroll
     for (int ld = 0; ld < NL; ++ld) {
       V y;
@@ -1184,7 +1195,7 @@ __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, co
         const int so = ck | (ld << KV);
         y[comp] = acc[cf][so & 3];
       }
-      *reinterpret_cast<LdsV*>((uintptr_t)addr[ld]) = y;
+      *reinterpret_cast<LdsV*>((uintptr_t)(Lt ^ OFF[ld])) = y;
     }
   }
   // the prefetch registers stay allocated to the end of the gate: were the store-out data of a later iteration to reuse
