@@ -869,41 +869,52 @@ __device__ __forceinline__ void blocked_inner_gate_valu(T* __restrict__ xr, T* _
   }
 }
 
+// The four descriptor words of a gate that the gate loop itself needs (BlockedGate::a_off .. wave_bits: one 16-byte scalar
+// load).  The loop requests the NEXT gate's descriptor before it runs the current gate: read at the top of a gate, the
+// scalar-cache round trip and the kind dispatch behind it stood in front of every gate's first LDS request.
+struct BlockedDesc {
+  unsigned a_off, kv, n_addr, wave_bits;
+};
+__device__ __forceinline__ BlockedDesc blocked_desc(const BlockedGate* __restrict__ gates, const unsigned gi) {
+  const BlockedGate& G = gates[gi];
+  return BlockedDesc{G.a_off, G.kv, G.n_addr, G.wave_bits};
+}
+
 // One inner gate of a pass by its kind (G.kv: KBITS * 4 + VMASK for the matrix-core form, 64 + k * 4 + VMASK for the
 // register butterflies).
 template <typename T, int BLOCK, bool ALDS>
-__device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, const unsigned gi, T* __restrict__ xr,
-                                                      T* __restrict__ xi, const T* __restrict__ als,
+__device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, const BlockedDesc D, const unsigned gi,
+                                                      T* __restrict__ xr, T* __restrict__ xi, const T* __restrict__ als,
                                                       const T* __restrict__ Atab, const BlockedTabT* __restrict__ tabs,
                                                       const unsigned tvb) {
   constexpr unsigned CB = Vec<T>::VB;
-  const T* A = ALDS ? als + G.a_off : Atab + G.a_off;
+  const T* A = ALDS ? als + D.a_off : Atab + D.a_off;
 #define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
   do {                                                                                                  \
     if constexpr (ALDS)                                                                                 \
-      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * BlockedTab<BLOCK>::kWords, (1u << (tvb - G.n_addr)) >> 4);       \
+      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * BlockedTab<BLOCK>::kWords, (1u << (tvb - D.n_addr)) >> 4);       \
     else                                                                                                \
       blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
   } while (0)
-  switch (G.kv) {
+  switch (D.kv) {
     case 16: HQ_BLOCKED_MFMA_GATE(4, 0); break;
     case 17: HQ_BLOCKED_MFMA_GATE(4, 1); break;
     case 20: HQ_BLOCKED_MFMA_GATE(5, 0); break;
     case 21: HQ_BLOCKED_MFMA_GATE(5, 1); break;
-    case 64 + 4 + 0: blocked_inner_gate_valu<T, 1, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-    case 64 + 4 + 1: blocked_inner_gate_valu<T, 1, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-    case 64 + 8 + 0: blocked_inner_gate_valu<T, 2, 0, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-    case 64 + 8 + 1: blocked_inner_gate_valu<T, 2, 1, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+    case 64 + 4 + 0: blocked_inner_gate_valu<T, 1, 0, BLOCK>(xr, xi, G, Atab + D.a_off, tvb); break;
+    case 64 + 4 + 1: blocked_inner_gate_valu<T, 1, 1, BLOCK>(xr, xi, G, Atab + D.a_off, tvb); break;
+    case 64 + 8 + 0: blocked_inner_gate_valu<T, 2, 0, BLOCK>(xr, xi, G, Atab + D.a_off, tvb); break;
+    case 64 + 8 + 1: blocked_inner_gate_valu<T, 2, 1, BLOCK>(xr, xi, G, Atab + D.a_off, tvb); break;
     default:
       if constexpr (CB == 2) {
-        switch (G.kv) {
+        switch (D.kv) {
           case 18: HQ_BLOCKED_MFMA_GATE(4, 2); break;
           case 19: HQ_BLOCKED_MFMA_GATE(4, 3); break;
           case 22: HQ_BLOCKED_MFMA_GATE(5, 2); break;
           case 23: HQ_BLOCKED_MFMA_GATE(5, 3); break;
-          case 64 + 4 + 2: blocked_inner_gate_valu<T, 1, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-          case 64 + 8 + 2: blocked_inner_gate_valu<T, 2, 2, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
-          case 64 + 8 + 3: blocked_inner_gate_valu<T, 2, 3, BLOCK>(xr, xi, G, Atab + G.a_off, tvb); break;
+          case 64 + 4 + 2: blocked_inner_gate_valu<T, 1, 2, BLOCK>(xr, xi, G, Atab + D.a_off, tvb); break;
+          case 64 + 8 + 2: blocked_inner_gate_valu<T, 2, 2, BLOCK>(xr, xi, G, Atab + D.a_off, tvb); break;
+          case 64 + 8 + 3: blocked_inner_gate_valu<T, 2, 3, BLOCK>(xr, xi, G, Atab + D.a_off, tvb); break;
           default: break;
         }
       }
@@ -1019,12 +1030,14 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
       }
     }
     __syncthreads();
+    BlockedDesc D = blocked_desc(gates, 0);
     for (unsigned gi = 0; gi < ngates; ++gi) {
-      const BlockedGate& G = gates[gi];
-      blocked_dispatch_gate<T, BLOCK, ALDS>(G, gi, xr, xi, als, Atab, tabs, tvb);
+      const BlockedDesc Dn = blocked_desc(gates, gi + 1 < ngates ? gi + 1 : gi);  // in flight while this gate runs
+      blocked_dispatch_gate<T, BLOCK, ALDS>(gates[gi], D, gi, xr, xi, als, Atab, tabs, tvb);
       // gates of one barrier-free group touch, wave by wave, the same part of the tile (same `wave_bits`): a wave only
       // needs its OWN stores to have landed (LDS operations of a wave complete in order; the gate ends with lgkmcnt(0))
-      if (!(ALDS && (G.wave_bits & kBlockedNoBarrier))) __syncthreads();
+      if (!(ALDS && (D.wave_bits & kBlockedNoBarrier))) __syncthreads();
+      D = Dn;
     }
     if constexpr (PREF) {
       V sr[NPV], si[NPV];  // all LDS reads in flight before the first store (the gates' registers are free here)
@@ -1280,10 +1293,12 @@ apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const Blocke
     const uint64_t nb = next_base(base);
     prefetch(tile + stride < ntiles ? nb : base);  // past the end: a repeat of this tile, never used
     if (!(G0.wave_bits & kBlockedNoBarrier)) __syncthreads();
+    BlockedDesc D = blocked_desc(gates, 1);  // (the host takes passes of at least two gates)
     for (unsigned gi = 1; gi < ngates; ++gi) {
-      const BlockedGate& G = gates[gi];
-      blocked_dispatch_gate<T, BLOCK, true>(G, gi, xr, xi, als, Atab, tabs, tvb);
-      if (!(G.wave_bits & kBlockedNoBarrier)) __syncthreads();
+      const BlockedDesc Dn = blocked_desc(gates, gi + 1 < ngates ? gi + 1 : gi);
+      blocked_dispatch_gate<T, BLOCK, true>(gates[gi], D, gi, xr, xi, als, Atab, tabs, tvb);
+      if (!(D.wave_bits & kBlockedNoBarrier)) __syncthreads();
+      D = Dn;
     }
     base_prev = base;
     have_prev = true;
