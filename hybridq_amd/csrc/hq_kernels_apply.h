@@ -2,6 +2,7 @@
 // matrix-core role kernels (k <= 4, k = 5/6), the cache-blocked many-gates-per-pass kernel, the k >= 7 tile GEMM,
 // the generic LDS-tile kernel and the tiny-state fallback.  Overview in hq_kernels_common.h.
 #pragma once
+#include <type_traits>
 #include "hq_kernels_common.h"
 
 // Pins a wave-uniform value to scalar registers (stops the optimiser from hoisting per-lane copies of it out of a loop).
@@ -617,9 +618,11 @@ __device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ t
   }
 }
 
-template <typename T, int KBITS, int VMASK, int BLOCK>
+// (BlockedPre, further down: the table words a gate needs first, requested one gate early; BlockedNoPre: read them here)
+struct BlockedNoPre {};
+template <typename T, int KBITS, int VMASK, int BLOCK, typename PRE>
 __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
-                                                       const BlockedTabT* __restrict__ tab, const unsigned niter) {
+                                                       const BlockedTabT* __restrict__ tab, const unsigned niter, const PRE& P) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
   constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;
@@ -636,9 +639,21 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
   for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
-  L = tab[BlockedTab<BLOCK>::kLane + lane];
+  constexpr bool kPre = !__is_same(PRE, BlockedNoPre);
+  unsigned t_first, t_second;
+  if constexpr (kPre) {  // requested one gate early
+    L = P.L;
+    t_first = P.t0;
+    t_second = P.t1;
 #pragma unroll
-  for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[BlockedTab<BLOCK>::kOff + ld];
+    for (int ld = 0; ld < NL; ++ld) OFF[ld] = ld < 4 ? P.off[ld < 4 ? ld : 0] : tab[BlockedTab<BLOCK>::kOff + ld];
+  } else {
+    L = tab[BlockedTab<BLOCK>::kLane + lane];
+    t_first = tab[BlockedTab<BLOCK>::kIter + wave];
+    t_second = tab[BlockedTab<BLOCK>::kIter + wave + (1u << WB)];
+#pragma unroll
+    for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[BlockedTab<BLOCK>::kOff + ld];
+  }
   typedef __attribute__((address_space(3))) V LdsV;  // addresses are absolute LDS byte addresses (base folded in LANE)
   // multiply-accumulate of one wave-iteration whose vectors are in x, results to the slots they came from (Lt ^ OFF[ld]).
   // Component c of vector ld sits in accumulator block (cf, so >> 2), register so & 3: a 16-byte store wants 4
@@ -723,7 +738,7 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
       // front of every iteration's first request); the index is clamped, an entry read past the last iteration is unused
       auto entry = [&](const unsigned i) { return tab[BlockedTab<BLOCK>::kIter + (i < niter ? i : wave)]; };
       V x0[NL], x1[NL];
-      unsigned Lt0 = L ^ entry(it), Lt1 = 0, t_next = entry(it + STEP);
+      unsigned Lt0 = L ^ t_first, Lt1 = 0, t_next = t_second;
       request(x0, Lt0);
       // The requests of the next iteration are UNCONDITIONAL: on a path without them the compiler's wait counts for the
       // set being multiplied are those of "nothing requested since" (lgkmcnt counts in order), and merged over both
@@ -757,7 +772,7 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
   } else if constexpr (NL <= 4) {  // all requests of the iteration in front of its first MFMA
     for (unsigned it = wave; it < niter; it += STEP) {
       V x[NL];
-      const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + it];
+      const unsigned Lt = L ^ (it == wave ? t_first : tab[BlockedTab<BLOCK>::kIter + it]);
       request(x, Lt);
       __builtin_amdgcn_sched_barrier(0);
       multiply(x, Lt);
@@ -765,7 +780,7 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
   } else {
     static_assert(KV == 0, "eight vectors per wave-iteration: no component target");
     for (unsigned it = wave; it < niter; it += STEP) {
-      const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + it];
+      const unsigned Lt = L ^ (it == wave ? t_first : tab[BlockedTab<BLOCK>::kIter + it]);
       Acc acc[NCB][NRB];
 #pragma unroll
       for (int cf = 0; cf < NCB; ++cf)
@@ -880,10 +895,36 @@ __device__ __forceinline__ BlockedDesc blocked_desc(const BlockedGate* __restric
   return BlockedDesc{G.a_off, G.kv, G.n_addr, G.wave_bits};
 }
 
+// The table words every matrix-core gate needs before it can request its first vectors -- the lane part, the entries of
+// this wave's first two iterations and the first four register-digit offsets -- requested from LDS one gate EARLY (at the
+// top of the previous gate, next to the descriptor): a gate then starts with its first vector requests instead of with an
+// LDS round trip for their addresses.  (Entries past a gate's last iteration are read but unused: wave + STEP is always
+// inside the ITER part of the table.)
+struct BlockedPre {
+  unsigned L, t0, t1, off[4];
+};
+template <int BLOCK, typename PRE>
+__device__ __forceinline__ PRE blocked_pre(const BlockedTabT* __restrict__ tabs, const unsigned gi) {
+  if constexpr (__is_same(PRE, BlockedNoPre)) return BlockedNoPre{};
+  else {
+  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
+  const BlockedTabT* __restrict__ tab = tabs + gi * BlockedTab<BLOCK>::kWords;
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  BlockedPre P;
+  P.L = tab[BlockedTab<BLOCK>::kLane + lane];
+  P.t0 = tab[BlockedTab<BLOCK>::kIter + wave];
+  P.t1 = tab[BlockedTab<BLOCK>::kIter + wave + (1u << WB)];
+#pragma unroll
+  for (int ld = 0; ld < 4; ++ld) P.off[ld] = tab[BlockedTab<BLOCK>::kOff + ld];
+  return P;
+  }
+}
+
 // One inner gate of a pass by its kind (G.kv: KBITS * 4 + VMASK for the matrix-core form, 64 + k * 4 + VMASK for the
 // register butterflies).
-template <typename T, int BLOCK, bool ALDS>
-__device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, const BlockedDesc D, const unsigned gi,
+template <typename T, int BLOCK, bool ALDS, typename PRE>
+__device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, const BlockedDesc D, const PRE& P, const unsigned gi,
                                                       T* __restrict__ xr, T* __restrict__ xi, const T* __restrict__ als,
                                                       const T* __restrict__ Atab, const BlockedTabT* __restrict__ tabs,
                                                       const unsigned tvb) {
@@ -892,7 +933,7 @@ __device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, cons
 #define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
   do {                                                                                                  \
     if constexpr (ALDS)                                                                                 \
-      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * BlockedTab<BLOCK>::kWords, (1u << (tvb - D.n_addr)) >> 4);       \
+      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * BlockedTab<BLOCK>::kWords, (1u << (tvb - D.n_addr)) >> 4, P); \
     else                                                                                                \
       blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
   } while (0)
@@ -1031,9 +1072,14 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     }
     __syncthreads();
     BlockedDesc D = blocked_desc(gates, 0);
+    // (complex128: no registers left beside the tile prefetch for the words of the next gate)
+    using Pre = typename std::conditional<ALDS && sizeof(T) == 4, BlockedPre, BlockedNoPre>::type;
+    Pre P = blocked_pre<BLOCK, Pre>(tabs, 0);
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedDesc Dn = blocked_desc(gates, gi + 1 < ngates ? gi + 1 : gi);  // in flight while this gate runs
-      blocked_dispatch_gate<T, BLOCK, ALDS>(gates[gi], D, gi, xr, xi, als, Atab, tabs, tvb);
+      const Pre Pn = blocked_pre<BLOCK, Pre>(tabs, gi + 1 < ngates ? gi + 1 : gi);
+      blocked_dispatch_gate<T, BLOCK, ALDS>(gates[gi], D, P, gi, xr, xi, als, Atab, tabs, tvb);
+      P = Pn;
       // gates of one barrier-free group touch, wave by wave, the same part of the tile (same `wave_bits`): a wave only
       // needs its OWN stores to have landed (LDS operations of a wave complete in order; the gate ends with lgkmcnt(0))
       if (!(ALDS && (D.wave_bits & kBlockedNoBarrier))) __syncthreads();
@@ -1294,9 +1340,13 @@ apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const Blocke
     prefetch(tile + stride < ntiles ? nb : base);  // past the end: a repeat of this tile, never used
     if (!(G0.wave_bits & kBlockedNoBarrier)) __syncthreads();
     BlockedDesc D = blocked_desc(gates, 1);  // (the host takes passes of at least two gates)
+    using Pre = typename std::conditional<sizeof(T) == 4, BlockedPre, BlockedNoPre>::type;
+    Pre P = blocked_pre<BLOCK, Pre>(tabs, 1);
     for (unsigned gi = 1; gi < ngates; ++gi) {
       const BlockedDesc Dn = blocked_desc(gates, gi + 1 < ngates ? gi + 1 : gi);
-      blocked_dispatch_gate<T, BLOCK, true>(gates[gi], D, gi, xr, xi, als, Atab, tabs, tvb);
+      const Pre Pn = blocked_pre<BLOCK, Pre>(tabs, gi + 1 < ngates ? gi + 1 : gi);
+      blocked_dispatch_gate<T, BLOCK, true>(gates[gi], D, P, gi, xr, xi, als, Atab, tabs, tvb);
+      P = Pn;
       if (!(D.wave_bits & kBlockedNoBarrier)) __syncthreads();
       D = Dn;
     }
