@@ -516,6 +516,10 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
       addr[ld] = Lt ^ OFF[ld];
       x[ld] = *reinterpret_cast<V*>(tile + addr[ld]);
     }
+    // all requests of the iteration stay in front of its first MFMA (left alone the compiler sinks each read to its
+    // consumers and waits for it there: see blocked_inner_gate_tab); the 8-vector shape keeps the compiler's order --
+    // it has no registers for more
+    if constexpr (NL <= 4) __builtin_amdgcn_sched_barrier(0);
     Acc acc[NCB][NRB];
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf)
