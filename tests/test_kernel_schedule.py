@@ -1,0 +1,72 @@
+"""Static checks on the ORDER of instructions in the gfx950 assembly of the cache-blocked kernels (no GPU needed: hipcc -S).
+
+Instruction counts and register budgets (tests/test_kernel_resources.py) did not show what cost the cache-blocked pass a
+quarter of its matrix-core time for three rounds: the compiler sinks LDS reads to their consumers, and the wait in between
+puts an LDS round trip in front of every 4-8 MFMAs.  The source now pins the requests ahead of the MFMAs
+(blocked_inner_gate_tab); this test keeps it that way -- a compiler or source change that serialises the
+loops again shows up here as "reads awaited in front of MFMAs" per MFMA going back up (old loop: 0.13, pipelined: 0.03) --
+and keeps the direct first gate free of vector-memory waits behind its stores."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def kernels(tmp_path_factory):
+    asm = str(tmp_path_factory.mktemp('isa') / 'hq_apply.s')
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
+                           os.path.join(ROOT, 'hybridq_amd', 'csrc', 'hq_apply.hip'), '-o', asm], stderr=subprocess.DEVNULL)
+    funcs = re.split(r'\n(?=\s*\.globl\s)', open(asm).read())
+    named = [(m.group(1), f) for f in funcs for m in [re.search(r'\.globl\s+(\S+)', f)] if m]
+    dem = subprocess.run(['c++filt'], input='\n'.join(n for n, _ in named), capture_output=True, text=True).stdout.splitlines()
+    return {re.sub(r'\(.*$', '', d).replace('void hq::', ''): f for (_, f), d in zip(named, dem)}
+
+
+def _instructions(body):
+    return [ln.strip() for ln in body.splitlines() if re.match(r'^\s+[a-z]', ln)]
+
+
+def _awaited_reads(body):
+    """LDS vector reads waited for with lgkmcnt(0) before any MFMA was issued behind them, with MFMAs right behind the wait."""
+    ins, n = _instructions(body), 0
+    for i, ln in enumerate(ins):
+        if ln.startswith(('ds_read_b128', 'ds_read_b64 ')):
+            j = i + 1
+            while j < len(ins) and j < i + 6 and not ins[j].startswith(('v_mfma', 's_waitcnt', 's_cbranch', 's_barrier')):
+                j += 1
+            if j < len(ins) and ins[j].startswith('s_waitcnt') and 'lgkmcnt(0)' in ins[j]:
+                k = j + 1
+                while k < len(ins) and k < j + 4 and not ins[k].startswith(('v_mfma', 'ds_', 's_cbranch')):
+                    k += 1
+                n += k < len(ins) and ins[k].startswith('v_mfma')
+    return n
+
+
+@pytest.mark.parametrize('name', ['apply_blocked_kernel<float, 512, true, true>', 'apply_blocked_kernel<double, 512, true, true>',
+                                  'apply_blocked_kernel<float, 1024, true, true>', 'apply_blocked_direct_kernel<float, 512>',
+                                  'apply_blocked_direct_kernel<double, 512>'])
+def test_lds_reads_stay_ahead_of_the_matrix_cores(kernels, name):
+    body = kernels[name]
+    mfma = sum(ln.startswith('v_mfma') for ln in _instructions(body))
+    awaited = _awaited_reads(body)
+    assert mfma >= 100 and awaited / mfma <= 0.06, (name, awaited, mfma)
+
+
+@pytest.mark.parametrize('name', ['apply_blocked_direct_kernel<float, 512>', 'apply_blocked_direct_kernel<double, 512>',
+                                  'apply_blocked_direct_kernel<float, 1024>'])
+def test_direct_first_gate_never_drains_its_stores(kernels, name):
+    """One s_waitcnt vmcnt(0) per tile, in front of the first gate (the prefetch is a tile old there); none between the
+    gate's global stores and the next prefetch; the rest are the kernel preamble and the linear store of the last tile."""
+    ins = _instructions(kernels[name])
+    assert sum(ln.startswith('s_waitcnt') and 'vmcnt(0)' in ln for ln in ins) <= 6, name
+    stores = [i for i, ln in enumerate(ins) if ln.startswith('global_store')]
+    loads = [i for i, ln in enumerate(ins) if ln.startswith('global_load_dwordx4')]
+    gate_stores = [i for i in stores if any(j > i for j in loads)]  # stores with a prefetch behind them = the first gate's
+    assert gate_stores
+    nxt = min(j for j in loads if j > gate_stores[-1])
+    between = ins[gate_stores[-1]:nxt]
+    assert not [ln for ln in between if ln.startswith('s_waitcnt') and 'vmcnt' in ln], [ln for ln in between if 'vmcnt' in ln]
