@@ -880,8 +880,6 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   static int a_in_lds = env_int("HQ_BLOCKED_ALDS", 1);
   // LDS left per workgroup behind the tile when `per_cu` workgroups share a CU
   const size_t a_budget = (160 * 1024) / per_cu - tile_bytes > 2048 ? (160 * 1024) / per_cu - tile_bytes - 1024 : 0;
-  // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
-  // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
   // HQ_BLOCKED_BIG=1 (opt-in until measured): tiles of 2^14 (f32) / 2^13 (f64) amplitudes = 128 KiB, ONE workgroup of
   // 1024 threads per CU (16 waves: the same four per SIMD as two 512-thread workgroups) with the register prefetch, the
   // barrier-free groups (four wave bits) and the direct first gate -- 25 instead of 28 passes on the n = 30 benchmark plan
@@ -899,6 +897,8 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   bool iter_ok = true;
   for (const BlockedGate& G : gates)
     if (G.kv < 64 && ((1u << (tb - CB - G.n_addr)) >> 4) > (big ? BlockedTab<1024>::kNIter : BlockedTab<512>::kNIter)) iter_ok = false;
+  // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
+  // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
   const bool fits = a_in_lds && iter_ok && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
   // register prefetch of the next tile (512 threads, 4 vectors per thread and plane = 13 (f32) / 12 (f64) tile bits;
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
