@@ -78,7 +78,21 @@ EMU_SLOW = ('apply_U_mfma_kernels', 'randomized_differential', 'apply_U_gemm_ker
             'sharded_api', 'test_gpu_determinism')
 
 
+#: order of the `-m gpu` files under `-x`: the per-call oracle tests (which pin U::apply and swap_array) first, then the
+#: reference-recorded vectors, the circuit-level parity files, the full-size and sharded runs, and last the files whose
+#: subject is the newest kernel code, so that a fault there cannot hide the oracle tests behind it
+GPU_FILE_ORDER = ('test_gpu_parity.py', 'test_gpu_golden.py', 'test_gpu_round2.py', 'test_gpu_round3.py',
+                  'test_gpu_depth_parity.py', 'test_gpu_fullsize.py', 'test_gpu_dist.py', 'test_gpu_determinism.py',
+                  'test_gpu_round4.py', 'test_gpu_upstream_mirrors.py', 'test_gpu_zz_guard_bands.py')
+
+
+def _file_rank(item):
+    name = os.path.basename(str(item.fspath))
+    return GPU_FILE_ORDER.index(name) if name in GPU_FILE_ORDER else -1   # CPU files keep their place in front
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_file_rank)   # stable: the order inside a file is untouched
     if not EMU_SUITE:
         return
     quick = os.environ.get('HQ_EMU_QUICK') == '1'
