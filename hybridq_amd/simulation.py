@@ -754,6 +754,24 @@ def _plan_key(circuit, qubits, n, ctype, auto_schedule, compress, blocked):
     return h.digest()
 
 
+def _own_matrices(gates):
+    """The op list with every matrix a private read-only copy.  A plan may carry the CALLER's arrays (compress=0, the
+    gate-by-gate plan of the auto-schedule, unfused inner gates of a cache-blocked pass, `gate.matrix()` objects that
+    hand out an internal buffer): kept by content digest, an in-place update of those arrays between two calls (a
+    parameter scan) would leave new values under the old key."""
+    def own(U):
+        U = np.array(U, copy=True)
+        U.setflags(write=False)
+        return U
+    out = []
+    for g in gates:  # no FunctionalGates here: _plan_key returns None for such circuits
+        if isinstance(g[0], str):
+            out.append(('B', g[1], [(own(U), p) for U, p in g[2]]) + tuple(g[3:]) if g[0] == 'B' else (g[0], own(g[1]), g[2]) + tuple(g[3:]))
+        else:
+            out.append((g[0], own(g[1])) + tuple(g[2:]))
+    return out
+
+
 def _execute_ops(state, gates):
     """The gate loop (simulation.py:522-646); returns the number of passes over the state."""
     n = state.n
@@ -890,7 +908,7 @@ def simulate(circuit, initial_state=None, final_state=None, optimize='evolution'
             else:
                 gates = _plan_ops(circuit, qubits, n, ctype, kwargs['compress'], kwargs.get('blocked', False))
         if key is not None:
-            _PLAN_CACHE[key] = (gates, dict(schedule_info) if schedule_info is not None else None)
+            _PLAN_CACHE[key] = (_own_matrices(gates), dict(schedule_info) if schedule_info is not None else None)
             while len(_PLAN_CACHE) > PLAN_CACHE_SIZE:
                 _PLAN_CACHE.popitem(last=False)
     host_ms['plan'] = 1e3 * (time.perf_counter() - _t)

@@ -226,3 +226,30 @@ def test_plans_are_cached_by_circuit_content(numpy_device):
     assert len(sim._PLAN_CACHE) == 2
     _, info5 = sim.simulate(gates, compress=4, **{k: v for k, v in kw.items() if k != 'optimize'}, optimize='evolution-hybridq')
     assert 'schedule' not in info5 and len(sim._PLAN_CACHE) == 3
+
+
+@pytest.mark.parametrize('kw', [dict(compress=0), dict(optimize='evolution'), dict(blocked=True)])
+def test_cached_plans_do_not_alias_the_callers_matrices(numpy_device, kw):
+    """A parameter scan that updates its matrices IN PLACE between calls: the plan kept under the first content digest
+    must keep the first values (compress=0 and the gate-by-gate plan used to store the caller's own arrays,
+    so a later circuit equal to the first one came back with the second one's amplitudes)."""
+    from hybridq_amd import simulation as sim
+    from hybridq_amd.circuits import rqc_1q2q
+    sim._PLAN_CACHE.clear()
+    n = 14
+    gates = [(np.array(U, dtype='complex128'), q) for U, q in rqc_1q2q(n, depth=4, seed=5)]
+    v1 = [(U.copy(), q) for U, q in gates]
+    run = dict(dict(initial_state='0' * n, complex_type='complex128', qubits=list(range(n)), simplify=False), **kw)
+    psi1 = sim.simulate(gates, **run)
+    rng = np.random.default_rng(1)
+    for U, _ in gates:  # in place: same objects, new values
+        U *= np.exp(2j * np.pi * rng.random())
+        U[0, :] *= -1
+    psi2 = sim.simulate(gates, **run)
+    assert np.abs(psi2 - psi1).max() > 1e-3
+    psi3 = sim.simulate(v1, **run)  # fresh arrays equal to the first circuit: a cache hit on the first key
+    assert np.array_equal(psi3, psi1)
+    for plan, _ in sim._PLAN_CACHE.values():
+        for op in plan:
+            mats = [U for U, _ in op[2]] if op[0] == 'B' else [op[1]]
+            assert not any(np.shares_memory(M, U) for M in mats for U, _ in gates)
