@@ -236,12 +236,15 @@ def parity_check(complex_type, depth, n=24):
 
 def blocked_variants(n, complex_type):
     """tools/ab_blocked.py (plan + 1 warm-up + 3 timed cache-blocked steps of the depth-40 generator circuit at n qubits) once
-    per switch setting: the default (barrier-free wave groups), one barrier per inner gate, the tile movement folded into
-    the first gate, 128 KiB tiles on one 1024-thread workgroup, both, and (a planner setting, not a kernel) one forced low
+    per switch setting: the default (pipelined inner gates, barrier-free wave groups), one barrier per inner gate, the old
+    inner-gate loops, both (= the kernels of round 2), the tile movement folded into the first gate, 128 KiB tiles on one 1024-thread workgroup, both, and (a planner setting, not a kernel) one forced low
     tile bit less.  Never raises."""
     import subprocess
     tb = 13 if complex_type == 'complex64' else 12
-    settings = [('default', {}, tb), ('groups_off', {'HQ_BLOCKED_GROUPS': '0'}, tb), ('direct', {'HQ_BLOCKED_DIRECT': '1'}, tb),
+    settings = [('default', {}, tb), ('groups_off', {'HQ_BLOCKED_GROUPS': '0'}, tb),
+                # the inner-gate loops of rounds 2-4a (LDS reads where the compiler puts them) / the kernels GPUTEST_r02 saw
+                ('pipe_off', {'HQ_BLOCKED_PIPE': '0'}, tb), ('round2_kernels', {'HQ_BLOCKED_PIPE': '0', 'HQ_BLOCKED_GROUPS': '0'}, tb),
+                ('direct', {'HQ_BLOCKED_DIRECT': '1'}, tb),
                 ('big_tiles', {'HQ_BLOCKED_BIG': '1'}, tb + 1), ('big_tiles_direct', {'HQ_BLOCKED_BIG': '1', 'HQ_BLOCKED_DIRECT': '1'}, tb + 1),
                 # one forced low tile bit less = 64-byte runs per plane instead of whole 128-byte lines: 26 instead of 28 passes
                 ('low_bits_minus_1', {'HQ_AB_LOW_BITS': str(4 if complex_type == 'complex64' else 3)}, tb)]
@@ -249,8 +252,6 @@ def blocked_variants(n, complex_type):
     for name, env, bits in settings:
         try:
             cmd = [sys.executable, os.path.join(ROOT, 'tools', 'ab_blocked.py'), str(n), complex_type, str(bits), 'json']
-            if os.environ.get('HQ_EMU_GPU_SUITE') == '1':  # the CPU suite's end-to-end run of this file (tests/emu): same launcher
-                cmd[1:1] = [os.path.join(ROOT, 'tests', 'emu', 'run_emulated.py')]
             r = subprocess.run(cmd,
                                env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

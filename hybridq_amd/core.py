@@ -158,6 +158,13 @@ _exchange = {
                                             ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int))
     for b in (32, 64)
 }
+_exchange_rounds = {
+    np.dtype(f'float{b}'): _define_function(_lib, f'hq_exchange_rounds_float{b}', ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint32),
+                                            ctypes.c_uint, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint))
+    for b in (32, 64)
+}
+_exchange_round_wait = _define_function(_lib, 'hq_exchange_round_wait', ctypes.c_int, ctypes.c_uint)
 
 _alloc = _define_function(_lib, 'hq_alloc', ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64, ctypes.c_int)
 _free = _define_function(_lib, 'hq_free', ctypes.c_int, ctypes.c_void_p)
@@ -204,9 +211,10 @@ EXPORTED = [
     'hq_program_begin', 'hq_program_end', 'hq_program_size', 'hq_program_run', 'hq_program_free',
     'hq_shard_unique_id', 'hq_shard_load_rccl', 'hq_shard_init_rccl', 'hq_shard_attach_rccl', 'hq_shard_init_p2p', 'hq_shard_p2p_register',
     'hq_shard_info', 'hq_shard_free', 'hq_shard_rccl_selftest', 'hq_ipc_export', 'hq_ipc_open', 'hq_ipc_close',
-    'hq_exchange_float32', 'hq_exchange_float64', 'hq_alloc', 'hq_free', 'hq_alloc_mapped', 'hq_alloc_scattered',
+    'hq_exchange_float32', 'hq_exchange_float64', 'hq_exchange_rounds_float32', 'hq_exchange_rounds_float64', 'hq_exchange_round_wait', 'hq_alloc', 'hq_free', 'hq_alloc_mapped', 'hq_alloc_scattered',
     'hq_alloc_state', 'hq_free_state', 'hq_state_info', 'hq_state_pool_trim',
     'hq_plan_blocked', 'hq_plan_counts', 'hq_plan_read', 'hq_plan_free', 'hq_plan_simplify', 'hq_plan_fuse',
+    'hq_blocked_selfcheck',
 ]
 
 
@@ -497,6 +505,29 @@ def exchange(src_re, src_im, dst_re, dst_im, perm=None, n_local=None):
     return bool(where.value)
 
 
+def exchange_rounds(src_re, src_im, dst_re, dst_im, perm=None, n_local=None, sub_bits=2):
+    """One qubit exchange in 2^sub_bits rounds (hq_exchange_rounds_*): returns (result in the SRC planes?, number of
+    rounds); the library stream has not waited for any of them -- exchange_round_wait(s) before touching the pieces of round s."""
+    ft = _float_dtype(src_re)
+    m = _n_qubits(src_re) if n_local is None else int(n_local)
+    pp = None
+    if perm is not None:
+        perm = np.ascontiguousarray(perm, dtype=np.uint32)
+        if len(perm) != m:
+            raise ValueError("'perm' must have one entry per local index bit")
+        pp = perm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    where, rounds = ctypes.c_int(0), ctypes.c_uint(0)
+    rc = _exchange_rounds[ft](_ptr(src_re), _ptr(src_im), _ptr(dst_re), _ptr(dst_im), m, pp, int(sub_bits), ctypes.byref(where),
+                              ctypes.byref(rounds))
+    _check(rc, 'exchange_rounds')
+    return bool(where.value), int(rounds.value)
+
+
+def exchange_round_wait(round_index):
+    """The library stream waits for round `round_index` of the last exchange_rounds call."""
+    _check(_exchange_round_wait(int(round_index)), 'exchange_round_wait')
+
+
 class DeviceBuffer:
     """Device memory from hq_alloc, visible to torch through ``__cuda_array_interface__``
     (``torch.as_tensor(buf, device='cuda')`` aliases it; the buffer must outlive the tensor --
@@ -685,6 +716,19 @@ def apply_blocked(psi_re, psi_im, tile_pos, gates=None, n_qubits=None, packed=No
     rc = _apply_blocked[ft](_ptr(psi_re), _ptr(psi_im), n, tile_pos.ctypes.data_as(U32P), len(tile_pos),
                             len(k_all), U_all.ctypes.data, pos_all.ctypes.data_as(U32P), k_all.ctypes.data_as(U32P))
     _check(rc, 'apply_blocked')
+
+
+_blocked_selfcheck = _define_function(_lib, 'hq_blocked_selfcheck', ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                      ctypes.POINTER(ctypes.c_int))
+
+
+def blocked_selfcheck():
+    """What the library's cross-check of the cache-blocked kernel variants has seen so far in this process
+    (include/hq_hip.h: hq_blocked_selfcheck): checks run / failed and which variants are currently on."""
+    runs, failures, sw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _check(_blocked_selfcheck(ctypes.byref(runs), ctypes.byref(failures), ctypes.byref(sw)), 'hq_blocked_selfcheck')
+    return {'runs': runs.value, 'failures': failures.value, 'pipe': bool(sw.value & 1), 'groups': bool(sw.value & 2),
+            'direct': bool(sw.value & 4), 'big': bool(sw.value & 8)}
 
 
 class Program:

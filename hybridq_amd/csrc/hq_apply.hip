@@ -469,12 +469,6 @@ template <typename T, int RBW, int CBW>
 static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned* dOff, const GemmArg& a,
                           uint64_t ntiles) {
   const size_t lds = (size_t)2 * sizeof(T) << a.tb;
-  static bool attr_done = false;  // under the context mutex
-  if (!attr_done) {
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW, 0>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr_done = true;
-  }
   const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 2048);
   // register prefetch of the next tile where the tile has the usual size of this wave shape and the registers allow
   // (not the 8 x 1 shape of k = 10: 224 + 64 registers); HQ_GEMM_PREF=0 switches it off
@@ -482,19 +476,26 @@ static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned*
   constexpr int NPVx = sizeof(T) == 4 ? (CBW == 2 && RBW == 1 ? 2 : 0)  // f32: k = 7 only (2 x 2, k = 8: no gain, -3 % for some positions; 4 x 2 would spill)
                                      : (CBW == 1 ? (RBW == 1 ? 2 : (RBW == 2 ? 4 : (RBW == 4 ? 8 : 0))) : 0);
   static const int use_pref = env_int("HQ_GEMM_PREF", 1);
+  // operands requested ahead of the matrix cores (round 4; HQ_GEMM_PIPE=0: the loop of rounds 1-4a, for A/B on one build)
+  static const int use_pipe = env_int("HQ_GEMM_PIPE", 1);
+  constexpr bool kCanPipe = gemm_can_pipe<T, RBW, CBW>();
+  static bool attr_done = false;  // under the context mutex
+  if (!attr_done) {
+    const void* fns[] = {(const void*)apply_gemm_kernel<T, RBW, CBW, 0, false>, (const void*)apply_gemm_kernel<T, RBW, CBW, 0, kCanPipe>,
+                         (const void*)apply_gemm_kernel<T, RBW, CBW, NPVx, false>, (const void*)apply_gemm_kernel<T, RBW, CBW, NPVx, kCanPipe>};
+    for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done = true;
+  }
+  const bool pipe = use_pipe && kCanPipe;
   if constexpr (NPVx > 0) {
     if (use_pref && ((1u << (a.tb - CBv)) == (unsigned)NPVx * kGemmBlock)) {
-      static bool attr2 = false;
-      if (!attr2) {
-        HQ_HIP_CHECK(hipFuncSetAttribute((const void*)apply_gemm_kernel<T, RBW, CBW, NPVx>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr2 = true;
-      }
-      HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, NPVx>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+      if (pipe) HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, NPVx, kCanPipe>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+      else HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, NPVx, false>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
       return 0;
     }
   }
-  HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, 0>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+  if (pipe) HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, 0, kCanPipe>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
+  else HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, 0, false>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
   return 0;
 }
 
@@ -772,122 +773,77 @@ static int apply_U_entry(T* re, T* im, const T* U, const unsigned* pos, unsigned
 }
 
 // ---------------------------------------------------------------------------------
-// apply_blocked: a list of gates inside one LDS tile, one HBM pass (device pointers, f32)
+// apply_blocked: a list of gates inside one LDS tile, one HBM pass (device pointers)
 // ---------------------------------------------------------------------------------
+// HQ_BLOCKED_*: read once per process.  `pipe`, `groups`, `direct` and `big` select kernel code of round 4, which was
+// written without access to hardware; the self-check below may switch them off at run time.
+struct BlockedSwitches {
+  int valu_kmax;  // largest k that takes the register butterfly on the LDS tile (blocked_inner_gate_valu) instead of the
+                  // matrix-core form with identity dummies: measured, k = 1 wins (4x fewer flops), k = 2 does not
+  int grid_cap;   // HQ_BLOCKED_GRID (a power of two) caps the resident workgroups: small states then walk several tiles per
+                  // workgroup, which is how the tile loop of the prefetching kernels is exercised without a 2^22-amplitude state
+  int threads, alds, pref;
+  int big;        // tiles of 2^14 (f32) / 2^13 (f64) amplitudes = 128 KiB, ONE workgroup of 1024 threads per CU (16 waves:
+                  // the same four per SIMD as two 512-thread workgroups); opt-in until measured
+  int direct;     // tile movement folded into the first gate (apply_blocked_direct_kernel); opt-in until measured
+  int groups;     // barrier-free wave groups
+  int pipe;       // LDS requests one wave-iteration ahead of the matrix cores, table words one gate ahead
+  int selfcheck;  // how many of the first passes of the process are cross-checked (0: none)
+};
+static BlockedSwitches& blocked_switches() {
+  static BlockedSwitches s = {env_int("HQ_BLOCKED_VALU", 1),   env_int("HQ_BLOCKED_GRID", 0), env_int("HQ_BLOCKED_THREADS", 512),
+                              env_int("HQ_BLOCKED_ALDS", 1),   env_int("HQ_BLOCKED_PREF", 1), env_int("HQ_BLOCKED_BIG", 0),
+                              env_int("HQ_BLOCKED_DIRECT", 0), env_int("HQ_BLOCKED_GROUPS", 1), env_int("HQ_BLOCKED_PIPE", 1),
+                              env_int("HQ_BLOCKED_SELFCHECK", 3)};
+  return s;
+}
+static int g_selfcheck_runs = 0, g_selfcheck_failures = 0;  // under the context mutex
+
+// One pass, parsed: gates in tile-local coordinates, their operand tables, the positions they touch.
 template <typename T>
-static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_pos, unsigned tb,
-                               unsigned n_gates, const T* U_all, const unsigned* pos_all,
-                               const unsigned* k_all) {
-  constexpr unsigned CB = Vec<T>::VB;
-  const unsigned max_tb = sizeof(T) == 4 ? kBlockedMaxTileBits : kBlockedMaxTileBits - 1;  // 128 KiB of LDS
-  Context& c = ctx();
-  std::lock_guard<std::mutex> lock(c.mu);
-  read_env(c);
-  if (!re || !im || !tile_pos || (n_gates && (!U_all || !pos_all || !k_all))) return fail("apply_blocked: null pointer");
-  if (n_gates == 0) return 0;
-  if (n > 62 || tb > max_tb || tb < 10 || tb > n) return fail("apply_blocked: tile size out of range");
-  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("apply_blocked: device pointers only");
-  if ((reinterpret_cast<uintptr_t>(re) % 32) || (reinterpret_cast<uintptr_t>(im) % 32))
-    return fail("apply_blocked: planes must be 32-byte aligned");
+struct BlockedPass {
   BlockedArg ba;
-  memset(&ba, 0, sizeof(ba));
-  ba.tb = tb;
-  int local_of[64];
-  for (int i = 0; i < 64; ++i) local_of[i] = -1;
-  for (unsigned i = 0; i < tb; ++i) {
-    if (tile_pos[i] >= n || (i && tile_pos[i] <= tile_pos[i - 1])) return fail("apply_blocked: tile positions must be ascending and < n");
-    ba.apos[i] = tile_pos[i];
-    local_of[tile_pos[i]] = (int)i;
-  }
-  for (unsigned b = 0; b < CB; ++b)
-    if (tile_pos[b] != b) return fail("apply_blocked: the tile must contain the vector-component index bits (0,1 for f32; 0 for f64)");
-  std::vector<BlockedGate> gates(n_gates);
-  std::vector<unsigned> touched(n_gates, 0u);  // tile-local positions a gate acts on
+  unsigned tb = 0;
+  std::vector<BlockedGate> gates;
+  std::vector<unsigned> touched;  // tile-local positions a gate acts on
   std::vector<T> Atab;
-  const T* Up = U_all;
-  const unsigned* pp = pos_all;
-  for (unsigned g = 0; g < n_gates; ++g) {
-    const unsigned k = k_all[g];
-    if (k < 1 || k > 4) return fail("apply_blocked: gates must have 1..4 targets");
-    unsigned lp[4];
-    for (unsigned j = 0; j < k; ++j) {
-      if (pp[j] >= 64 || local_of[pp[j]] < 0) return fail("apply_blocked: gate target outside the tile");
-      lp[j] = (unsigned)local_of[pp[j]];
-      touched[g] |= 1u << lp[j];
-    }
-    if (check_positions(lp, tb, k)) return fail("apply_blocked: duplicate targets");
-    // largest k that takes the register butterfly on the LDS tile (blocked_inner_gate_valu) instead
-    // of the matrix-core form with identity dummies: measured, k = 1 wins (4x fewer flops), k = 2 does not
-    static int valu_kmax = env_int("HQ_BLOCKED_VALU", 1);
-    if (k <= 2 && (int)k <= valu_kmax) {
-      std::vector<T> Us;
-      unsigned sp[kMaxK];
-      sort_gate<T>(Up, lp, k, Us, sp);  // planar, matrix index bits in ascending local position
-      BlockedGate& G = gates[g];
-      memset(&G, 0, sizeof(G));
-      unsigned vmask = 0, kr = 0;
-      for (int m = 0; m < 6; ++m) G.ro.pos[m] = 31;
-      for (unsigned j = 0; j < k; ++j) {
-        if (sp[j] < CB) vmask |= 1u << sp[j];
-        else G.ro.pos[kr++] = sp[j] - CB;
-      }
-      if (tb - CB < kr) return fail("apply_blocked: tile too small");
-      G.a_off = (unsigned)Atab.size();
-      G.kv = 64 + k * 4 + vmask;
-      G.n_addr = kr;
-      Atab.insert(Atab.end(), Us.begin(), Us.end());
-      while (Atab.size() % 4) Atab.push_back((T)0);  // keep the next table 16-byte aligned
-      Up += (size_t)2 << (2 * k);
-      pp += k;
-      continue;
-    }
-    MfmaPlan<T> P;
-    if (!plan_mfma<T>(c, Up, lp, tb, k, P, true)) return fail("apply_blocked: cannot plan an inner gate");
-    BlockedGate& G = gates[g];
-    memset(&G, 0, sizeof(G));
-    G.ro = P.ro;
-    for (int m = 0; m < 4; ++m)
-      if (G.ro.pos[m] >= 31) G.ro.pos[m] = 31;
-    G.a_off = (unsigned)Atab.size();
-    G.kv = (unsigned)(P.kbits * 4 + P.vmask);
-    G.n_addr = P.n_addr;
-    Atab.insert(Atab.end(), P.A.begin(), P.A.end());
-    Up += (size_t)2 << (2 * k);
-    pp += k;
-  }
+};
+
+template <typename T>
+static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPass<T> P /* a copy: reordered / annotated here */,
+                          const BlockedSwitches& sw, const bool describe, int* moved_front = nullptr) {
+  constexpr unsigned CB = Vec<T>::VB;
+  const unsigned tb = P.tb, n_gates = (unsigned)P.gates.size();
+  std::vector<BlockedGate>& gates = P.gates;
+  std::vector<unsigned>& touched = P.touched;
+  const std::vector<T>& Atab = P.Atab;
+  const BlockedArg& ba = P.ba;
   const uint64_t ntiles = 1ull << (n - tb);
   const size_t tile_bytes = ((size_t)2 << tb) * sizeof(T);
   const size_t per_cu = std::min<size_t>(std::max<size_t>(1, (160 * 1024) / tile_bytes), 4);
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[] = {(const void*)apply_blocked_kernel<float, 256, false, false>, (const void*)apply_blocked_kernel<float, 512, false, false>,
-                         (const void*)apply_blocked_kernel<double, 256, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false>,
-                         (const void*)apply_blocked_kernel<float, 512, true, false>, (const void*)apply_blocked_kernel<double, 512, true, false>,
-                         (const void*)apply_blocked_kernel<float, 512, true, true>, (const void*)apply_blocked_kernel<float, 512, false, true>,
-                         (const void*)apply_blocked_kernel<double, 512, true, true>,
+    const void* fns[] = {(const void*)apply_blocked_kernel<float, 256, false, false, false>, (const void*)apply_blocked_kernel<float, 512, false, false, false>,
+                         (const void*)apply_blocked_kernel<double, 256, false, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false, false>,
+                         (const void*)apply_blocked_kernel<float, 512, true, false, true>, (const void*)apply_blocked_kernel<double, 512, true, false, true>,
+                         (const void*)apply_blocked_kernel<float, 512, true, false, false>, (const void*)apply_blocked_kernel<double, 512, true, false, false>,
+                         (const void*)apply_blocked_kernel<float, 512, true, true, true>, (const void*)apply_blocked_kernel<double, 512, true, true, true>,
+                         (const void*)apply_blocked_kernel<float, 512, true, true, false>, (const void*)apply_blocked_kernel<double, 512, true, true, false>,
+                         (const void*)apply_blocked_kernel<float, 512, false, true, false>,
                          (const void*)apply_blocked_direct_kernel<float, 512>, (const void*)apply_blocked_direct_kernel<double, 512>,
-                         (const void*)apply_blocked_kernel<float, 1024, true, true>, (const void*)apply_blocked_kernel<double, 1024, true, true>,
+                         (const void*)apply_blocked_kernel<float, 1024, true, true, true>, (const void*)apply_blocked_kernel<double, 1024, true, true, true>,
                          (const void*)apply_blocked_direct_kernel<float, 1024>, (const void*)apply_blocked_direct_kernel<double, 1024>};
     for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  // HQ_BLOCKED_GRID (a power of two) caps the resident workgroups: small states then walk several tiles per workgroup, which
-  // is how the tile loop of the prefetching kernels is exercised by tests without a 2^22-amplitude state
-  static int grid_cap = env_int("HQ_BLOCKED_GRID", 0);
   unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
-  if (grid_cap > 0 && (grid_cap & (grid_cap - 1)) == 0) grid = std::min<unsigned>(grid, (unsigned)grid_cap);
-  static int block_threads = env_int("HQ_BLOCKED_THREADS", 512);
-  static int a_in_lds = env_int("HQ_BLOCKED_ALDS", 1);
+  if (sw.grid_cap > 0 && (sw.grid_cap & (sw.grid_cap - 1)) == 0) grid = std::min<unsigned>(grid, (unsigned)sw.grid_cap);
+  const int block_threads = sw.threads, a_in_lds = sw.alds;
   // LDS left per workgroup behind the tile when `per_cu` workgroups share a CU
   const size_t a_budget = (160 * 1024) / per_cu - tile_bytes > 2048 ? (160 * 1024) / per_cu - tile_bytes - 1024 : 0;
-  // HQ_BLOCKED_BIG=1 (opt-in until measured): tiles of 2^14 (f32) / 2^13 (f64) amplitudes = 128 KiB, ONE workgroup of
-  // 1024 threads per CU (16 waves: the same four per SIMD as two 512-thread workgroups) with the register prefetch, the
-  // barrier-free groups (four wave bits) and the direct first gate -- 25 instead of 28 passes on the n = 30 benchmark plan
-  static int use_big = env_int("HQ_BLOCKED_BIG", 0);
-  static int use_pref = env_int("HQ_BLOCKED_PREF", 1);
   auto table_bytes = [&](unsigned words) { return (((size_t)n_gates * words * sizeof(BlockedTabT)) + 15) & ~(size_t)15; };
-  // all or nothing: the 1024-thread kernel exists only with the tables in LDS and the register prefetch
-  const bool big = use_big && use_pref && block_threads != 256 && a_in_lds && tb == (sizeof(T) == 4 ? 14u : 13u) &&
+  // all or nothing: the 1024-thread kernel exists only with the tables in LDS, the register prefetch and the pipelined gates
+  const bool big = sw.big && sw.pref && sw.pipe && block_threads != 256 && a_in_lds && tb == (sizeof(T) == 4 ? 14u : 13u) &&
                    Atab.size() * sizeof(T) + table_bytes(BlockedTab<1024>::kWords) <= a_budget;
   const unsigned wave_bits_n = big ? 4u : 3u;
   const size_t tab_bytes = table_bytes(big ? BlockedTab<1024>::kWords : BlockedTab<512>::kWords);  // per-gate address tables (built in-kernel)
@@ -902,14 +858,13 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
   const bool fits = a_in_lds && iter_ok && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
   // register prefetch of the next tile (512 threads, 4 vectors per thread and plane = 13 (f32) / 12 (f64) tile bits;
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
-  const bool pref = use_pref && block_threads != 256 && ((tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits)) || big);
-  // Tile movement folded into the first gate (apply_blocked_direct_kernel; opt-in until measured): the pass needs a
+  const bool pref = sw.pref && block_threads != 256 && ((tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits)) || big);
+  // Tile movement folded into the first gate (apply_blocked_direct_kernel): the pass needs a
   // k <= 3 matrix-core gate (KBITS = 4) whose register digits lie above tile-local vector bit 2 -- every wave-level HBM
   // access of the gate's own addressing is then a set of whole 128-byte lines -- that may run first: the earliest such gate
   // that shares no position with the gates in front of it is moved to the front (disjoint gates commute exactly).
-  static int use_direct = env_int("HQ_BLOCKED_DIRECT", 0);
   bool direct = false;
-  if (use_direct && pref && n_gates >= 2 && a_in_lds &&
+  if (sw.direct && sw.pipe && pref && n_gates >= 2 && a_in_lds && fits &&
       Atab.size() * sizeof(T) + tab_bytes + blocked_gtab_words<1024>() * sizeof(uint64_t) <= a_budget) {
     auto eligible = [&](const BlockedGate& G) {
       if (G.kv < 16 || G.kv > 19) return false;
@@ -924,14 +879,14 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
         std::rotate(gates.begin(), gates.begin() + g, gates.begin() + g + 1);
         std::rotate(touched.begin(), touched.begin() + g, touched.begin() + g + 1);
         direct = true;
+        if (moved_front) *moved_front = (int)g;
         break;
       }
       before |= touched[g];
     }
   }
   unsigned n_barriers = n_gates;
-  static int elide = env_int("HQ_BLOCKED_GROUPS", 1);
-  if (fits && elide) {
+  if (fits && sw.groups) {
     // Barrier-free groups (round 4).  A matrix-core inner gate splits the tile among the 8 waves by three tile-local
     // vector bits that are not address digits of the gate; consecutive gates that can agree on those three bits hand
     // the tile on wave by wave, and the workgroup barrier between them goes ("barrier only when a
@@ -970,47 +925,216 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
       g0 = g1;
     }
   }
+  void *dG = nullptr, *dA = nullptr;
+  if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
+  if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
+  const BlockedGate* const pG = (const BlockedGate*)dG;
+  const T* const pA = (const T*)dA;
+  const unsigned a_elems = (unsigned)Atab.size();
+#define HQ_BLOCKED_LAUNCH(kern, threads_, lds_, ae_) \
+  HQ_LAUNCH(c, kern, dim3(grid), dim3(threads_), lds_, re, im, pG, n_gates, pA, ae_, ba, ntiles)
   if (fits) {
-    void *dG = nullptr, *dA = nullptr;
-    if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
-    if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
     const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes + (direct ? blocked_gtab_words<1024>() * sizeof(uint64_t) : 0);
     if (big) {
-      if (direct)
-        HQ_LAUNCH(c, (apply_blocked_direct_kernel<T, 1024>), dim3(grid), dim3(1024), lds, re, im, (const BlockedGate*)dG,
-                  n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
-      else
-        HQ_LAUNCH(c, (apply_blocked_kernel<T, 1024, true, true>), dim3(grid), dim3(1024), lds, re, im, (const BlockedGate*)dG,
-                  n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+      if (direct) HQ_BLOCKED_LAUNCH((apply_blocked_direct_kernel<T, 1024>), 1024, lds, a_elems);
+      else HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 1024, true, true, true>), 1024, lds, a_elems);
     } else if (direct) {
-      HQ_LAUNCH(c, (apply_blocked_direct_kernel<T, 512>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
-                n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+      HQ_BLOCKED_LAUNCH((apply_blocked_direct_kernel<T, 512>), 512, lds, a_elems);
     } else if (pref) {
-      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
-                n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+      if (sw.pipe) HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 512, true, true, true>), 512, lds, a_elems);
+      else HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 512, true, true, false>), 512, lds, a_elems);
     } else {
-      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, true, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG,
-                n_gates, (const T*)dA, (unsigned)Atab.size(), ba, ntiles);
+      if (sw.pipe) HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 512, true, false, true>), 512, lds, a_elems);
+      else HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 512, true, false, false>), 512, lds, a_elems);
     }
   } else {
-    void *dG = nullptr, *dA = nullptr;
-    if (arena_upload(c, gates.data(), gates.size() * sizeof(BlockedGate), &dG)) return 1;
-    if (arena_upload(c, Atab.data(), Atab.size() * sizeof(T), &dA)) return 1;
     const size_t lds = tile_bytes;
-    if (block_threads == 256)
-      HQ_LAUNCH(c, (apply_blocked_kernel<T, 256, false, false>), dim3(grid), dim3(256), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
-    else if (pref) {
-      if constexpr (sizeof(T) == 4)
-        HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, false, true>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
-    } else
-      HQ_LAUNCH(c, (apply_blocked_kernel<T, 512, false, false>), dim3(grid), dim3(512), lds, re, im, (const BlockedGate*)dG, n_gates, (const T*)dA, 0u, ba, ntiles);
+    if (block_threads == 256) {
+      HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 256, false, false, false>), 256, lds, 0u);
+    } else if (pref && sizeof(T) == 4) {
+      if constexpr (sizeof(T) == 4) HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 512, false, true, false>), 512, lds, 0u);
+    } else {
+      HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 512, false, false, false>), 512, lds, 0u);
+    }
   }
+#undef HQ_BLOCKED_LAUNCH
   HQ_HIP_CHECK(hipGetLastError());
-  c.last_kernel = "blocked";
-  c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
-                std::to_string(block_threads == 256 ? 256 : (big ? 1024 : 512)) + "> tb=" + std::to_string(tb) + " gates=" +
-                std::to_string(n_gates) + " barriers=" + std::to_string(n_barriers) + (direct ? " direct" : "");
+  if (describe) {
+    c.last_kernel = "blocked";
+    c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
+                  std::to_string(block_threads == 256 ? 256 : (big ? 1024 : 512)) + "> pipe=" + (fits && sw.pipe ? "1" : "0") + " tb=" + std::to_string(tb) +
+                  " gates=" + std::to_string(n_gates) + " barriers=" + std::to_string(n_barriers) + (direct ? " direct" : "");
+  }
   return 0;
+}
+
+// The cross-check of the kernel code that was written without hardware (rounds 3-4: pipelined inner gates, barrier-free
+// wave groups, direct first gate, 1024-thread tiles).  The first `HQ_BLOCKED_SELFCHECK` (default 3) passes of a process
+// that would use any of it are ALSO run -- same gates, same tile shape, a scratch state of 64 tiles of pseudo-random
+// amplitudes walked by 16 workgroups -- through the kernels of round 2 (one workgroup barrier per gate, LDS reads where
+// the compiler puts them), whose results hardware tests have compared with the oracle.  All variants perform the same
+// floating-point operations in the same order on every amplitude (the direct kernel may move a gate to the front of the
+// pass: the reference run then takes the same order), so the two results must agree BIT FOR BIT; if they do not, the
+// switches that survive the same comparison on their own stay on, the others go off for the rest of the process, and a
+// warning names them.  Costs ~1 ms per checked pass.  Not recorded into programs; hq_blocked_selfcheck() reports.
+template <typename T>
+static int blocked_selfcheck(Context& c, const BlockedPass<T>& P, const unsigned n, BlockedSwitches& sw) {
+  constexpr unsigned CB = Vec<T>::VB;
+  const unsigned tb = P.tb, nc = std::min(n, tb + 6);
+  BlockedPass<T> Q = P;
+  for (unsigned i = CB; i < tb; ++i)  // the contiguous low run stays, the scattered bits move to the top of the small state
+    if (P.ba.apos[i] != i) Q.ba.apos[i] = nc - tb + i;
+  const size_t amps = (size_t)1 << nc, plane = amps * sizeof(T);
+  std::vector<T> host(2 * amps), ref(2 * amps), got(2 * amps);
+  uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)P.gates.size();
+  for (T& v : host) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    v = (T)((double)(int64_t)(x >> 11) * (1.0 / 4503599627370496.0) - 1.0);  // [-1, 1)
+  }
+  unsigned char* buf = nullptr;
+  HQ_HIP_CHECK(hipMalloc((void**)&buf, 2 * plane));
+  auto run = [&](const BlockedPass<T>& pass, const BlockedSwitches& s, std::vector<T>& out, int* moved) -> int {
+    hipError_t e = hipMemcpyAsync(buf, host.data(), 2 * plane, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess && blocked_launch<T>(c, (T*)buf, (T*)(buf + plane), nc, pass, s, false, moved)) return 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), buf, 2 * plane, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(std::string("blocked self-check: ") + hipGetErrorString(e)); }
+    return 0;
+  };
+  BlockedSwitches base = sw;
+  base.pipe = base.groups = base.direct = base.big = 0;
+  base.grid_cap = 16;
+  // 0: the switches agree with the round-2 kernels on this pass, 1: they do not, -1: a runtime call failed
+  auto differs = [&](BlockedSwitches s) -> int {
+    s.grid_cap = 16;
+    int moved = -1;
+    if (run(Q, s, got, &moved)) return -1;
+    BlockedPass<T> R = Q;
+    if (moved > 0) {
+      std::rotate(R.gates.begin(), R.gates.begin() + moved, R.gates.begin() + moved + 1);
+      std::rotate(R.touched.begin(), R.touched.begin() + moved, R.touched.begin() + moved + 1);
+    }
+    if (run(R, base, ref, nullptr)) return -1;
+    return memcmp(ref.data(), got.data(), 2 * plane) != 0;
+  };
+  ++g_selfcheck_runs;
+  int d = differs(sw);
+  if (d > 0) {
+    ++g_selfcheck_failures;
+    std::string off;
+    struct { const char* name; int BlockedSwitches::*field; } parts[] = {{"HQ_BLOCKED_PIPE", &BlockedSwitches::pipe}, {"HQ_BLOCKED_GROUPS", &BlockedSwitches::groups},
+                                                                         {"HQ_BLOCKED_DIRECT", &BlockedSwitches::direct}, {"HQ_BLOCKED_BIG", &BlockedSwitches::big}};
+    const BlockedSwitches asked = sw;
+    for (auto& part : parts) {
+      if (!(asked.*(part.field))) continue;
+      BlockedSwitches one = base;
+      one.*(part.field) = asked.*(part.field);
+      if (part.field == &BlockedSwitches::direct || part.field == &BlockedSwitches::big) one.pipe = 1;  // they exist with the pipelined gates only
+      if ((d = differs(one)) < 0) break;
+      if (d) {
+        sw.*(part.field) = 0;
+        off += std::string(off.empty() ? "" : ", ") + part.name;
+      }
+    }
+    if (d >= 0 && (d = differs(sw)) > 0) {  // what is left, together
+      sw.pipe = sw.groups = sw.direct = sw.big = 0;
+      off = "HQ_BLOCKED_PIPE, HQ_BLOCKED_GROUPS, HQ_BLOCKED_DIRECT, HQ_BLOCKED_BIG";
+    }
+    if (d >= 0)
+      fprintf(stderr, "libhq_hip: WARNING: the cache-blocked kernel variants disagree on this device (pass of %zu gates, tile of 2^%u); "
+              "switched off for this process: %s\n", P.gates.size(), tb, off.c_str());
+  }
+  (void)hipFree(buf);
+  return d < 0;
+}
+
+template <typename T>
+static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_pos, unsigned tb,
+                               unsigned n_gates, const T* U_all, const unsigned* pos_all,
+                               const unsigned* k_all) {
+  constexpr unsigned CB = Vec<T>::VB;
+  const unsigned max_tb = sizeof(T) == 4 ? kBlockedMaxTileBits : kBlockedMaxTileBits - 1;  // 128 KiB of LDS
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  read_env(c);
+  if (!re || !im || !tile_pos || (n_gates && (!U_all || !pos_all || !k_all))) return fail("apply_blocked: null pointer");
+  if (n_gates == 0) return 0;
+  if (n > 62 || tb > max_tb || tb < 10 || tb > n) return fail("apply_blocked: tile size out of range");
+  if (!is_device_pointer(re) || !is_device_pointer(im)) return fail("apply_blocked: device pointers only");
+  if ((reinterpret_cast<uintptr_t>(re) % 32) || (reinterpret_cast<uintptr_t>(im) % 32))
+    return fail("apply_blocked: planes must be 32-byte aligned");
+  BlockedSwitches& sw = blocked_switches();
+  BlockedPass<T> P;
+  BlockedArg& ba = P.ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.tb = P.tb = tb;
+  int local_of[64];
+  for (int i = 0; i < 64; ++i) local_of[i] = -1;
+  for (unsigned i = 0; i < tb; ++i) {
+    if (tile_pos[i] >= n || (i && tile_pos[i] <= tile_pos[i - 1])) return fail("apply_blocked: tile positions must be ascending and < n");
+    ba.apos[i] = tile_pos[i];
+    local_of[tile_pos[i]] = (int)i;
+  }
+  for (unsigned b = 0; b < CB; ++b)
+    if (tile_pos[b] != b) return fail("apply_blocked: the tile must contain the vector-component index bits (0,1 for f32; 0 for f64)");
+  std::vector<BlockedGate>& gates = P.gates;
+  std::vector<unsigned>& touched = P.touched;
+  std::vector<T>& Atab = P.Atab;
+  gates.resize(n_gates);
+  touched.assign(n_gates, 0u);
+  const T* Up = U_all;
+  const unsigned* pp = pos_all;
+  for (unsigned g = 0; g < n_gates; ++g) {
+    const unsigned k = k_all[g];
+    if (k < 1 || k > 4) return fail("apply_blocked: gates must have 1..4 targets");
+    unsigned lp[4];
+    for (unsigned j = 0; j < k; ++j) {
+      if (pp[j] >= 64 || local_of[pp[j]] < 0) return fail("apply_blocked: gate target outside the tile");
+      lp[j] = (unsigned)local_of[pp[j]];
+      touched[g] |= 1u << lp[j];
+    }
+    if (check_positions(lp, tb, k)) return fail("apply_blocked: duplicate targets");
+    if (k <= 2 && (int)k <= sw.valu_kmax) {
+      std::vector<T> Us;
+      unsigned sp[kMaxK];
+      sort_gate<T>(Up, lp, k, Us, sp);  // planar, matrix index bits in ascending local position
+      BlockedGate& G = gates[g];
+      memset(&G, 0, sizeof(G));
+      unsigned vmask = 0, kr = 0;
+      for (int m = 0; m < 6; ++m) G.ro.pos[m] = 31;
+      for (unsigned j = 0; j < k; ++j) {
+        if (sp[j] < CB) vmask |= 1u << sp[j];
+        else G.ro.pos[kr++] = sp[j] - CB;
+      }
+      if (tb - CB < kr) return fail("apply_blocked: tile too small");
+      G.a_off = (unsigned)Atab.size();
+      G.kv = 64 + k * 4 + vmask;
+      G.n_addr = kr;
+      Atab.insert(Atab.end(), Us.begin(), Us.end());
+      while (Atab.size() % 4) Atab.push_back((T)0);  // keep the next table 16-byte aligned
+      Up += (size_t)2 << (2 * k);
+      pp += k;
+      continue;
+    }
+    MfmaPlan<T> M;
+    if (!plan_mfma<T>(c, Up, lp, tb, k, M, true)) return fail("apply_blocked: cannot plan an inner gate");
+    BlockedGate& G = gates[g];
+    memset(&G, 0, sizeof(G));
+    G.ro = M.ro;
+    for (int m = 0; m < 4; ++m)
+      if (G.ro.pos[m] >= 31) G.ro.pos[m] = 31;
+    G.a_off = (unsigned)Atab.size();
+    G.kv = (unsigned)(M.kbits * 4 + M.vmask);
+    G.n_addr = M.n_addr;
+    Atab.insert(Atab.end(), M.A.begin(), M.A.end());
+    Up += (size_t)2 << (2 * k);
+    pp += k;
+  }
+  if (sw.selfcheck > 0 && !c.rec && (sw.pipe || sw.groups || sw.direct || sw.big) && sw.alds && sw.threads != 256) {
+    --sw.selfcheck;
+    if (blocked_selfcheck<T>(c, P, n, sw)) return 1;
+  }
+  return blocked_launch<T>(c, re, im, n, std::move(P), sw, true);
 }
 
 int apply_device_f32(Context& c, float* re, float* im, const float* U, const unsigned* pos, unsigned n, unsigned k) {
@@ -1044,6 +1168,16 @@ int hq_apply_blocked_float64(double* re, double* im, unsigned int n, const unsig
                              unsigned int tile_bits, unsigned int n_gates, const double* U_all,
                              const unsigned int* pos_all, const unsigned int* k_all) {
   return hq::apply_blocked_entry<double>(re, im, n, tile_pos, tile_bits, n_gates, U_all, pos_all, k_all);
+}
+
+int hq_blocked_selfcheck(int* runs, int* failures, int* switches) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  const hq::BlockedSwitches& sw = hq::blocked_switches();
+  if (runs) *runs = hq::g_selfcheck_runs;
+  if (failures) *failures = hq::g_selfcheck_failures;
+  if (switches) *switches = (sw.pipe ? 1 : 0) | (sw.groups ? 2 : 0) | (sw.direct ? 4 : 0) | (sw.big ? 8 : 0);
+  return 0;
 }
 
 }  // extern "C"

@@ -624,7 +624,7 @@ __device__ __forceinline__ void blocked_build_tables(BlockedTabT* __restrict__ t
 
 // (BlockedPre, further down: the table words a gate needs first, requested one gate early; BlockedNoPre: read them here)
 struct BlockedNoPre {};
-template <typename T, int KBITS, int VMASK, int BLOCK, typename PRE>
+template <typename T, int KBITS, int VMASK, int BLOCK, bool PIPE, typename PRE>
 __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
                                                        const BlockedTabT* __restrict__ tab, const unsigned niter, const PRE& P) {
   using V = typename Vec<T>::type;
@@ -675,9 +675,9 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
       *reinterpret_cast<LdsV*>((uintptr_t)(Lt ^ OFF[ld])) = y;
     }
   };
-#ifdef HQ_BLOCKED_NOPIPE
-  // (the loop of rounds 2-4a, kept for A/B builds: the compiler sinks every ds_read_b128 to just in front of the MFMAs
-  // that consume it and waits for it there -- 4 to 8 exposed LDS latencies per wave-iteration)
+  if constexpr (!PIPE) {
+  // (PIPE = false, HQ_BLOCKED_PIPE=0 at run time: the loop of rounds 2-4a -- the compiler sinks every ds_read_b128 to just
+  // in front of the MFMAs that consume it and waits for it there, 4 to 8 exposed LDS latencies per wave-iteration)
   for (unsigned it = wave; it < niter; it += 1u << WB) {
     const unsigned Lt = L ^ tab[BlockedTab<BLOCK>::kIter + it];
     V x[NL];
@@ -700,7 +700,7 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
     }
     store_results(acc, Lt);
   }
-#else
+  } else {
   // LDS reads ahead of the matrix cores (round 4, from the assembly: left to itself the compiler sinks every
   // ds_read_b128 to just in front of the 4-8 MFMAs that consume it, `s_waitcnt lgkmcnt(0)` in between -- a wave then
   // feeds the matrix pipe for 128-256 cycles, waits ~100+ for LDS, feeds it again: the 1276 cycles that the 16 MFMAs
@@ -808,7 +808,7 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
       store_results(acc, Lt);
     }
   }
-#endif
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
@@ -927,7 +927,7 @@ __device__ __forceinline__ PRE blocked_pre(const BlockedTabT* __restrict__ tabs,
 
 // One inner gate of a pass by its kind (G.kv: KBITS * 4 + VMASK for the matrix-core form, 64 + k * 4 + VMASK for the
 // register butterflies).
-template <typename T, int BLOCK, bool ALDS, typename PRE>
+template <typename T, int BLOCK, bool ALDS, bool PIPE, typename PRE>
 __device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, const BlockedDesc D, const PRE& P, const unsigned gi,
                                                       T* __restrict__ xr, T* __restrict__ xi, const T* __restrict__ als,
                                                       const T* __restrict__ Atab, const BlockedTabT* __restrict__ tabs,
@@ -937,7 +937,7 @@ __device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, cons
 #define HQ_BLOCKED_MFMA_GATE(KB, VM)                                                                    \
   do {                                                                                                  \
     if constexpr (ALDS)                                                                                 \
-      blocked_inner_gate_tab<T, KB, VM, BLOCK>(A, tabs + gi * BlockedTab<BLOCK>::kWords, (1u << (tvb - D.n_addr)) >> 4, P); \
+      blocked_inner_gate_tab<T, KB, VM, BLOCK, PIPE>(A, tabs + gi * BlockedTab<BLOCK>::kWords, (1u << (tvb - D.n_addr)) >> 4, P); \
     else                                                                                                \
       blocked_inner_gate<T, KB, VM, BLOCK>(xr, xi, G, A, tvb);                                          \
   } while (0)
@@ -977,7 +977,10 @@ __device__ __forceinline__ void blocked_dispatch_gate(const BlockedGate& G, cons
 // before the gates of the current tile start and dropped into LDS after its stores were issued.  Needs the
 // no-scratch register budget: a scratch reload is a vector-memory load and would queue (vmcnt is in order) behind
 // the prefetch it was supposed to overlap.
-template <typename T, int BLOCK, bool ALDS, bool PREF>
+// PIPE (with ALDS; HQ_BLOCKED_PIPE, default 1): the inner gates request their LDS vectors one wave-iteration ahead of the
+// matrix cores and the table words of the next gate one gate early (blocked_inner_gate_tab, BlockedPre); false = the
+// loops of rounds 2-4a, kept as a run-time alternative so that one lease can time and bisect both.
+template <typename T, int BLOCK, bool ALDS, bool PREF, bool PIPE>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* __restrict__ gates,
                      const unsigned ngates, const T* __restrict__ Atab, const unsigned a_elems,
@@ -1077,12 +1080,12 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
     __syncthreads();
     BlockedDesc D = blocked_desc(gates, 0);
     // (complex128: no registers left beside the tile prefetch for the words of the next gate)
-    using Pre = typename std::conditional<ALDS && sizeof(T) == 4, BlockedPre, BlockedNoPre>::type;
+    using Pre = typename std::conditional<ALDS && PIPE && sizeof(T) == 4, BlockedPre, BlockedNoPre>::type;
     Pre P = blocked_pre<BLOCK, Pre>(tabs, 0);
     for (unsigned gi = 0; gi < ngates; ++gi) {
       const BlockedDesc Dn = blocked_desc(gates, gi + 1 < ngates ? gi + 1 : gi);  // in flight while this gate runs
       const Pre Pn = blocked_pre<BLOCK, Pre>(tabs, gi + 1 < ngates ? gi + 1 : gi);
-      blocked_dispatch_gate<T, BLOCK, ALDS>(gates[gi], D, P, gi, xr, xi, als, Atab, tabs, tvb);
+      blocked_dispatch_gate<T, BLOCK, ALDS, PIPE>(gates[gi], D, P, gi, xr, xi, als, Atab, tabs, tvb);
       P = Pn;
       // gates of one barrier-free group touch, wave by wave, the same part of the tile (same `wave_bits`): a wave only
       // needs its OWN stores to have landed (LDS operations of a wave complete in order; the gate ends with lgkmcnt(0))
@@ -1349,7 +1352,7 @@ apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const Blocke
     for (unsigned gi = 1; gi < ngates; ++gi) {
       const BlockedDesc Dn = blocked_desc(gates, gi + 1 < ngates ? gi + 1 : gi);
       const Pre Pn = blocked_pre<BLOCK, Pre>(tabs, gi + 1 < ngates ? gi + 1 : gi);
-      blocked_dispatch_gate<T, BLOCK, true>(gates[gi], D, P, gi, xr, xi, als, Atab, tabs, tvb);
+      blocked_dispatch_gate<T, BLOCK, true, true>(gates[gi], D, P, gi, xr, xi, als, Atab, tabs, tvb);
       P = Pn;
       if (!(D.wave_bits & kBlockedNoBarrier)) __syncthreads();
       D = Dn;
@@ -1384,6 +1387,7 @@ apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const Blocke
 // target positions.  After the K loop the results replace the tile in LDS and stream back.
 // ---------------------------------------------------------------------------------
 constexpr int kGemmBlock = 512;
+template <typename T, int RBW, int CBW> constexpr bool gemm_can_pipe() { return !(sizeof(T) == 8 && RBW * CBW >= 8); }
 constexpr int kGemmMaxTileBits = 14;
 struct GemmArg {
   unsigned tb, k;                    // tile bits, target bits
@@ -1397,7 +1401,8 @@ struct GemmArg {
 // MFMA phase of the current one and dropped into LDS after its results were stored (the same recipe, for the same
 // reason, as apply_blocked_kernel's PREF: copy-in, MFMA and copy-out phases run in step on the whole chip, so HBM
 // idled while the matrix cores worked and vice versa -- k = 7 measured 10.5 ms = 7.0 ms of MFMA + 2.9 ms of HBM).
-template <typename T, int RBW, int CBW, int NPV>
+// PIPE (HQ_GEMM_PIPE, default 1): operands requested ahead of the matrix cores (below); false = the loop of rounds 1-4a.
+template <typename T, int RBW, int CBW, int NPV, bool PIPE>
 __global__ void __launch_bounds__(kGemmBlock)
 apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ Atab,
                   const unsigned* __restrict__ offs, const GemmArg a, const uint64_t ntiles) {
@@ -1513,7 +1518,7 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
 #pragma unroll
       for (int c = 0; c < CBW; ++c) { accr[rb][c] = Acc{0, 0, 0, 0}; acci[rb][c] = Acc{0, 0, 0, 0}; }
     // the loop of rounds 1-4a: still what complex128 with 128 accumulator registers runs (no registers for a second
-    // operand set), and what -DHQ_GEMM_NOPIPE builds everywhere for A/B
+    // operand set), and what PIPE = false runs everywhere
     auto plain_loop = [&]() {
     for (unsigned sg = 0; sg < a.nsg; ++sg) {
         V ur[RBW], ui[RBW];
@@ -1542,11 +1547,7 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
         }
       }
     };
-#ifdef HQ_GEMM_NOPIPE
-    constexpr bool kPipe = false;
-#else
-    constexpr bool kPipe = !(sizeof(T) == 8 && RBW * CBW >= 8);
-#endif
+    constexpr bool kPipe = PIPE && gemm_can_pipe<T, RBW, CBW>();
     if constexpr (!kPipe) {
       plain_loop();
     } else {

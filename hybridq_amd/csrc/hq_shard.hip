@@ -31,6 +31,8 @@ struct Shard {
   bool own_comm = false;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> round_ev;  // hq_exchange_rounds_*: one per round, recorded on the communication stream
+  unsigned rounds_pending = 0;       // rounds of the last hq_exchange_rounds_* call (hq_exchange_round_wait checks its argument)
   // p2p: local buffer address -> the same buffer on every rank (mapped into this process)
   struct Peers { const void* local; void* peer[kMaxShardRanks]; };
   std::vector<Peers> registry;
@@ -146,8 +148,18 @@ static int launch_pack(Context& c, hipStream_t s, const E* s0, const E* s1, cons
 // local index bits: chunk j of rank r becomes chunk r of rank j.  *result_in_src = 1 when the
 // exchanged shard ends up in the src planes (RCCL transport with a permutation: pack src -> dst,
 // transfer dst -> src), 0 when it is in the dst planes.
+//
+// `sub_bits` / `n_rounds` (hq_exchange_rounds_*): the same exchange moved in 2^sub_bits ROUNDS -- round s carries piece s
+// (of 2^sub_bits) of every chunk, both planes, all 2(G-1) transfers of a round in one group -- with an event per round
+// on the communication stream and NO wait on the library stream: the caller waits round by round
+// (hq_exchange_round_wait) and works on the pieces that have landed while the later rounds are on the wire.  The pack
+// pass stays folded in and stays whole-plane: the transfers of a plane write into the src plane the pack has just read
+// (there is no third buffer), so a plane's first round starts when that plane's pack is done -- the rounds of the re
+// plane overlap the pack of im -- and the rounds then alternate between the planes.  The peer-to-peer transport (stores
+// into the peers' planes, bracketed by the caller's barriers) and a single rank run as ONE round.
 template <typename E>
-static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m, const unsigned* perm, int* result_in_src) {
+static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m, const unsigned* perm, int* result_in_src,
+                          const unsigned sub_bits = 0, unsigned* n_rounds = nullptr) {
   Context& c = ctx();
   std::lock_guard<std::mutex> lock(c.mu);
   read_env(c);
@@ -156,6 +168,15 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
   if (!src_re || !src_im || !dst_re || !dst_im || !result_in_src) return fail("exchange: null pointer");
   if (sh.transport == 0 && sh.world > 1) return fail("exchange: no transport (call hq_shard_init_rccl / hq_shard_init_p2p)");
   if (m > 62 || m < 2 * sh.g + 2) return fail("exchange: shard too small for the number of ranks");
+  if (sub_bits > 6 || (sub_bits && m < 2 * sh.g + 2 + sub_bits)) return fail("exchange: too many rounds for this shard");
+  const bool rounds = n_rounds != nullptr;
+  if (rounds) { *n_rounds = 1; sh.rounds_pending = 1; }
+  if (rounds && sh.round_ev.empty()) {  // round 0 of a one-round exchange: nothing to wait for, but the event must exist
+    hipEvent_t e0 = nullptr;
+    HQ_HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    sh.round_ev.push_back(e0);
+  }
+  if (rounds) HQ_HIP_CHECK(hipEventRecord(sh.round_ev[0], c.stream));  // "everything issued so far": overwritten by the RCCL path
   if (!is_device_pointer(src_re) || !is_device_pointer(src_im) || !is_device_pointer(dst_re) || !is_device_pointer(dst_im))
     return fail("exchange: device pointers only");
   const unsigned G = sh.world, g = sh.g;
@@ -185,7 +206,7 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
       i += len;
     }
   }
-  unsigned char* S[2] = {reinterpret_cast<unsigned char*>(src_re), reinterpret_cast<unsigned char*>(src_im)};
+  unsigned char* S_[2] = {reinterpret_cast<unsigned char*>(src_re), reinterpret_cast<unsigned char*>(src_im)};
   unsigned char* D[2] = {reinterpret_cast<unsigned char*>(dst_re), reinterpret_cast<unsigned char*>(dst_im)};
 
   if (G == 1) {  // one rank: the exchange is the permutation alone
@@ -221,22 +242,59 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
   // transfers of a plane in ONE group so that the 7 xGMI links of a GPU run at the same time; the
   // self chunk never goes near RCCL (its self copy measured 180 GB/s; ours streams at HBM rate).
   hipStream_t cs = sh.comm_stream;
-  auto transfer_plane = [&](unsigned char* from, unsigned char* to) -> int {
+  const unsigned S = rounds ? 1u << sub_bits : 1u;
+  const size_t piece = chunk >> (rounds ? sub_bits : 0);
+  // piece s of every chunk of one plane (S = 1: the whole chunks)
+  auto transfer_plane = [&](unsigned char* from, unsigned char* to, unsigned s_ = 0) -> int {
     for (unsigned j = 0; j < G; ++j) {
       if (j == sh.rank) continue;
-      HQ_NCCL_CHECK(sh, sh.api.Send(from + (size_t)j * chunk, chunk, ncclChar, (int)j, sh.comm, cs));
-      HQ_NCCL_CHECK(sh, sh.api.Recv(to + (size_t)j * chunk, chunk, ncclChar, (int)j, sh.comm, cs));
+      HQ_NCCL_CHECK(sh, sh.api.Send(from + (size_t)j * chunk + s_ * piece, piece, ncclChar, (int)j, sh.comm, cs));
+      HQ_NCCL_CHECK(sh, sh.api.Recv(to + (size_t)j * chunk + s_ * piece, piece, ncclChar, (int)j, sh.comm, cs));
     }
     return 0;
   };
+  if (rounds) {
+    while (sh.round_ev.size() < S) {
+      hipEvent_t e = nullptr;
+      HQ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      sh.round_ev.push_back(e);
+    }
+    *n_rounds = sh.rounds_pending = S;
+    unsigned char** from = has_perm ? D : S_;
+    unsigned char** to = has_perm ? S_ : D;
+    if (has_perm) {
+      // pack plane p into the dst planes (send layout) on the library stream; ev[p] releases that plane's rounds
+      a.planes = 1;
+      for (int p = 0; p < 2; ++p) {
+        for (unsigned j = 0; j < G; ++j) a.dst[j][0] = D[p] + (size_t)j * chunk;
+        if (launch_pack<E>(c, c.stream, reinterpret_cast<const E*>(S_[p]), (const E*)nullptr, a, perm)) return 1;
+        HQ_HIP_CHECK(hipEventRecord(sh.ev[p], c.stream));
+      }
+    } else {
+      HQ_HIP_CHECK(hipEventRecord(sh.ev[0], c.stream));  // src is final once the stream reaches here
+    }
+    for (unsigned s_ = 0; s_ < S; ++s_) {
+      for (int p = 0; p < 2; ++p) {
+        if (s_ == 0 && (p == 0 || has_perm)) HQ_HIP_CHECK(hipStreamWaitEvent(cs, sh.ev[p], 0));
+        HQ_NCCL_CHECK(sh, sh.api.GroupStart());
+        if (transfer_plane(from[p], to[p], s_)) { (void)sh.api.GroupEnd(); return 1; }
+        HQ_NCCL_CHECK(sh, sh.api.GroupEnd());
+      }
+      HQ_HIP_CHECK(hipEventRecord(sh.round_ev[s_], cs));
+    }
+    for (int p = 0; p < 2; ++p)  // self chunk, all its pieces (with a permutation: after BOTH packs, src chunk `rank` is free)
+      if (copy16(c, c.stream, to[p] + (size_t)sh.rank * chunk, from[p] + (size_t)sh.rank * chunk, chunk)) return 1;
+    *result_in_src = has_perm ? 1 : 0;
+    return 0;
+  }
   if (!has_perm) {
     HQ_HIP_CHECK(hipEventRecord(sh.ev[0], c.stream));  // src is final once the stream reaches here
     HQ_HIP_CHECK(hipStreamWaitEvent(cs, sh.ev[0], 0));
     HQ_NCCL_CHECK(sh, sh.api.GroupStart());
-    if (transfer_plane(S[0], D[0]) || transfer_plane(S[1], D[1])) { (void)sh.api.GroupEnd(); return 1; }
+    if (transfer_plane(S_[0], D[0]) || transfer_plane(S_[1], D[1])) { (void)sh.api.GroupEnd(); return 1; }
     HQ_NCCL_CHECK(sh, sh.api.GroupEnd());
     for (int p = 0; p < 2; ++p)
-      if (copy16(c, c.stream, D[p] + (size_t)sh.rank * chunk, S[p] + (size_t)sh.rank * chunk, chunk)) return 1;
+      if (copy16(c, c.stream, D[p] + (size_t)sh.rank * chunk, S_[p] + (size_t)sh.rank * chunk, chunk)) return 1;
     HQ_HIP_CHECK(hipEventRecord(sh.ev[2], cs));
     HQ_HIP_CHECK(hipStreamWaitEvent(c.stream, sh.ev[2], 0));
     *result_in_src = 0;
@@ -247,15 +305,15 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
   a.planes = 1;
   for (int p = 0; p < 2; ++p) {
     for (unsigned j = 0; j < G; ++j) a.dst[j][0] = D[p] + (size_t)j * chunk;
-    if (launch_pack<E>(c, c.stream, reinterpret_cast<const E*>(S[p]), (const E*)nullptr, a, perm)) return 1;
+    if (launch_pack<E>(c, c.stream, reinterpret_cast<const E*>(S_[p]), (const E*)nullptr, a, perm)) return 1;
     HQ_HIP_CHECK(hipEventRecord(sh.ev[p], c.stream));
     HQ_HIP_CHECK(hipStreamWaitEvent(cs, sh.ev[p], 0));
     HQ_NCCL_CHECK(sh, sh.api.GroupStart());
-    if (transfer_plane(D[p], S[p])) { (void)sh.api.GroupEnd(); return 1; }
+    if (transfer_plane(D[p], S_[p])) { (void)sh.api.GroupEnd(); return 1; }
     HQ_NCCL_CHECK(sh, sh.api.GroupEnd());
   }
   for (int p = 0; p < 2; ++p)  // self chunk: after BOTH packs (the main stream is ordered), src chunk `rank` is free
-    if (copy16(c, c.stream, S[p] + (size_t)sh.rank * chunk, D[p] + (size_t)sh.rank * chunk, chunk)) return 1;
+    if (copy16(c, c.stream, S_[p] + (size_t)sh.rank * chunk, D[p] + (size_t)sh.rank * chunk, chunk)) return 1;
   HQ_HIP_CHECK(hipEventRecord(sh.ev[2], cs));
   HQ_HIP_CHECK(hipStreamWaitEvent(c.stream, sh.ev[2], 0));
   *result_in_src = 1;
@@ -452,6 +510,29 @@ int hq_exchange_float32(float* src_re, float* src_im, float* dst_re, float* dst_
 int hq_exchange_float64(double* src_re, double* src_im, double* dst_re, double* dst_im, unsigned int n_local,
                         const unsigned int* perm, int* result_in_src) {
   return hq::exchange_entry<uint64_t>((uint64_t*)src_re, (uint64_t*)src_im, (uint64_t*)dst_re, (uint64_t*)dst_im, n_local, perm, result_in_src);
+}
+
+int hq_exchange_rounds_float32(float* src_re, float* src_im, float* dst_re, float* dst_im, unsigned int n_local,
+                               const unsigned int* perm, unsigned int sub_bits, int* result_in_src, unsigned int* n_rounds) {
+  if (!n_rounds) return hq::fail("exchange: null pointer");
+  return hq::exchange_entry<uint32_t>((uint32_t*)src_re, (uint32_t*)src_im, (uint32_t*)dst_re, (uint32_t*)dst_im, n_local, perm, result_in_src,
+                                      sub_bits, n_rounds);
+}
+
+int hq_exchange_rounds_float64(double* src_re, double* src_im, double* dst_re, double* dst_im, unsigned int n_local,
+                               const unsigned int* perm, unsigned int sub_bits, int* result_in_src, unsigned int* n_rounds) {
+  if (!n_rounds) return hq::fail("exchange: null pointer");
+  return hq::exchange_entry<uint64_t>((uint64_t*)src_re, (uint64_t*)src_im, (uint64_t*)dst_re, (uint64_t*)dst_im, n_local, perm, result_in_src,
+                                      sub_bits, n_rounds);
+}
+
+int hq_exchange_round_wait(unsigned int round) {
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::Shard& sh = hq::shard();
+  if (round >= sh.rounds_pending || round >= sh.round_ev.size()) return hq::fail("hq_exchange_round_wait: no such round");
+  HQ_HIP_CHECK(hipStreamWaitEvent(c.stream, sh.round_ev[round], 0));
+  return 0;
 }
 
 }  // extern "C"

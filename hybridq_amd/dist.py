@@ -264,8 +264,8 @@ def overlap_exchanges(schedule, m, g, sub_bits=OVERLAP_SUB_BITS, itemsize=4, bud
 
 
 def exchange_in_rounds(be, dist, src, dst, m, g, sub_bits, ops, group, rank, apply_ops):
-    """The executor of 'XO' on top of torch.distributed point-to-point operations (RCCL send / recv on the device, gloo
-    in the CPU tests): round s posts, for every peer j, the send of piece s of chunk j and the receive of piece s of the
+    """The executor of 'XO' for backends WITHOUT an exchange of their own (the numpy backend of the CPU tests over gloo;
+    HipBackend on its torch.distributed fallback transport) on top of torch.distributed point-to-point operations: round s posts, for every peer j, the send of piece s of chunk j and the receive of piece s of the
     peer's chunk for this rank; all rounds are posted at once, then the attached ops run on the pieces of round s as soon
     as that round has landed -- on the compute stream, while the later rounds are still moving.  The result is in `dst`."""
     G, S = 1 << g, 1 << sub_bits
@@ -562,6 +562,21 @@ class HipBackend:
         self.all_to_all(dst, src, group)
         return perm is not None
 
+    def exchange_rounds(self, src, dst, perm, m, sub_bits, group):
+        """The exchange in 2^sub_bits rounds (hq_exchange_rounds_*): returns (result in `src`?, number of rounds) without
+        having waited for the transfers; exchange_round_wait(r) makes the gate stream wait for round r.  The RCCL
+        transport runs all rounds on the library's communication stream; the peer-to-peer transport (one pass of
+        stores into the peers' planes between two host barriers) and the torch fallback complete before they return
+        and report ONE round."""
+        core = self.core
+        if self.transport in ('rccl', 'none'):
+            return core.exchange_rounds(src[0], src[1], dst[0], dst[1], perm, m, sub_bits)
+        return self.exchange(src, dst, perm, m, group), 1
+
+    def exchange_round_wait(self, r):
+        if self.transport in ('rccl', 'none'):
+            self.core.exchange_round_wait(r)
+
     def fill_zero(self, planes):
         planes.zero_()
 
@@ -751,14 +766,27 @@ class ShardedEvolution:
                 be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m)
                 self.cur = 1 - self.cur
             elif op[0] == 'XO':  # exchange in rounds, the attached local ops applied to the pieces as they land
-                if op[1] is not None:  # the eviction permutation as a pass of its own (the rounds move contiguous pieces)
-                    be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m)
+                if hasattr(be, 'exchange_rounds'):
+                    # behind the C ABI (hq_exchange_rounds_*): eviction permutation folded into the pack pass, the library's
+                    # own transports, one completion event per round that the gate stream waits for
+                    where, n_rounds = be.exchange_rounds(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m, op[2], self.group)
+                    res = self.bufs[self.cur] if where else self.bufs[1 - self.cur]
+                    G, S, n_sub = 1 << self.g, 1 << op[2], self.m - self.g - op[2]
+                    pieces = [res[pl].view(G, S, 1 << n_sub) for pl in (0, 1)]
+                    for r in range(n_rounds):
+                        be.exchange_round_wait(r)
+                        for s_ in range(r * S // n_rounds, (r + 1) * S // n_rounds):  # (one round: every piece)
+                            for j in range(G):
+                                self._apply_local_ops((pieces[0][j, s_], pieces[1][j, s_]), op[3], n_sub)
+                    if not where:
+                        self.cur = 1 - self.cur
+                else:
+                    if op[1] is not None:  # the eviction permutation as a pass of its own (the rounds move contiguous pieces)
+                        be.permute(self.bufs[self.cur], self.bufs[1 - self.cur], op[1], self.m)
+                        self.cur = 1 - self.cur
+                    exchange_in_rounds(be, self.dist, self.bufs[self.cur], self.bufs[1 - self.cur], self.m, self.g, op[2], op[3],
+                                       self.group, self.rank, self._apply_local_ops)
                     self.cur = 1 - self.cur
-                if hasattr(be, 'before_rounds'):
-                    be.before_rounds(self.group)
-                exchange_in_rounds(be, self.dist, self.bufs[self.cur], self.bufs[1 - self.cur], self.m, self.g, op[2], op[3],
-                                   self.group, self.rank, self._apply_local_ops)
-                self.cur = 1 - self.cur
             else:  # 'X' / 'XP': the exchange, with the eviction permutation folded in for 'XP'
                 perm = op[1] if op[0] == 'XP' else None
                 if hasattr(be, 'exchange'):

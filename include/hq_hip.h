@@ -235,6 +235,21 @@ int hq_exchange_float32(float *src_re, float *src_im, float *dst_re, float *dst_
                         const unsigned int *perm, int *result_in_src);
 int hq_exchange_float64(double *src_re, double *src_im, double *dst_re, double *dst_im, unsigned int n_local,
                         const unsigned int *perm, int *result_in_src);
+/* The same exchange in 2^sub_bits ROUNDS (sub_bits <= 6, n_local >= 2g + 2 + sub_bits): round s moves piece s (of
+ * 2^sub_bits) of every chunk, both planes -- all 2(G-1) transfers of a round in one ncclGroup, so every xGMI link is busy
+ * in every round -- and the library stream does NOT wait for the transfers: hq_exchange_round_wait(s) makes it wait for
+ * round s, after which pieces [chunk j][piece s] of the result planes (where *result_in_src says) are final and the
+ * caller may work on them while the later rounds are still on the wire (hybridq_amd.dist: the local gates attached to
+ * an exchange run on the pieces as they land).  The caller waits for EVERY round, the last one at the latest before it
+ * touches either plane pair in any other way.  The pack pass stays folded in (a plane's rounds start when that plane has
+ * been packed; the rounds of re overlap the pack of im).  *n_rounds: the number of rounds actually used -- 2^sub_bits on
+ * the RCCL transport, 1 on the peer-to-peer transport (whose stores the caller brackets with barriers as for
+ * hq_exchange_*) and on a single rank; hq_exchange_round_wait(0) is then a no-op in stream order. */
+int hq_exchange_rounds_float32(float *src_re, float *src_im, float *dst_re, float *dst_im, unsigned int n_local,
+                               const unsigned int *perm, unsigned int sub_bits, int *result_in_src, unsigned int *n_rounds);
+int hq_exchange_rounds_float64(double *src_re, double *src_im, double *dst_re, double *dst_im, unsigned int n_local,
+                               const unsigned int *perm, unsigned int sub_bits, int *result_in_src, unsigned int *n_rounds);
+int hq_exchange_round_wait(unsigned int round);
 
 /* sum_i re[i]^2 + im[i]^2 accumulated in double, written to *out (host).
  * Synchronises the stream.  Device pointers only. */
@@ -277,6 +292,13 @@ int hq_apply_blocked_float32(float *psi_re, float *psi_im, unsigned int n_qubits
 int hq_apply_blocked_float64(double *psi_re, double *psi_im, unsigned int n_qubits,
                              const unsigned int *tile_pos, unsigned int tile_bits, unsigned int n_gates,
                              const double *U_all, const unsigned int *pos_all, const unsigned int *k_all);
+
+/* The cache-blocked kernel variants written in rounds 3-4 (pipelined inner gates, barrier-free wave groups, direct first
+ * gate, 1024-thread tiles) are cross-checked on the device against the per-gate-barrier kernels of round 2 for the first
+ * HQ_BLOCKED_SELFCHECK (default 3) passes of a process; a variant whose result differs by one bit is switched off for the
+ * process with a warning on stderr.  *runs / *failures: checks done / failed so far; *switches: bit 0 pipelined gates,
+ * bit 1 barrier-free groups, bit 2 direct first gate, bit 3 1024-thread tiles currently ON.  Any pointer may be NULL. */
+int hq_blocked_selfcheck(int *runs, int *failures, int *switches);
 
 /* Compiled circuits.  Between hq_program_begin() and hq_program_end() every DEVICE-pointer call
  * of apply_U_*, hq_apply_blocked_*, swap_* (LDS path), hq_permute_bits_*, hq_to_complex*,

@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_round4.py (a fresh process: the library reads HQ_BLOCKED_* once).  The cache-blocked
-schedule of a depth-16 benchmark-generator circuit, pass by pass, with whatever HQ_BLOCKED_DIRECT / HQ_BLOCKED_GRID the
-caller set, against the per-gate kernels on the same initial state.  Prints one JSON line."""
+schedule of a depth-16 benchmark-generator circuit, pass by pass, with whatever HQ_BLOCKED_* the caller set, against the
+ORACLE (the reference core driven by the reference protocol on the same gates and the same initial state; U.h:87-95) --
+the parity statement -- and, as extras, against the per-gate HIP kernels and against a second run.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -19,6 +20,9 @@ from hybridq_amd import core  # noqa: E402
 from hybridq_amd.blocking import plan_blocked  # noqa: E402
 from hybridq_amd.circuits import rqc_1q2q  # noqa: E402
 from tolerances import circuit_tol  # noqa: E402
+import oracle  # noqa: E402
+
+ORACLE = oracle.load_ref() if oracle.have_ref() else oracle.load_port()
 
 core.use_torch_stream()
 out = {}
@@ -33,6 +37,8 @@ for ct, ft, n, inner in CASES:
     ops = plan_blocked(gates, ident, n, tile_bits=min(tb, n), low_bits=5 if ct == 'complex64' else 4, complex_type=ct, inner_max=inner)
     base = torch.from_numpy(rng.standard_normal((2, 1 << n))).to(ft).cuda()
     base /= base.norm()
+    host0 = base.cpu().numpy()
+    exp, _ = oracle.evolve_reference_protocol(ORACLE, gates, n, initial_state=host0[0] + 1j * host0[1], qubits=list(range(n)), complex_type=ct)
     ref = base.clone()
     for U, qs in gates:
         core.apply_U(ref[0], ref[1], np.ascontiguousarray(U, dtype=ct), [ident[q] for q in reversed(qs)], n)
@@ -47,6 +53,8 @@ for ct, ft, n, inner in CASES:
             big.append('1024' in core.last_kernel_desc())
     core.sync()
     err = float(((got - ref).abs().max() / ref.abs().max()).item())
+    got_h = got.cpu().numpy()
+    err_oracle = float(np.abs((got_h[0] + 1j * got_h[1]) - exp).max() / np.abs(exp).max())
     again = base.clone()
     for op in ops:
         if op[0] == 'G':
@@ -56,6 +64,8 @@ for ct, ft, n, inner in CASES:
     core.sync()
     import hashlib
     out[f'{ct} inner_max={inner}'] = {'n': n, 'passes': len(kinds), 'direct_passes': int(sum(kinds)), 'passes_1024_threads': int(sum(big)), 'err_vs_per_gate': err,
+               'err_vs_oracle': err_oracle, 'oracle': ORACLE.kind, 'literal_bar_met': bool(err_oracle <= (1e-6 if ct == 'complex64' else 1e-12)),
                'tol': circuit_tol(gates, gates, complex_type=ct), 'repeatable': bool(torch.equal(got, again)),
                'sha': hashlib.sha256(got.cpu().numpy().tobytes()).hexdigest()[:24]}
+out['selfcheck'] = core.blocked_selfcheck()
 print(json.dumps(out))

@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, 'hybridq_amd', 'csrc')
 #: memory access of every kernel body is bounds-checked against the emulated device allocations (malloc) -- the sanitizer
 #: run the GPU boxes could not do (their instrumented code object needs XNACK)
 ASAN = os.environ.get('HQ_EMU_ASAN') == '1'
-#: HQ_EMU_EXTRA_FLAGS='-DHQ_BLOCKED_NOPIPE -DHQ_GEMM_NOPIPE': an A/B build of the emulated library in its own directory (bit-identity checks
+#: HQ_EMU_EXTRA_FLAGS='-D...': an A/B build of the emulated library in its own directory (bit-identity checks
 #: between loop variants of a kernel: tests/test_emu_kernels.py::test_pipelined_loops_are_bit_identical)
 EXTRA = os.environ.get('HQ_EMU_EXTRA_FLAGS', '').split()
 OUT = os.path.join(HERE, '_build_asan' if ASAN else ('_build_ab' if EXTRA else '_build'))

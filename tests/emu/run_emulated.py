@@ -21,6 +21,22 @@ os.environ['HQ_EMU_GPU_SUITE'] = '1'
 import fake_cuda  # noqa: E402
 
 fake_cuda.install()
+
+# children the script starts as `python <file of this repository> ...` (bench.py's blocked_variants leg: one
+# tools/ab_blocked.py process per switch setting) run under this launcher too -- the product files know nothing of it
+import subprocess  # noqa: E402
+
+_run = subprocess.run
+
+
+def _run_emulated(cmd, *a, **kw):
+    if isinstance(cmd, (list, tuple)) and len(cmd) >= 2 and cmd[0] == sys.executable and str(cmd[1]).endswith('.py') \
+            and os.path.abspath(cmd[1]).startswith(ROOT + os.sep) and os.path.abspath(cmd[1]) != os.path.abspath(__file__):
+        cmd = [cmd[0], os.path.abspath(__file__)] + list(cmd[1:])
+    return _run(cmd, *a, **kw)
+
+
+subprocess.run = _run_emulated
 script = sys.argv[1]
 sys.argv = sys.argv[1:]
 runpy.run_path(os.path.join(ROOT, script) if not os.path.isabs(script) else script, run_name='__main__')

@@ -1,6 +1,6 @@
 """Worker of tests/test_emu_kernels.py::test_pipelined_loops_are_bit_identical: digests of cache-blocked passes (every shape of
 inner gate) and of k = 4..10 gates through the tile GEMM kernel on the emulated device; the caller runs it against the
-default build and against an HQ_EMU_EXTRA_FLAGS='-DHQ_BLOCKED_NOPIPE -DHQ_GEMM_NOPIPE' build and compares line by line."""
+default switches and under HQ_BLOCKED_PIPE=0 HQ_GEMM_PIPE=0 (the loops of rounds 1-4a) and compares line by line."""
 import hashlib
 import os
 import sys

@@ -62,7 +62,7 @@ def test_bench_line_end_to_end_against_the_emulated_library():
     for leg in ('cfg4_dense_k34', 'cfg5_noisy_dm'):
         assert line[leg]['roofline']['kernel'] and line[leg]['gate_apps_per_s'] > 0 and line[leg]['parity_small_n']['pass'] is True
     bv = line['blocked_variants']  # the opt-in kernel switches of round 4, one subprocess each
-    assert set(bv) == {'default', 'groups_off', 'direct', 'big_tiles', 'big_tiles_direct', 'low_bits_minus_1'} and not [k for k, v in bv.items() if 'error' in v], bv
+    assert set(bv) == {'default', 'groups_off', 'pipe_off', 'round2_kernels', 'direct', 'big_tiles', 'big_tiles_direct', 'low_bits_minus_1'} and not [k for k, v in bv.items() if 'error' in v], bv
     assert all(len(v['ms_per_step']) == 3 and v['passes'] >= 1 for v in bv.values()), bv  # (which kernels a 14-qubit circuit takes says nothing)
     pc = line['parity_check']
     assert pc['pass'] is True and pc['literal_bar_depth'] == pc['literal_bar_depth_of'] and len(pc['prefixes']) >= 8
@@ -90,4 +90,4 @@ def test_multi_rank_gpu_tests_against_the_emulated_library(transport):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=3600, cwd=ROOT)
     tail = out.stdout[-3000:]
     assert out.returncode == 0, tail + out.stderr[-2000:]
-    assert re.search(r'\b8 passed', tail), tail
+    assert re.search(r'\b11 passed', tail), tail

@@ -82,18 +82,17 @@ def _worker(rank, world, port, n, ct, out_dir):
         shb.run(schedb)
         psib = shb.state_numpy()
         nb = sum(1 for op in schedb if op[0] == 'B')
-        # exchange / compute overlap (round 4): exchanges in rounds of torch.distributed send / recv with the attached gates
-        # applied to the pieces by the REAL backend.  Needs point-to-point operations on device tensors: RCCL on a
-        # multi-GPU node, gloo on the emulated device; ranks sharing one real GPU over gloo cannot do it
-        n_xo, psi_o = -1, psi
-        if EMU or dist.get_backend() == 'nccl':
-            import hybridq_amd.dist as dist_mod
-            dist_mod.OVERLAP_MIN_SUB_QUBITS = 8
-            sho = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, overlap=True)
-            scho = sho.plan(gates)
-            n_xo = sum(1 for op in scho if op[0] == 'XO')
-            sho.run(scho)
-            psi_o = sho.state_numpy()
+        # exchange / compute overlap: exchanges in rounds behind the C ABI (hq_exchange_rounds_*: folded pack, the
+        # library's transports, one completion event per round), the attached gates applied to the pieces as they land
+        # (RCCL transport: 2^sub_bits rounds on the communication stream; peer-to-peer stores between ranks that share a
+        # GPU: one round)
+        import hybridq_amd.dist as dist_mod
+        dist_mod.OVERLAP_MIN_SUB_QUBITS = 8
+        sho = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, overlap=True)
+        scho = sho.plan(gates)
+        n_xo = sum(1 for op in scho if op[0] == 'XO')
+        sho.run(scho)
+        psi_o = sho.state_numpy()
         if rank == 0:
             np.savez(os.path.join(out_dir, 'out.npz'), psi=psi, psib=psib, nb=nb, raw=raw, psi_h=psi_h, transport=transport,
                      n_xo=n_xo, psi_o=psi_o,
@@ -120,10 +119,82 @@ def test_sharded_hip_backend_two_ranks_one_gpu(torch_cuda, tmp_path, world, n, c
     expb = oracle.evolve_tensordot(rqc_1q2q(n + 2, depth=8, seed=13), n + 2)
     assert np.abs(out['psib'] - expb).max() / np.abs(expb).max() < 5 * tol
     assert int(out['nb']) >= 1  # blocked passes were really used
-    if int(out['n_xo']) >= 0:  # overlapped exchanges ran (the pieces may dispatch to other kernels than the whole shard: to rounding)
+    if True:  # overlapped exchanges (the pieces may dispatch to other kernels than the whole shard: equal to rounding)
         assert int(out['n_xo']) >= 1
         assert np.abs(out['psi_o'] - exp).max() / np.abs(exp).max() < tol, np.abs(out['psi_o'] - exp).max() / np.abs(exp).max()
         assert np.abs(out['psi_o'] - out['psi']).max() / np.abs(exp).max() < tol
+
+
+def _rounds_worker(rank, world, port, out_dir):
+    import emu_boot
+    emu_boot.maybe_install()
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from hybridq_amd import core
+        from hybridq_amd.dist import HipBackend
+        g = int(np.log2(world))
+        report = {}
+        for ft, tdt, m in ((np.float32, torch.float32, 13), (np.float64, torch.float64, 12)):
+            be = HipBackend(ft, placement='plain')
+            bufs = [be.empty_planes(m), be.empty_planes(m)]
+            be.setup_exchange(None, bufs)
+            rng = np.random.default_rng(100 * rank + m)
+            data = torch.from_numpy(rng.standard_normal((2, 1 << m))).to(tdt).cuda()
+            prng = np.random.default_rng(m)  # the same permutations on every rank
+            perms = [None, prng.permutation(m), np.concatenate([np.arange(4), 4 + prng.permutation(m - 4)])]
+            for pi, perm in enumerate(perms):
+                for sub_bits in (1, 2):
+                    bufs[0].copy_(data)
+                    bufs[1].zero_()
+                    where = be.exchange(bufs[0], bufs[1], perm, m, None)
+                    plain = (bufs[0] if where else bufs[1]).clone()
+                    bufs[0].copy_(data)
+                    bufs[1].zero_()
+                    where_r, n_rounds = be.exchange_rounds(bufs[0], bufs[1], perm, m, sub_bits, None)
+                    res = bufs[0] if where_r else bufs[1]
+                    G, S = world, 1 << sub_bits
+                    seen = torch.zeros_like(res)
+                    for r in range(n_rounds):  # copy out the pieces of round r as soon as that round has landed
+                        be.exchange_round_wait(r)
+                        for s_ in range(r * S // n_rounds, (r + 1) * S // n_rounds):
+                            for pl in (0, 1):
+                                seen[pl].view(G, S, -1)[:, s_].copy_(res[pl].view(G, S, -1)[:, s_])
+                    be.sync()
+                    key = f'{ft.__name__} perm{pi} sub_bits={sub_bits}'
+                    report[key] = dict(rounds=n_rounds, where=(where, where_r), equal=bool(torch.equal(seen, plain)), transport=be.transport)
+            del bufs
+        everyone = [None] * world
+        dist.all_gather_object(everyone, report)
+        if rank == 0:
+            import json
+            with open(os.path.join(out_dir, 'rounds.json'), 'w') as f:
+                json.dump(everyone, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_exchange_rounds_equal_the_plain_exchange(torch_cuda, tmp_path, world):
+    """hq_exchange_rounds_* against hq_exchange_* between 2 / 4 / 8 processes on the library's own transport, without and
+    with a folded eviction permutation, 2 and 4 rounds: every piece, copied out right after ITS round's completion event,
+    is bit-identical to the plain exchange's result; same result planes.  (Ranks sharing one GPU: peer-to-peer stores,
+    one round; under the host emulation also the RCCL transport with real rounds on the communication stream.)"""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_rounds_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    everyone = json.load(open(os.path.join(str(tmp_path), 'rounds.json')))
+    assert len(everyone) == world
+    for rank, report in enumerate(everyone):
+        assert len(report) == 12
+        for key, r in report.items():
+            assert r['transport'] == WANT_TRANSPORT, (rank, key, r)
+            assert r['equal'] and r['where'][0] == r['where'][1], (rank, key, r)
+            assert r['rounds'] == (1 << int(key[-1]) if WANT_TRANSPORT == 'rccl' else 1), (rank, key, r)
 
 
 def test_exchange_one_rank_is_the_permutation(torch_cuda):

@@ -13,12 +13,42 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_ROUND2_LOOPS = {}
+
+
 def _worker(**env):
+    """{case: result} of tests/direct_gpu_worker.py under `env`; the library's own cross-check of the kernel variants (the
+    first passes of the process, bit for bit against the round-2 kernels) must have run and found nothing."""
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'direct_gpu_worker.py')], env=e, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    chk = res.pop('selfcheck')
+    assert 'disagree' not in r.stderr, r.stderr[-2000:]
+    if any(env.get(k, d) != '0' for k, d in (('HQ_BLOCKED_PIPE', '1'), ('HQ_BLOCKED_GROUPS', '1'), ('HQ_BLOCKED_DIRECT', '0'), ('HQ_BLOCKED_BIG', '0'))):
+        assert chk['runs'] >= 1 and chk['failures'] == 0, chk
+    for ct, r_ in res.items():  # the parity statement: every setting against the oracle
+        assert r_['err_vs_oracle'] <= r_['tol'], (ct, env, r_)
+    return res
+
+
+@pytest.mark.parametrize('env', [dict(HQ_BLOCKED_PIPE='0', HQ_BLOCKED_GROUPS='0'), dict(HQ_BLOCKED_PIPE='1', HQ_BLOCKED_GROUPS='0'),
+                                 dict(HQ_BLOCKED_PIPE='0', HQ_BLOCKED_GROUPS='1'), dict(HQ_BLOCKED_PIPE='1', HQ_BLOCKED_GROUPS='1')],
+                         ids=lambda e: 'pipe%s_groups%s' % (e['HQ_BLOCKED_PIPE'], e['HQ_BLOCKED_GROUPS']))
+def test_blocked_staged_variants_against_the_oracle(torch_cuda, capsys, env):
+    """The staged cache-blocked kernel in its four settings -- the loops of round 2 (HQ_BLOCKED_PIPE=0 HQ_BLOCKED_GROUPS=0:
+    the ones GPUTEST_r02 saw), pipelined inner gates, barrier-free wave groups, both (the default) -- each against the
+    oracle on a depth-16 circuit, several tiles per workgroup; all four agree bit for bit (same arithmetic, same order)."""
+    res = _worker(HQ_BLOCKED_GRID='256', **env)
+    with capsys.disabled():
+        print(f'\n  {env}: {res}')
+    if env == dict(HQ_BLOCKED_PIPE='0', HQ_BLOCKED_GROUPS='0'):  # (first parameter set)
+        _ROUND2_LOOPS.update(res)
+    base = _ROUND2_LOOPS or _worker(HQ_BLOCKED_GRID='256', HQ_BLOCKED_PIPE='0', HQ_BLOCKED_GROUPS='0')
+    for ct, r in res.items():
+        assert r['repeatable'] and r['direct_passes'] == 0, (ct, r)
+        assert r['sha'] == base[ct]['sha'], (ct, env)
 
 
 def test_blocked_direct_pass_on_the_device(torch_cuda, capsys):
