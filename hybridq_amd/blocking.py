@@ -254,7 +254,7 @@ def _plan_blocked_native(gates, pos_of, n, tile_bits, low_bits, inner_max, min_g
     # positions stand for the qubits: the planner sorts a fused gate's qubits by them (most significant first), this
     # module by label -- the same operator either way
     as_pos = [(U, [pos_of[q] for q in qs]) for U, qs in gates]
-    tol = exact_tolerance(gates)
+    tol = exact_tolerance(gates, ctype)
     kind, first, tile, gk, gpos, mats = core.plan_blocked(n, as_pos, tile_bits, low_bits, inner_max, min_gates, max(1, tries),
                                                            max(1, fusion_orders), 4 if single else 8, seed, tol)
     ops = []

@@ -74,11 +74,15 @@ static std::vector<cd> matmul(const std::vector<cd>& A, const std::vector<cd>& B
   return C;
 }
 
+// widest union of two gates whose commutator is still evaluated (2^24 complex entries per operand)
+constexpr size_t kMaxCommuteQubits = 12;
+
 // |AB - BA| <= tol + tol |BA| entry by entry (np.allclose's test); one row first: generic gates fail there
 static bool commute(const std::vector<cd>& U1, const std::vector<unsigned>& q1, const std::vector<cd>& U2,
                     const std::vector<unsigned>& q2, double tol) {
   if (!(mask_of(q1) & mask_of(q2))) return true;
   const std::vector<unsigned> Q = sorted_union(q1, q2);
+  if (Q.size() > kMaxCommuteQubits) return false;  // not tested (no reordering): three 2^(2|Q|) matrices would be needed
   const size_t D = (size_t)1 << Q.size();
   const std::vector<cd> A = embed(U1, q1, Q), B = embed(U2, q2, Q);
   for (size_t j = 0; j < D; ++j) {
@@ -466,12 +470,30 @@ static void plan_blocked(const std::vector<Gate>& gates, const Options& o, Resul
 }  // namespace plan
 }  // namespace hq
 
+namespace hq { namespace plan {
+// nothing thrown inside a planner (std::bad_alloc from a matrix a caller's limits made huge, std::length_error) may cross
+// the C ABI: it becomes an error code and a message
+template <typename F>
+static int guarded(const char* what, F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return hq::fail(std::string(what) + ": out of memory");
+  } catch (const std::exception& e) {
+    return hq::fail(std::string(what) + ": " + e.what());
+  } catch (...) {
+    return hq::fail(std::string(what) + ": unknown exception");
+  }
+}
+}}  // namespace hq::plan
+
 extern "C" {
 
 int hq_plan_blocked(unsigned int n_qubits, unsigned int n_gates, const unsigned int* k, const unsigned int* positions,
                     const double* U, unsigned int tile_bits, unsigned int low_bits, unsigned int inner_max,
                     unsigned int min_gates, unsigned int tries, unsigned int fusion_orders, unsigned int elem_bytes,
                     uint64_t seed, double commute_tol, void** plan) {
+  return hq::plan::guarded("hq_plan_blocked", [&]() -> int {
   using namespace hq::plan;
   if (!plan) return hq::fail("hq_plan_blocked: null output");
   *plan = nullptr;
@@ -497,19 +519,22 @@ int hq_plan_blocked(unsigned int n_qubits, unsigned int n_gates, const unsigned 
   plan_blocked(gates, o, *r);
   *plan = r;
   return 0;
+  });
 }
 
 int hq_plan_simplify(unsigned int n_qubits, unsigned int n_gates, const unsigned int* k, const unsigned int* qubits, const double* U,
                      double atol, int use_matrix_commutation, unsigned int max_n_qubits_matrix, int remove_id_gates,
                      unsigned int* out_index, unsigned int* out_count) {
+  return hq::plan::guarded("hq_plan_simplify", [&]() -> int {
   using namespace hq::plan;
   if (!out_index || !out_count) return hq::fail("hq_plan_simplify: null output");
   if (n_gates && (!k || !qubits || !U)) return hq::fail("hq_plan_simplify: null input");
   if (n_qubits == 0 || n_qubits > 62) return hq::fail("hq_plan_simplify: qubit ids must be below 62");
+  max_n_qubits_matrix = std::min<unsigned>(max_n_qubits_matrix, (unsigned)kMaxCommuteQubits);
   std::vector<Gate> gates(n_gates);
   size_t po = 0, uo = 0;
   for (unsigned g = 0; g < n_gates; ++g) {
-    if (k[g] == 0 || k[g] > 12) return hq::fail("hq_plan_simplify: gates act on 1..12 qubits");
+    if (k[g] == 0 || k[g] > hq::kMaxK) return hq::fail("hq_plan_simplify: gates act on 1..10 qubits");
     if (hq::check_positions(qubits + po, n_qubits, k[g])) return hq::fail("hq_plan_simplify: invalid qubit ids");
     gates[g].q.assign(qubits + po, qubits + po + k[g]);
     const size_t e = (size_t)1 << (2 * k[g]);
@@ -522,21 +547,25 @@ int hq_plan_simplify(unsigned int n_qubits, unsigned int n_gates, const unsigned
   std::copy(out.begin(), out.end(), out_index);
   *out_count = (unsigned)out.size();
   return 0;
+  });
 }
 
 int hq_plan_fuse(unsigned int n_qubits, unsigned int n_gates, const unsigned int* k, const unsigned int* qubits, const double* U,
                  unsigned int max_n_qubits, int use_matrix_commutation, unsigned int max_n_qubits_matrix, uint64_t exclude_mask,
                  double commute_tol, void** plan) {
+  return hq::plan::guarded("hq_plan_fuse", [&]() -> int {
   using namespace hq::plan;
   if (!plan) return hq::fail("hq_plan_fuse: null output");
   *plan = nullptr;
   if (n_gates && (!k || !qubits || !U)) return hq::fail("hq_plan_fuse: null input");
   if (n_qubits == 0 || n_qubits > 62) return hq::fail("hq_plan_fuse: qubit ids must be below 62");
   if (!(commute_tol > 0)) return hq::fail("hq_plan_fuse: commute_tol must be positive");
+  if (max_n_qubits > hq::kMaxK) return hq::fail("hq_plan_fuse: fused gates are limited to 10 qubits (max_n_qubits)");
+  max_n_qubits_matrix = std::min<unsigned>(max_n_qubits_matrix, (unsigned)kMaxCommuteQubits);
   std::vector<Gate> gates(n_gates);
   size_t po = 0, uo = 0;
   for (unsigned g = 0; g < n_gates; ++g) {
-    if (k[g] == 0 || k[g] > 12) return hq::fail("hq_plan_fuse: gates act on 1..12 qubits");
+    if (k[g] == 0 || k[g] > hq::kMaxK) return hq::fail("hq_plan_fuse: gates act on 1..10 qubits");
     if (hq::check_positions(qubits + po, n_qubits, k[g])) return hq::fail("hq_plan_fuse: invalid qubit ids");
     gates[g].q.assign(qubits + po, qubits + po + k[g]);
     const size_t e = (size_t)1 << (2 * k[g]);
@@ -562,10 +591,12 @@ int hq_plan_fuse(unsigned int n_qubits, unsigned int n_gates, const unsigned int
   }
   *plan = r;
   return 0;
+  });
 }
 
 int hq_plan_counts(const void* plan, unsigned int* n_ops, unsigned int* n_gates, uint64_t* n_positions,
                    uint64_t* n_matrix_elems, unsigned int* tile_bits) {
+  return hq::plan::guarded("hq_plan_counts", [&]() -> int {
   if (!plan) return hq::fail("hq_plan_counts: null plan");
   const hq::plan::Result& r = *static_cast<const hq::plan::Result*>(plan);
   uint64_t np = 0, ne = 0;
@@ -576,10 +607,12 @@ int hq_plan_counts(const void* plan, unsigned int* n_ops, unsigned int* n_gates,
   if (n_matrix_elems) *n_matrix_elems = ne;
   if (tile_bits) *tile_bits = r.tile_bits;
   return 0;
+  });
 }
 
 int hq_plan_read(const void* plan, unsigned int* op_kind, unsigned int* op_first_gate, unsigned int* op_tile,
                  unsigned int* gate_k, unsigned int* gate_positions, double* U) {
+  return hq::plan::guarded("hq_plan_read", [&]() -> int {
   if (!plan) return hq::fail("hq_plan_read: null plan");
   const hq::plan::Result& r = *static_cast<const hq::plan::Result*>(plan);
   if (op_kind) std::copy(r.op_kind.begin(), r.op_kind.end(), op_kind);
@@ -596,11 +629,14 @@ int hq_plan_read(const void* plan, unsigned int* op_kind, unsigned int* op_first
     uo += G.U.size();
   }
   return 0;
+  });
 }
 
 int hq_plan_free(void* plan) {
+  return hq::plan::guarded("hq_plan_free", [&]() -> int {
   delete static_cast<hq::plan::Result*>(plan);
   return 0;
+  });
 }
 
 }  // extern "C"

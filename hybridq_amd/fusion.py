@@ -85,6 +85,10 @@ def _sorted_union(a, b):
 _COMMUTE_ATOL = 1e-5
 
 
+#: widest union of two gates whose commutator is still evaluated (three 2^(2 |Q|) matrices)
+MAX_COMMUTE_QUBITS = 12
+
+
 def commute(U1, q1, U2, q2, atol=None, exact=False):
     """True if the two gates commute (trivially when they share no qubit); mirrors
     ``PowerMatrixGate.commutes_with`` (hybridq/gate/property.py:498-580), whose tolerance is fixed (`atol` is accepted and,
@@ -95,6 +99,8 @@ def commute(U1, q1, U2, q2, atol=None, exact=False):
     if not set(q1) & set(q2):
         return True
     Q = _sorted_union(q1, q2)
+    if len(Q) > MAX_COMMUTE_QUBITS:  # not tested = no reordering (csrc/hq_plan.hip: kMaxCommuteQubits)
+        return False
     A, B = _embed(U1, q1, Q), _embed(U2, q2, Q)
     # one row of the commutator first: generic gates that share a qubit fail right here (the verdict is the full
     # test's: it needs EVERY entry to pass), for O(D^2) instead of two D^3 products -- which the planners otherwise pay
@@ -110,11 +116,15 @@ def commute(U1, q1, U2, q2, atol=None, exact=False):
     return bool((np.abs(AB - BA) <= a_tol + r_tol * np.abs(BA)).all())  # np.allclose's test without its bookkeeping
 
 
-def exact_tolerance(gates):
+def exact_tolerance(gates, complex_type=None):
     """The "commutes to rounding" tolerance for a gate list: 1e-12 for double-precision matrices; 8 eps(float32) = 9.5e-7
     as soon as one matrix is given in single precision -- the commutator of two such gates that commute mathematically is
     ~sqrt(D) eps = 2-5e-7, and the stricter bound would silently stop the planner from sliding them, while
-    anything above stays below the 1e-6 bar of complex64 parity."""
+    anything above stays below the 1e-6 bar of complex64 parity.  A complex128 evolution (`complex_type`) keeps 1e-12
+    whatever the precision the matrices arrive in: its bar is 1e-12, and reordering a pair whose commutator is ~1e-6 would
+    move the state by as much."""
+    if complex_type is not None and np.dtype(complex_type) == np.dtype('complex128'):
+        return 1e-12
     single = any(np.asarray(U).dtype in (np.dtype('complex64'), np.dtype('float32'), np.dtype('float16')) for U, _ in gates)
     return 8 * float(np.finfo(np.float32).eps) if single else 1e-12
 
@@ -204,7 +214,7 @@ def fuse(gates, max_n_qubits=4, complex_type='complex64', use_matrix_commutation
     if max_n_qubits is None or max_n_qubits <= 0:
         return [(U.astype(complex_type), qs) for U, qs in gates]
     if exact_commutation is True:
-        exact_commutation = exact_tolerance(gates)
+        exact_commutation = exact_tolerance(gates, complex_type)
     if (native is None or native) and gates:
         labels = _sorted_union([q for _, qs in gates for q in qs], ())  # ids follow the order of the labels
         ok = (len(labels) <= 62 and max_n_qubits <= 10 and

@@ -337,7 +337,10 @@ int hq_plan_read(const void *plan, unsigned int *op_kind, unsigned int *op_first
 int hq_plan_free(void *plan);
 /* fusion.fuse = the reference's utils.compress + to_matrix_gate (hybridq/circuit/utils.py:467-685, 419-464) with its options;
  * `qubits` are integer ids below 62 whose ORDER is the order of the labels (a fused gate's qubits come out sorted, most
- * significant first); commute_tol 1e-5 reproduces the reference.  The plan holds one plain op per fused gate. */
+ * significant first); commute_tol 1e-5 reproduces the reference.  The plan holds one plain op per fused gate.
+ * Limits (all three planners): gates of 1..10 qubits, max_n_qubits <= 10, max_n_qubits_matrix is clamped to 12, and the
+ * commutator of two gates is only evaluated when their union has at most 12 qubits (wider: treated as not commuting).
+ * Nothing thrown inside a planner crosses the ABI: out-of-memory and the like come back as return code 1 + hq_last_error. */
 int hq_plan_fuse(unsigned int n_qubits, unsigned int n_gates, const unsigned int *k, const unsigned int *qubits, const double *U,
                  unsigned int max_n_qubits, int use_matrix_commutation, unsigned int max_n_qubits_matrix, uint64_t exclude_mask,
                  double commute_tol, void **plan);

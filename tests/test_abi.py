@@ -124,6 +124,20 @@ def test_exact_commutation_tolerance_follows_the_precision_of_the_gates():
     assert fusion.exact_tolerance([(rx(0.3), (0,))]) == 1e-12
     tol = fusion.exact_tolerance([(a64, (0,)), (rx(0.2), (1,))])
     assert 1e-7 < tol < 1e-6
+    # ... of the gates AND of the evolution: a complex128 run keeps its 1e-12 whatever precision the matrices arrive in
+    # (ADVICE r04), in both planners
+    assert fusion.exact_tolerance([(a64, (0,)), (rx(0.2), (1,))], 'complex128') == 1e-12
+    assert fusion.exact_tolerance([(a64, (0,)), (rx(0.2), (1,))], 'complex64') == tol
+    from hybridq_amd.blocking import plan_blocked
+    # a pair that commutes to ~1e-7 only (single-precision rounding of the matrices) around a gate that blocks one of them
+    c = np.array([[0, 1], [1, 0]], dtype=np.complex64)
+    circ = [(a64, (0,)), (np.kron(c, c).astype(np.complex64), (0, 1)), (b64, (0,))]
+    for native in (True, False):
+        kw = dict(tile_bits=10, low_bits=4, native=native)
+        ops64 = plan_blocked(circ, {q: q for q in range(14)}, 14, complex_type='complex64', **kw)
+        ops128 = plan_blocked(circ, {q: q for q in range(14)}, 14, complex_type='complex128', **kw)
+        for ops, ct in ((ops64, np.complex64), (ops128, np.complex128)):
+            assert all(U.dtype == ct for op in ops for U in ([u for u, _ in op[2]] if op[0] == 'B' else [op[1]]))
     assert not fusion.commute(a64, (0,), b64, (0,), exact=True) or np.abs(a64 @ b64 - b64 @ a64).max() <= 1e-12
     assert fusion.commute(a64, (0,), b64, (0,), exact=tol)
     z = np.diag([1, 1j]).astype(np.complex64)

@@ -156,3 +156,27 @@ def test_native_fuse_equals_the_python_statement():
                    dict(max_n_qubits=6, max_n_qubits_matrix=3)):
             assert same(fusion.fuse(g, native=False, **kw), fusion.fuse(g, native=True, **kw)), (trial, kw)
         assert same(fusion.fuse(labelled, 4, native=False), fusion.fuse(labelled, 4)), trial
+
+
+def test_planner_limits_come_back_as_error_codes():
+    """ADVICE r04: a C caller's oversized limits must not abort the process (std::bad_alloc across the ABI): max_n_qubits
+    above 10 and gates wider than 10 qubits are refused with a message; a commutator over a union wider than 12 qubits is
+    not evaluated (both planners treat the pair as not commuting)."""
+    import ctypes
+    from hybridq_amd import core, fusion
+    U32P = ctypes.POINTER(ctypes.c_uint32)
+    k = np.array([1, 1], dtype=np.uint32)
+    q = np.array([0, 1], dtype=np.uint32)
+    U = np.tile(np.eye(2, dtype=np.complex128).view(np.float64).reshape(-1), 2).copy()
+    plan = ctypes.c_void_p()
+    rc = core._lib.hq_plan_fuse(ctypes.c_uint(2), ctypes.c_uint(2), k.ctypes.data_as(U32P), q.ctypes.data_as(U32P), ctypes.c_void_p(U.ctypes.data),
+                                ctypes.c_uint(40), ctypes.c_int(1), ctypes.c_uint(40), ctypes.c_uint64(0), ctypes.c_double(1e-5), ctypes.byref(plan))
+    assert rc == 1 and 'limited to 10 qubits' in core.last_error() and not plan.value
+    k11 = np.array([11], dtype=np.uint32)
+    q11 = np.arange(11, dtype=np.uint32)
+    rc = core._lib.hq_plan_fuse(ctypes.c_uint(11), ctypes.c_uint(1), k11.ctypes.data_as(U32P), q11.ctypes.data_as(U32P), ctypes.c_void_p(U.ctypes.data),
+                                ctypes.c_uint(4), ctypes.c_int(1), ctypes.c_uint(10), ctypes.c_uint64(0), ctypes.c_double(1e-5), ctypes.byref(plan))
+    assert rc == 1 and '1..10 qubits' in core.last_error()
+    wide = np.eye(1 << 7, dtype=np.complex128)  # identities commute -- but the union of the two has 13 qubits
+    assert not fusion.commute(wide, tuple(range(7)), wide, tuple(range(6, 13)))
+    assert fusion.commute(wide, tuple(range(7)), wide, tuple(range(5, 12)))
