@@ -154,7 +154,7 @@ static bool plan_mfma(const Context& c, const T* U, const unsigned* pos, unsigne
   std::vector<Digit> E;
   uint64_t used = 0;
   for (unsigned j = 0; j < k; ++j) { E.push_back({sp[j], (int)j}); used |= 1ull << sp[j]; }
-  // Where the identity dummies of a k < 3 gate go (measured at n = 30, tools/sweep_dummy.py):
+  // Where the identity dummies of a k < 3 gate go (measured at n = 30 in round 2; the sweep script is in the history: tools/sweep_dummy.py):
   // in free index bits >= 6.  They become register digits whose 16-byte accesses are >= 256 B
   // apart (non-temporal policy applies) while the real low targets keep the q-digit role (a
   // permutation of one contiguous run).  Never slower than the two earlier placements

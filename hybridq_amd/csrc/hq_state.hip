@@ -312,7 +312,7 @@ static void state_release(StateAlloc& st) {
   st = StateAlloc();
 }
 
-constexpr size_t kPlanePadBytes = 12288;     // measured at n = 30 (tools/sweep_pad.py): +3..15 % for high targets
+constexpr size_t kPlanePadBytes = 12288;     // measured at n = 30 (round 1 sweep; script in the history): +3..15 % for high targets
 constexpr size_t kTunedMinBytes = 1u << 28;  // states below this stay on hipMalloc memory (HQ_STATE_TUNED_MIN_BYTES: tests)
 static size_t tuned_min_bytes() {
   const char* e = getenv("HQ_STATE_TUNED_MIN_BYTES");
