@@ -295,6 +295,22 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar for the optimiser
   const unsigned q = lane >> 4, j = lane & 15;
   const V* __restrict__ Al = As + lane;
+  // A ds_read carries a 16-bit byte offset: with a table above 64 KiB (complex128 k = 6: 128 KiB) the compiler
+  // materialised one address register per operand read in the upper half and SPILLED them to reuse in the second column
+  // block -- 10 of the 13 dwords of scratch that instantiation had in rounds 2-4, which had been put down to the 32 input
+  // vectors + 8 accumulator blocks and had cost it its operand pipelining.  A second, opaque base address 64 KiB up keeps
+  // every read at base + immediate (32-bit LDS addresses: a pointer through inline assembly loses its address space):
+  // 223 registers with the operand pipeline, no scratch.
+  constexpr int kHalf = 65536 / 16;  // vectors
+  constexpr bool kTwoBases = (size_t)NRB * NG * 64 > (size_t)kHalf;
+  typedef __attribute__((address_space(3))) const V LdsCV;
+  const unsigned al_lo = (unsigned)reinterpret_cast<uintptr_t>(Al);  // LDS byte address of this lane's slot of row 0
+  unsigned al_hi = al_lo + (kTwoBases ? 65536u : 0u);
+  if constexpr (kTwoBases) asm volatile("" : "+v"(al_hi));
+  auto Aop = [&](const int idx) -> V {
+    if constexpr (!kTwoBases) return Al[idx];
+    else return *reinterpret_cast<LdsCV*>((uintptr_t)((idx >= kHalf ? al_hi : al_lo) + 16u * (unsigned)(idx & (kHalf - 1))));
+  };
   // address of load ld in iteration it = lane base (loop-invariant, per lane: plane of the q digit,
   // q-digit offsets, the slot bits j spread over the non-digit index bits) + 16 * spread(it * 16)
   // (wave-uniform, a handful of scalar ops per iteration) + tab.off[ld] (wave-uniform, scalar load)
@@ -337,9 +353,8 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
   // available after 40: back-to-back MFMAs on ONE accumulator lose a fifth of the pipe).  The
   // pipeline runs across column blocks (the operand sequence repeats): only the first read of an
   // iteration is exposed.  Alone this phase runs at 149 of 157 TFLOP/s (k = 6 knock-out).
-  constexpr bool kOperandPipe = !(sizeof(T) == 8 && NL == 32);  // (with it the complex128 k = 6 kernel needs 218 registers and spills)
   auto compute = [&](V (&x)[NL]) {
-    V a0 = Al[0], a1 = Al[NG * 64];
+    V a0 = Aop(0), a1 = Aop(NG * 64);
 #pragma unroll
     for (int cf = 0; cf < NCB; ++cf) {
       Acc acc[NRB];
@@ -350,16 +365,9 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
         const int sg = g / NP, rb = 2 * (g % NP);
         const int gn = (g + 1) % NGRP, sgn = gn / NP, rbn = 2 * (gn % NP);
         V n0 = a0, n1 = a1;
-        if constexpr (kOperandPipe) {
-          if (g + 1 < NGRP || cf + 1 < NCB) {
-            n0 = Al[(rbn * NG + sgn) * 64];
-            n1 = Al[((rbn + 1) * NG + sgn) * 64];
-          }
-        } else {  // complex128 k = 6 without a component target: no registers for a second operand pair
-          a0 = Al[(rb * NG + sg) * 64];
-          a1 = Al[((rb + 1) * NG + sg) * 64];
-          n0 = a0;
-          n1 = a1;
+        if (g + 1 < NGRP || cf + 1 < NCB) {
+          n0 = Aop((rbn * NG + sgn) * 64);
+          n1 = Aop(((rbn + 1) * NG + sgn) * 64);
         }
         __builtin_amdgcn_sched_barrier(0);  // the reads of the NEXT pair-group stay in front of ...
 #pragma unroll

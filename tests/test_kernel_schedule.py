@@ -46,14 +46,41 @@ def _awaited_reads(body):
     return n
 
 
-@pytest.mark.parametrize('name', ['apply_blocked_kernel<float, 512, true, true>', 'apply_blocked_kernel<double, 512, true, true>',
-                                  'apply_blocked_kernel<float, 1024, true, true>', 'apply_blocked_direct_kernel<float, 512>',
+@pytest.mark.parametrize('name', ['apply_blocked_kernel<float, 512, true, true, true>', 'apply_blocked_kernel<double, 512, true, true, true>',
+                                  'apply_blocked_kernel<float, 1024, true, true, true>', 'apply_blocked_direct_kernel<float, 512>',
                                   'apply_blocked_direct_kernel<double, 512>'])
 def test_lds_reads_stay_ahead_of_the_matrix_cores(kernels, name):
     body = kernels[name]
     mfma = sum(ln.startswith('v_mfma') for ln in _instructions(body))
     awaited = _awaited_reads(body)
     assert mfma >= 100 and awaited / mfma <= 0.06, (name, awaited, mfma)
+
+
+def test_the_old_loops_are_still_what_pipe_off_selects(kernels):
+    """PIPE = false (HQ_BLOCKED_PIPE=0) must stay the loop of rounds 2-4a -- it is the reference of the library's self-check
+    and of the A/B: reads awaited in front of the MFMAs as the compiler places them (0.13 per MFMA)."""
+    body = kernels['apply_blocked_kernel<float, 512, true, true, false>']
+    mfma = sum(ln.startswith('v_mfma') for ln in _instructions(body))
+    assert mfma >= 100 and _awaited_reads(body) / mfma >= 0.10
+
+
+@pytest.mark.parametrize('name,min_mfma', [('apply_mfma_big_kernel<double, 7, 0, true, 512, true>', 512),
+                                           ('apply_mfma_big_kernel<double, 7, 1, true, 512, true>', 256),
+                                           ('apply_mfma_big_kernel<float, 7, 0, true, 512, true>', 512)])
+def test_role_kernel_operand_reads_are_base_plus_immediate(kernels, name, min_mfma):
+    """k = 6 role kernels: every operand read of the MFMA phase is `ds_read_b128 dst, base offset:imm` on one of at most two
+    base registers (tables above 64 KiB: a second base 64 KiB up), one pair-group ahead of its MFMAs (lgkmcnt(2) / (3),
+    never 0 inside the phase), and nothing is spilled -- the complex128 instantiation kept per-read address registers alive
+    across its column blocks until round 5 (52 B/lane of scratch, no operand pipelining)."""
+    ins = _instructions(kernels[name])
+    assert sum(ln.startswith('v_mfma') for ln in ins) >= min_mfma
+    assert not [ln for ln in ins if ln.startswith('scratch_')]
+    reads = [ln for ln in ins if ln.startswith('ds_read_b128')]
+    bases = {re.split(r'[,\s]+', ln)[2] for ln in reads}
+    assert len(reads) >= min_mfma // 4 and len(bases) <= 2, (len(reads), bases)
+    first, last = [i for i, ln in enumerate(ins) if ln.startswith('v_mfma')][0], [i for i, ln in enumerate(ins) if ln.startswith('v_mfma')][-1]
+    drained = [ln for ln in ins[first + 8:last] if ln.startswith('s_waitcnt') and 'lgkmcnt(0)' in ln]
+    assert len(drained) <= 2, drained
 
 
 @pytest.mark.parametrize('name', ['apply_blocked_direct_kernel<float, 512>', 'apply_blocked_direct_kernel<double, 512>',
