@@ -860,15 +860,15 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
   const bool pref = sw.pref && block_threads != 256 && ((tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits)) || big);
   // Tile movement folded into the first gate (apply_blocked_direct_kernel): the pass needs a
-  // k <= 3 matrix-core gate (KBITS = 4) whose register digits lie above tile-local vector bit 2 -- every wave-level HBM
+  // matrix-core gate (k <= 4) whose register digits lie above tile-local vector bit 2 -- every wave-level HBM
   // access of the gate's own addressing is then a set of whole 128-byte lines -- that may run first: the earliest such gate
   // that shares no position with the gates in front of it is moved to the front (disjoint gates commute exactly).
   bool direct = false;
-  if (sw.direct && sw.pipe && pref && n_gates >= 2 && a_in_lds && fits &&
-      Atab.size() * sizeof(T) + tab_bytes + blocked_gtab_words<1024>() * sizeof(uint64_t) <= a_budget) {
+  const size_t gtab_bytes = (big ? blocked_gtab_words<1024>() : blocked_gtab_words<512>()) * sizeof(uint64_t);
+  if (sw.direct && sw.pipe && pref && n_gates >= 2 && a_in_lds && fits && Atab.size() * sizeof(T) + tab_bytes + gtab_bytes <= a_budget) {
     auto eligible = [&](const BlockedGate& G) {
-      if (G.kv < 16 || G.kv > 19) return false;
-      const unsigned nr = 2u - (unsigned)__builtin_popcount(G.kv & 3u);
+      if (G.kv < 16 || G.kv > 23) return false;  // matrix-core gates: KBITS = 4 (k <= 3), 5 (k = 4)
+      const unsigned nr = (G.kv >> 2) - 2u - (unsigned)__builtin_popcount(G.kv & 3u);
       for (unsigned b = 0; b < nr; ++b)
         if (G.ro.r_plane != (int)b && G.ro.r_off[b] < 8u) return false;
       return true;
@@ -934,7 +934,7 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
 #define HQ_BLOCKED_LAUNCH(kern, threads_, lds_, ae_) \
   HQ_LAUNCH(c, kern, dim3(grid), dim3(threads_), lds_, re, im, pG, n_gates, pA, ae_, ba, ntiles)
   if (fits) {
-    const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes + (direct ? blocked_gtab_words<1024>() * sizeof(uint64_t) : 0);
+    const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes + (direct ? gtab_bytes : 0);
     if (big) {
       if (direct) HQ_BLOCKED_LAUNCH((apply_blocked_direct_kernel<T, 1024>), 1024, lds, a_elems);
       else HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 1024, true, true, true>), 1024, lds, a_elems);

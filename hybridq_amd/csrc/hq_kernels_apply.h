@@ -1142,8 +1142,8 @@ apply_blocked_kernel(T* __restrict__ re, T* __restrict__ im, const BlockedGate* 
 // streams it back LDS -> registers -> HBM (store phase): per tile that is two LDS passes, two workgroup barriers and a
 // BURST of 8 stores + 8 loads per lane issued into a memory system that is already saturated -- the waves stall at
 // issue and the matrix cores see only the other workgroup of the CU meanwhile (~1.3 ms of every 4.9 ms pass at
-// n = 30).  Here the first gate of the pass (a k <= 3 matrix-core gate: KBITS = 4) does the movement in ITS OWN
-// addressing:
+// n = 30).  Here the first gate of the pass (a matrix-core gate: KBITS = 4 for k <= 3, KBITS = 5 for k = 4) does the
+// movement in ITS OWN addressing:
 //   * the prefetch requests the next tile's vectors from HBM as that gate's B operands (lane (q, j), wave-iteration,
 //     register digit -> global address through two 64-bit tables built once per kernel: GLANE[lane] ^ GWAVE[wave][i]);
 //   * the gate multiplies straight from the prefetch registers and writes its results into the LDS tile -- no fill pass;
@@ -1158,6 +1158,16 @@ constexpr unsigned kBlockedGTabLane = 0, kBlockedGTabWave = 64;  // 64-bit words
 template <int BLOCK> constexpr unsigned blocked_gtab_words() { return kBlockedGTabWave + (BLOCK / 64) * 8; }
 constexpr unsigned kBlockedGTabWords = blocked_gtab_words<512>();
 constexpr uint64_t kBlockedPlaneBit = 1ull << 63;  // of a table entry: the vector lives in the imaginary plane
+// This lane's entry of the GLANE part.  The lane index is recomputed HERE from the thread index, opaquely: one shared
+// address register kept alive across all the gates of a tile is what the complex128 kernel (128 registers, 32 of them the
+// prefetch) spilled -- and a scratch reload is a vector-memory load that queues behind the prefetch (vmcnt is in order).
+__device__ __forceinline__ uint64_t blocked_gtab_lane(const uint64_t* __restrict__ gt) {
+  unsigned l = threadIdx.x & 63u;
+#ifndef HQ_ASAN
+  asm volatile("" : "+v"(l));
+#endif
+  return gt[kBlockedGTabLane + l];
+}
 
 template <typename T, int BLOCK>
 __device__ __forceinline__ void blocked_build_direct_tables(uint64_t* __restrict__ gt, const BlockedGate& G,
@@ -1166,7 +1176,7 @@ __device__ __forceinline__ void blocked_build_direct_tables(uint64_t* __restrict
   constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
   const MfmaRoles& ro = G.ro;
   const unsigned digits = blocked_digits(ro), wmask = G.wave_bits & ~kBlockedNoBarrier;
-  const unsigned nr = 2u - (unsigned)__builtin_popcount(G.kv & 3u);  // register digits of a KBITS = 4 gate
+  const unsigned nr = (G.kv >> 2) - 2u - (unsigned)__builtin_popcount(G.kv & 3u);  // register digits of the first gate (KBITS = kv >> 2)
   auto vec_off = [&](unsigned e) {  // tile-local vector index -> global vector offset (OR-linear)
     uint64_t g = 0;
     for (unsigned m = CB; m < ba.tb; ++m) g |= (uint64_t)((e >> (m - CB)) & 1u) << (ba.apos[m] - CB);
@@ -1192,9 +1202,17 @@ __device__ __forceinline__ void blocked_build_direct_tables(uint64_t* __restrict
   }
 }
 
-// The first gate of a direct pass: blocked_inner_gate_tab<T, 4, VMASK, BLOCK> with its B operands in `pf` and the
-// store-out of the previous tile in front of every overwrite.
-template <typename T, int VMASK, int BLOCK>
+// The first gate of a direct pass: blocked_inner_gate_tab<T, KBITS, VMASK, BLOCK> with its B operands in `pf` and the
+// store-out of the previous tile in front of every overwrite.  KBITS = 4 (k <= 3) or 5 (k = 4, round 5).
+//
+// A wave owns 8 vectors per lane of the tile (both planes): NITL wave-iterations of NL vectors.  The work is cut into
+// HALVES of NLH = 4 >> KV result vectors -- one output row block of one wave-iteration each (KBITS = 4: NRB = 1, a half
+// IS an iteration; KBITS = 5: NRB = 2 row blocks per iteration).  A half multiplies ALL NL prefetched vectors of its
+// iteration by its row block of the operand table (the inputs live in registers, so the LDS slots of the tile are free
+// to be overwritten half by half), and its results are exactly the vectors ld = rb * NLH .. rb * NLH + NLH - 1 of the
+// iteration: only one row block of accumulators is live at a time (k = 4 without a component target: 16 instead of 32
+// registers beside the 32 of the prefetch), and the store-out moves NLH vectors at a time.
+template <typename T, int KBITS, int VMASK, int BLOCK>
 __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, const BlockedTabT* __restrict__ tab,
                                                      const uint64_t* __restrict__ gt,
                                                      typename Vec<T>::type (&pf)[8], const bool have_prev,
@@ -1203,40 +1221,59 @@ __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, co
                                                      typename Vec<T>::type* __restrict__ vim) {
   using V = typename Vec<T>::type;
   using Acc = typename Mfma<T>::acc;
-  constexpr int KBITS = 4;
+  static_assert(KBITS == 4 || KBITS == 5, "first gates of a direct pass: k <= 4");
   constexpr int CB = Vec<T>::VB, NCOMP = 1 << CB;
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
-  constexpr int NCB = 1 << (CB - KV), NSTEP = 1 << NS, NITL = 8 / NL;
+  constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS, NITL = 8 / NL;
+  constexpr int NLH = NL / NRB, NH = NITL * NRB;  // result vectors per half, halves per wave
   constexpr int FMASK = ~VMASK & (NCOMP - 1);
+  static_assert(NLH * NH == 8 && NLH == (4 >> KV), "eight vectors per lane");
   constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  T a[NSTEP];
+  // the operand rows of both row blocks up front (KBITS = 5, f32: 16 registers) -- or one row block at a time, re-read at
+  // the top of each half (f64: 2 x 16 registers do not fit beside the prefetch; the read hides behind 32 f64 MFMAs)
+  constexpr bool kRowsUpFront = NRB == 1 || sizeof(T) == 4;
+  T a[kRowsUpFront ? NRB : 1][NSTEP];
+  if constexpr (kRowsUpFront) {
 #pragma unroll
-  for (int s = 0; s < NSTEP; ++s) a[s] = A[s * 64 + lane];
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) a[rb][s] = A[(rb * NSTEP + s) * 64 + lane];
+  }
   const unsigned L = tab[BlockedTab<BLOCK>::kLane + lane];
   unsigned OFF[NL];
 #pragma unroll
   for (int ld = 0; ld < NL; ++ld) OFF[ld] = tab[BlockedTab<BLOCK>::kOff + ld];
-  const uint64_t gl = gt[kBlockedGTabLane + lane];
+  const uint64_t gl = blocked_gtab_lane(gt);
   typedef __attribute__((address_space(3))) V LdsV;
-  // The store-out reads run one wave-iteration AHEAD of the MFMAs (left in program order -- read, store, multiply -- every
-  // iteration had an LDS round trip in front of its MFMAs; see blocked_inner_gate_tab): the slots of iteration i + 1 are
-  // requested before the MFMAs of iteration i, the stores of iteration i are issued behind its MFMAs.
+  // The store-out reads run one half AHEAD of the MFMAs (left in program order -- read, store, multiply -- every
+  // half had an LDS round trip in front of its MFMAs; see blocked_inner_gate_tab): the slots of half h + 1 are
+  // requested before the MFMAs of half h, the stores of half h are issued behind its MFMAs.
   unsigned Ltv[NITL];
 #pragma unroll
   for (int itl = 0; itl < NITL; ++itl) Ltv[itl] = L ^ tab[BlockedTab<BLOCK>::kIter + wave + ((unsigned)itl << WB)];
-  V t[2][NL];
-  if (have_prev) {  // uniform
+  // (complex128: no registers for a second set -- the slots of half h are requested in front of ITS OWN MFMAs, which
+  // still hides the round trip: the data is first needed by the stores behind them)
+  constexpr int TD = sizeof(T) == 8 ? 1 : 2;
+  V t[TD][NLH];
+  auto request_out = [&](V (&dst)[NLH], const int h) {  // h = itl * NRB + rb
 #pragma unroll
-    for (int ld = 0; ld < NL; ++ld) t[0][ld] = *reinterpret_cast<LdsV*>((uintptr_t)(Ltv[0] ^ OFF[ld]));
-  }
+    for (int l = 0; l < NLH; ++l) dst[l] = *reinterpret_cast<LdsV*>((uintptr_t)(Ltv[h / NRB] ^ OFF[(h % NRB) * NLH + l]));
+  };
+  if (TD == 2 && have_prev) request_out(t[0], 0);  // uniform
 #pragma unroll
-  for (int itl = 0; itl < NITL; ++itl) {
+  for (int h = 0; h < NH; ++h) {
+    const int itl = h / NRB, rb = h % NRB;
     const unsigned Lt = Ltv[itl];
-    if (have_prev && itl + 1 < NITL) {
+    if constexpr (TD == 2) {
+      if (have_prev && h + 1 < NH) request_out(t[(h + 1) & 1], h + 1);
+    } else {
+      if (have_prev) request_out(t[0], h);
+    }
+    if constexpr (!kRowsUpFront) {
 #pragma unroll
-      for (int ld = 0; ld < NL; ++ld) t[(itl + 1) & 1][ld] = *reinterpret_cast<LdsV*>((uintptr_t)(Ltv[itl + 1] ^ OFF[ld]));
+      for (int s = 0; s < NSTEP; ++s) a[0][s] = A[(rb * NSTEP + s) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
     Acc acc[NCB];
@@ -1248,20 +1285,21 @@ __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, co
 #pragma unroll
       for (int cf = 0; cf < NCB; ++cf) {
         const int comp = pdep_c(ck, VMASK) | pdep_c(cf, FMASK);
-        acc[cf] = Mfma<T>::run(a[s], pf[itl * NL + ld][comp], acc[cf]);
+        acc[cf] = Mfma<T>::run(a[kRowsUpFront ? rb : 0][s], pf[itl * NL + ld][comp], acc[cf]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (have_prev) {  // the finished amplitudes of the previous tile leave from the slots this iteration overwrites
+    if (have_prev) {  // the finished amplitudes of the previous tile leave from the slots this half overwrites
 #pragma unroll
-      for (int ld = 0; ld < NL; ++ld) {
-        const uint64_t o = gl ^ gt[kBlockedGTabWave + wave * 8 + itl * NL + ld];
+      for (int l = 0; l < NLH; ++l) {
+        const uint64_t o = gl ^ gt[kBlockedGTabWave + wave * 8 + itl * NL + rb * NLH + l];
         V* const p = (o & kBlockedPlaneBit) ? vim : vre;
-        __builtin_nontemporal_store(t[itl & 1][ld], p + (base_prev | (o & ~kBlockedPlaneBit)));
+        __builtin_nontemporal_store(t[h & (TD - 1)][l], p + (base_prev | (o & ~kBlockedPlaneBit)));
       }
     }
 #pragma unroll
-    for (int ld = 0; ld < NL; ++ld) {
+    for (int l = 0; l < NLH; ++l) {
+      const int ld = rb * NLH + l;  // so = ck | (ld << KV) lies in row block rb: so >> 2 == rb
       V y;
 #pragma unroll
       for (int comp = 0; comp < NCOMP; ++comp) {
@@ -1272,7 +1310,7 @@ __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, co
       *reinterpret_cast<LdsV*>((uintptr_t)(Lt ^ OFF[ld])) = y;
     }
   }
-  // the prefetch registers stay allocated to the end of the gate: were the store-out data of a later iteration to reuse
+  // the prefetch registers stay allocated to the end of the gate: were the store-out data of a later half to reuse
   // them, the next prefetch (which overwrites them right after this gate) would have to wait for those stores to drain
 #pragma unroll
   for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(pf[i]));
@@ -1316,7 +1354,7 @@ apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const Blocke
   V pf[8];
   auto prefetch = [&](uint64_t b) {  // unconditional (see apply_blocked_kernel); b = tile_base(tile), wave-uniform
     HQ_PIN_SGPR(b);
-    const uint64_t gl = gt[kBlockedGTabLane + lane];
+    const uint64_t gl = blocked_gtab_lane(gt);
 #pragma unroll
     for (unsigned i = 0; i < 8; ++i) {
       const uint64_t o = gl ^ gt[kBlockedGTabWave + wave * 8 + i];
@@ -1341,16 +1379,24 @@ apply_blocked_direct_kernel(T* __restrict__ re, T* __restrict__ im, const Blocke
     // a wait in front of the NEXT prefetch, for the old contents of its registers, would do the same).  A real S_WAITCNT
     // (not inline assembly), so that the compiler's wait-count insertion sees the queue empty.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt, lgkmcnt untouched
+#define HQ_GATE0(KB, VM) blocked_gate0_direct<T, KB, VM, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim)
     switch (G0.kv) {
-      case 16: blocked_gate0_direct<T, 0, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim); break;
-      case 17: blocked_gate0_direct<T, 1, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim); break;
+      case 16: HQ_GATE0(4, 0); break;
+      case 17: HQ_GATE0(4, 1); break;
+      case 20: HQ_GATE0(5, 0); break;
+      case 21: HQ_GATE0(5, 1); break;
       default:
         if constexpr (CB == 2) {
-          if (G0.kv == 18) blocked_gate0_direct<T, 2, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim);
-          else blocked_gate0_direct<T, 3, BLOCK>(A0, tabs, gt, pf, have_prev, base_prev, vre, vim);
+          switch (G0.kv) {
+            case 18: HQ_GATE0(4, 2); break;
+            case 19: HQ_GATE0(4, 3); break;
+            case 22: HQ_GATE0(5, 2); break;
+            default: HQ_GATE0(5, 3); break;
+          }
         }
         break;
     }
+#undef HQ_GATE0
     const uint64_t nb = next_base(base);
     prefetch(tile + stride < ntiles ? nb : base);  // past the end: a repeat of this tile, never used
     if (!(G0.wave_bits & kBlockedNoBarrier)) __syncthreads();

@@ -28,7 +28,7 @@ def rand_u(k, ct, rng):
     return ((rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) / np.sqrt(2.0 * d)).astype(ct)
 
 
-CASES = [(3, 3, 2, 4, 3), (4, 2, 3, 3), (1, 3, 3), (3, 3), (3, 3, 2)]
+CASES = [(3, 3, 2, 4, 3), (4, 2, 3, 3), (1, 3, 3), (3, 3), (3, 3, 2), (4, 2), (4, 3), (4, 2, 2)]  # 5-7: a k = 4 FIRST gate (round 5)
 for ft in (np.float32, np.float64):
     ct = np.complex64 if ft == np.float32 else np.complex128
     tb = (13 if ft == np.float32 else 12) + (os.environ.get('HQ_TEST_BIG_TILES', os.environ.get('HQ_BLOCKED_BIG')) == '1')  # 128 KiB tiles
@@ -43,6 +43,10 @@ for ft in (np.float32, np.float64):
         if case == 4:  # both vector-component bits among the targets: the most wave-iterations a gate can have (128 on 128 KiB tiles)
             gates[1] = (gates[1][0], np.array([0, int(tile[-2]), 1], dtype=np.uint32))
             gates[2] = (gates[2][0], np.array([1, 0], dtype=np.uint32))
+        if case == 6:  # k = 4 first gate with one target among the vector-component bits
+            gates[0] = (gates[0][0], np.array([int(tile[-1]), 0, int(tile[7]), int(tile[9])], dtype=np.uint32))
+        if case == 7:  # ... and with as many as the precision has (complex64: both, complex128: the one)
+            gates[0] = (gates[0][0], np.array([0, int(tile[8]), 1 if ft == np.float32 else int(tile[6]), int(tile[-2])], dtype=np.uint32))
         psi = (rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)).astype(ct)
         re[:], im[:] = psi.real, psi.imag
         core.apply_blocked(re, im, tile, gates, n)
