@@ -1,7 +1,9 @@
-"""Round-4 device code that no earlier GPU test reaches: apply_blocked_direct_kernel (HQ_BLOCKED_DIRECT=1, the tile
-movement folded into the first gate of a cache-blocked pass) and the 1024-thread kernels for 128 KiB tiles
-(HQ_BLOCKED_BIG=1).  The staged 512-thread kernel is the default until they have been timed against each other
-(tools/ab_round4.sh, bench.py's blocked_variants); these tests make sure the opt-in paths are RIGHT on the device."""
+"""Device code of rounds 4-5 that no earlier GPU test reaches, in every switch setting, against the ORACLE: the staged
+cache-blocked kernel with / without pipelined inner gates and barrier-free wave groups (HQ_BLOCKED_PIPE, HQ_BLOCKED_GROUPS),
+apply_blocked_direct_kernel (HQ_BLOCKED_DIRECT=1, the tile movement folded into the first gate of a pass -- k <= 4 first
+gates) and the 1024-thread kernels for 128 KiB tiles (HQ_BLOCKED_BIG=1).  Every worker also reports the library's own
+bit-for-bit cross-check of these variants against the round-2 kernels (hq_blocked_selfcheck): it must have run and found
+nothing.  Timings: tools/r5_first.sh, bench.py's blocked_variants."""
 import json
 import os
 import subprocess
