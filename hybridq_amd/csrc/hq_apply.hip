@@ -2,6 +2,8 @@
 // k dispatch and kernel selection) and hq_apply_blocked_* (many gates per HBM pass).
 #include "hq_common.h"
 #include "hq_kernels_apply.h"
+#include "hq_kernels_blocked.h"
+#include "hq_kernels_gemm.h"
 
 namespace hq {
 
