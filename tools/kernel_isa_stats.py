@@ -9,7 +9,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else r'apply_blocked_kernel<float, 512, true, (true|false)>')
+pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else r'apply_blocked_kernel<float, 512, true, true, (true|false)>')
 with tempfile.TemporaryDirectory() as td:
     asm = os.path.join(td, 'hq_apply.s')
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',

@@ -1,4 +1,4 @@
-"""Helpers of the placement experiments (tools/pmc_placement.py, tools/rccl_vmm_probe.py, tools/placement_remap.py): an
+"""Helpers of the placement experiments (tools/pmc_placement.py, tools/placement_remap.py): an
 explicitly laid-out VMM buffer seen by torch, and the gate-application probe.  The PRODUCT's search lives behind the C
 ABI (hq_alloc_state); these are for experiments that need control over the layout."""
 import numpy as np
