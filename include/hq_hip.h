@@ -22,8 +22,12 @@
  * HQ_PROGRAM_GRAPH (0: replay programs as a launch loop instead of a hipGraph);
  * measurement switches: HQ_GEMM_TB (tile bits of the k >= 7 kernel),
  * HQ_BLOCKED_THREADS (256|512), HQ_BLOCKED_ALDS (0: operand and address tables of
- * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_GROUPS
- * (0: a workgroup barrier after every inner gate), HQ_BLOCKED_DIRECT (1: tile
+ * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_PIPE /
+ * HQ_GEMM_PIPE (0: the inner-gate / K loops of rounds 1-4a: operands requested where
+ * the compiler puts them instead of ahead of the matrix cores), HQ_BLOCKED_GROUPS
+ * (0: a workgroup barrier after every inner gate), HQ_BLOCKED_SELFCHECK (how many of
+ * the first blocked passes of a process are cross-checked against the round-2
+ * kernels, default 3; hq_blocked_selfcheck), HQ_BLOCKED_DIRECT (1: tile
  * movement of a blocked pass folded into its first gate), HQ_BLOCKED_BIG (1: 128 KiB
  * tiles run on one 1024-thread workgroup per CU), HQ_BLOCKED_GRID (cap,
  * a power of two, on the resident workgroups of a blocked pass), HQ_BLOCKED_PREF,
