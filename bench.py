@@ -717,6 +717,9 @@ def main():
                                      host_planning_seconds_untimed=t_plan,
                                      state_placement='plain (torch allocator)' if bstate is not state else 'tuned (shared with the per-gate run)')
             result['blocked']['inner_k_histogram'] = {str(k): v for k, v in st['inner_k_histogram'].items()}
+            # the library's own cross-check of the kernel variants of rounds 4-5 against the round-2 kernels on this device
+            # (bit for bit, the first passes of the process: hq_blocked_selfcheck) -- failures must be 0
+            result['blocked']['selfcheck'] = core.blocked_selfcheck()
             # the same blocked schedule WITHOUT any algebraic fusion: each of the original gates is
             # applied on its own inside the LDS tiles (what "no fusion" looks like when gates share passes)
             uops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, inner_max=0, complex_type=args.dtype)

@@ -63,7 +63,8 @@ def test_bench_line_end_to_end_against_the_emulated_library():
         assert line[leg]['roofline']['kernel'] and line[leg]['gate_apps_per_s'] > 0 and line[leg]['parity_small_n']['pass'] is True
     bv = line['blocked_variants']  # the opt-in kernel switches of round 4, one subprocess each
     assert set(bv) == {'default', 'groups_off', 'pipe_off', 'round2_kernels', 'direct', 'big_tiles', 'big_tiles_direct', 'low_bits_minus_1'} and not [k for k, v in bv.items() if 'error' in v], bv
-    assert all(len(v['ms_per_step']) == 3 and v['passes'] >= 1 for v in bv.values()), bv  # (which kernels a 14-qubit circuit takes says nothing)
+    assert all(len(v['ms_per_step']) == 3 and v['passes'] >= 1 and v['selfcheck']['failures'] == 0 for v in bv.values()), bv
+    assert line['blocked']['selfcheck']['failures'] == 0 and line['blocked']['selfcheck']['runs'] >= 1  # (which kernels a 14-qubit circuit takes says nothing)
     pc = line['parity_check']
     assert pc['pass'] is True and pc['literal_bar_depth'] == pc['literal_bar_depth_of'] and len(pc['prefixes']) >= 8
     assert 'l2_rel_diff_per_gate' in pc and 'reference_vs_f64_leaves_bar_after' in pc

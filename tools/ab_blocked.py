@@ -49,7 +49,8 @@ for kw in ((dict(),) if as_json else (dict(), dict(inner_max=0))):
                 n_direct += core.last_kernel_desc().endswith('direct')
         torch.cuda.synchronize()
         print(json.dumps({'tile_bits': tb, 'low_bits': int(os.environ.get('HQ_AB_LOW_BITS', 5 if ctype == 'complex64' else 4)), 'passes': st['blocked_passes'], 'plain_gates': st['plain_gates'], 'inner_gates': st['inner_gates'],
-                          'direct_passes': n_direct, 'kernel': core.last_kernel_desc().split(' tb=')[0], 'ms_per_step': [round(t, 3) for t in ts]}), flush=True)
+                          'direct_passes': n_direct, 'kernel': core.last_kernel_desc().split(' tb=')[0], 'ms_per_step': [round(t, 3) for t in ts],
+                          'selfcheck': core.blocked_selfcheck()}), flush=True)
         continue
     print(os.path.basename(os.environ.get('HQ_HIP_LIBRARY', 'in-tree')), f'tb={tb}', core.last_kernel_desc().split('>')[0].split('<')[-1], kw, f"passes {st['blocked_passes']} + {st['plain_gates']} plain, inner {st['inner_gates']}:",
           ' '.join('%.1f' % t for t in ts), 'ms', flush=True)
