@@ -784,7 +784,7 @@ struct BlockedSwitches {
                   // matrix-core form with identity dummies: measured, k = 1 wins (4x fewer flops), k = 2 does not
   int grid_cap;   // HQ_BLOCKED_GRID (a power of two) caps the resident workgroups: small states then walk several tiles per
                   // workgroup, which is how the tile loop of the prefetching kernels is exercised without a 2^22-amplitude state
-  int threads, alds, pref;
+  int alds, pref;
   int big;        // tiles of 2^14 (f32) / 2^13 (f64) amplitudes = 128 KiB, ONE workgroup of 1024 threads per CU (16 waves:
                   // the same four per SIMD as two 512-thread workgroups); opt-in until measured
   int direct;     // tile movement folded into the first gate (apply_blocked_direct_kernel); opt-in until measured
@@ -793,7 +793,7 @@ struct BlockedSwitches {
   int selfcheck;  // how many of the first passes of the process are cross-checked (0: none)
 };
 static BlockedSwitches& blocked_switches() {
-  static BlockedSwitches s = {env_int("HQ_BLOCKED_VALU", 1),   env_int("HQ_BLOCKED_GRID", 0), env_int("HQ_BLOCKED_THREADS", 512),
+  static BlockedSwitches s = {env_int("HQ_BLOCKED_VALU", 1),   env_int("HQ_BLOCKED_GRID", 0),
                               env_int("HQ_BLOCKED_ALDS", 1),   env_int("HQ_BLOCKED_PREF", 1), env_int("HQ_BLOCKED_BIG", 0),
                               env_int("HQ_BLOCKED_DIRECT", 0), env_int("HQ_BLOCKED_GROUPS", 1), env_int("HQ_BLOCKED_PIPE", 1),
                               env_int("HQ_BLOCKED_SELFCHECK", 3)};
@@ -825,8 +825,7 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
   const size_t per_cu = std::min<size_t>(std::max<size_t>(1, (160 * 1024) / tile_bytes), 4);
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[] = {(const void*)apply_blocked_kernel<float, 256, false, false, false>, (const void*)apply_blocked_kernel<float, 512, false, false, false>,
-                         (const void*)apply_blocked_kernel<double, 256, false, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false, false>,
+    const void* fns[] = {(const void*)apply_blocked_kernel<float, 512, false, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false, false>,
                          (const void*)apply_blocked_kernel<float, 512, true, false, true>, (const void*)apply_blocked_kernel<double, 512, true, false, true>,
                          (const void*)apply_blocked_kernel<float, 512, true, false, false>, (const void*)apply_blocked_kernel<double, 512, true, false, false>,
                          (const void*)apply_blocked_kernel<float, 512, true, true, true>, (const void*)apply_blocked_kernel<double, 512, true, true, true>,
@@ -840,12 +839,12 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
   }
   unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
   if (sw.grid_cap > 0 && (sw.grid_cap & (sw.grid_cap - 1)) == 0) grid = std::min<unsigned>(grid, (unsigned)sw.grid_cap);
-  const int block_threads = sw.threads, a_in_lds = sw.alds;
+  const int a_in_lds = sw.alds;
   // LDS left per workgroup behind the tile when `per_cu` workgroups share a CU
   const size_t a_budget = (160 * 1024) / per_cu - tile_bytes > 2048 ? (160 * 1024) / per_cu - tile_bytes - 1024 : 0;
   auto table_bytes = [&](unsigned words) { return (((size_t)n_gates * words * sizeof(BlockedTabT)) + 15) & ~(size_t)15; };
   // all or nothing: the 1024-thread kernel exists only with the tables in LDS, the register prefetch and the pipelined gates
-  const bool big = sw.big && sw.pref && sw.pipe && block_threads != 256 && a_in_lds && tb == (sizeof(T) == 4 ? 14u : 13u) &&
+  const bool big = sw.big && sw.pref && sw.pipe && a_in_lds && tb == (sizeof(T) == 4 ? 14u : 13u) &&
                    Atab.size() * sizeof(T) + table_bytes(BlockedTab<1024>::kWords) <= a_budget;
   const unsigned wave_bits_n = big ? 4u : 3u;
   const size_t tab_bytes = table_bytes(big ? BlockedTab<1024>::kWords : BlockedTab<512>::kWords);  // per-gate address tables (built in-kernel)
@@ -857,10 +856,10 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
     if (G.kv < 64 && ((1u << (tb - CB - G.n_addr)) >> 4) > (big ? BlockedTab<1024>::kNIter : BlockedTab<512>::kNIter)) iter_ok = false;
   // operand tables in LDS only when ALL of them fit behind the tile without costing a resident
   // workgroup (measured: -3 % per pass; splitting a pass to make them fit costs a whole HBM pass)
-  const bool fits = a_in_lds && iter_ok && block_threads != 256 && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
+  const bool fits = a_in_lds && iter_ok && Atab.size() * sizeof(T) + tab_bytes <= a_budget;
   // register prefetch of the next tile (512 threads, 4 vectors per thread and plane = 13 (f32) / 12 (f64) tile bits;
   // f64 only with the table-driven gates: the computed-address variant has no registers left for it)
-  const bool pref = sw.pref && block_threads != 256 && ((tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits)) || big);
+  const bool pref = sw.pref && ((tb == (sizeof(T) == 4 ? 13u : 12u) && (sizeof(T) == 4 || fits)) || big);
   // Tile movement folded into the first gate (apply_blocked_direct_kernel): the pass needs a
   // matrix-core gate (k <= 4) whose register digits lie above tile-local vector bit 2 -- every wave-level HBM
   // access of the gate's own addressing is then a set of whole 128-byte lines -- that may run first: the earliest such gate
@@ -951,9 +950,7 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
     }
   } else {
     const size_t lds = tile_bytes;
-    if (block_threads == 256) {
-      HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 256, false, false, false>), 256, lds, 0u);
-    } else if (pref && sizeof(T) == 4) {
+    if (pref && sizeof(T) == 4) {
       if constexpr (sizeof(T) == 4) HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 512, false, true, false>), 512, lds, 0u);
     } else {
       HQ_BLOCKED_LAUNCH((apply_blocked_kernel<T, 512, false, false, false>), 512, lds, 0u);
@@ -964,7 +961,7 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
   if (describe) {
     c.last_kernel = "blocked";
     c.last_desc = std::string("apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", " +
-                  std::to_string(block_threads == 256 ? 256 : (big ? 1024 : 512)) + "> pipe=" + (fits && sw.pipe ? "1" : "0") + " tb=" + std::to_string(tb) +
+                  std::to_string(big ? 1024 : 512) + "> pipe=" + (fits && sw.pipe ? "1" : "0") + " tb=" + std::to_string(tb) +
                   " gates=" + std::to_string(n_gates) + " barriers=" + std::to_string(n_barriers) + (direct ? " direct" : "");
   }
   return 0;
@@ -1132,7 +1129,7 @@ static int apply_blocked_entry(T* re, T* im, unsigned n, const unsigned* tile_po
     Up += (size_t)2 << (2 * k);
     pp += k;
   }
-  if (sw.selfcheck > 0 && !c.rec && (sw.pipe || sw.groups || sw.direct || sw.big) && sw.alds && sw.threads != 256) {
+  if (sw.selfcheck > 0 && !c.rec && (sw.pipe || sw.groups || sw.direct || sw.big) && sw.alds) {
     --sw.selfcheck;
     if (blocked_selfcheck<T>(c, P, n, sw)) return 1;
   }

@@ -76,7 +76,7 @@ __device__ __forceinline__ void blocked_inner_gate(T* __restrict__ xr, T* __rest
     }
     return v;
   };
-  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);  // log2(waves per workgroup)
+  constexpr unsigned WB = BLOCK == 512 ? 3 : 4;  // log2(waves per workgroup)
   static_assert(BLOCK == 64u << WB, "workgroup size");
   const unsigned lane_off = ((q & 1) ? ro.q_off[0] : 0u) | ((q & 2) ? ro.q_off[1] : 0u);
   const unsigned lane_plane = ro.q_plane >= 0 ? ((q >> ro.q_plane) & 1u) : 0u;
@@ -219,7 +219,7 @@ __device__ __forceinline__ void blocked_inner_gate_tab(const T* __restrict__ A,
   constexpr int NS = KBITS - 2, KV = popc_c(VMASK), NR = NS - KV, NL = 1 << NR;
   constexpr int NRB = 1 << (NS - 2), NCB = 1 << (CB - KV), NSTEP = 1 << NS;
   constexpr int FMASK = ~VMASK & (NCOMP - 1);
-  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
+  constexpr unsigned WB = BLOCK == 512 ? 3 : 4;
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   T a[NRB][NSTEP];
@@ -497,7 +497,7 @@ template <int BLOCK, typename PRE>
 __device__ __forceinline__ PRE blocked_pre(const BlockedTabT* __restrict__ tabs, const unsigned gi) {
   if constexpr (__is_same(PRE, BlockedNoPre)) return BlockedNoPre{};
   else {
-  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
+  constexpr unsigned WB = BLOCK == 512 ? 3 : 4;
   const BlockedTabT* __restrict__ tab = tabs + gi * BlockedTab<BLOCK>::kWords;
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -751,7 +751,7 @@ template <typename T, int BLOCK>
 __device__ __forceinline__ void blocked_build_direct_tables(uint64_t* __restrict__ gt, const BlockedGate& G,
                                                             const BlockedArg& ba, const unsigned tile_vec_bits) {
   constexpr unsigned CB = Vec<T>::VB;
-  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
+  constexpr unsigned WB = BLOCK == 512 ? 3 : 4;
   const MfmaRoles& ro = G.ro;
   const unsigned digits = blocked_digits(ro), wmask = G.wave_bits & ~kBlockedNoBarrier;
   const unsigned nr = (G.kv >> 2) - 2u - (unsigned)__builtin_popcount(G.kv & 3u);  // register digits of the first gate (KBITS = kv >> 2)
@@ -806,7 +806,7 @@ __device__ __forceinline__ void blocked_gate0_direct(const T* __restrict__ A, co
   constexpr int NLH = NL / NRB, NH = NITL * NRB;  // result vectors per half, halves per wave
   constexpr int FMASK = ~VMASK & (NCOMP - 1);
   static_assert(NLH * NH == 8 && NLH == (4 >> KV), "eight vectors per lane");
-  constexpr unsigned WB = BLOCK == 512 ? 3 : (BLOCK == 256 ? 2 : 4);
+  constexpr unsigned WB = BLOCK == 512 ? 3 : 4;
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // the operand rows of both row blocks up front (KBITS = 5, f32: 16 registers) -- or one row block at a time, re-read at

@@ -21,7 +21,7 @@
  * HQ_PROGRAM_MB (table buffer of a recorded program, default 64),
  * HQ_PROGRAM_GRAPH (0: replay programs as a launch loop instead of a hipGraph);
  * measurement switches: HQ_GEMM_TB (tile bits of the k >= 7 kernel),
- * HQ_BLOCKED_THREADS (256|512), HQ_BLOCKED_ALDS (0: operand and address tables of
+ * HQ_BLOCKED_ALDS (0: operand and address tables of
  * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_PIPE /
  * HQ_GEMM_PIPE (0: the inner-gate / K loops of rounds 1-4a: operands requested where
  * the compiler puts them instead of ahead of the matrix cores), HQ_BLOCKED_GROUPS

@@ -17,7 +17,7 @@ SETTINGS = [
     {},
     {'HQ_BLOCKED_PREF': '0', 'HQ_GEMM_PREF': '0', 'HQ_SWAP_PREF': '0', 'HQ_PERM_PREF': '1'},
     {'HQ_BLOCKED_ALDS': '0'},
-    {'HQ_BLOCKED_THREADS': '256', 'HQ_BIG_PHASED': '0'},
+    {'HQ_BIG_PHASED': '0', 'HQ_BLOCKED_PIPE': '0', 'HQ_GEMM_PIPE': '0'},  # round 5: the inner-gate / K loops of rounds 1-4a
     {'HQ_BIG_PHASED': '1', 'HQ_PERM_TB': '12', 'HQ_PERM_INPLACE_TB': '14'},
     {'HQ_PERM_TILE': '0'},  # round-2 paths: table-driven swap, two tile passes, gather kernels
     {'HQ_BLOCKED_GROUPS': '0'},  # round 4: a workgroup barrier after EVERY inner gate (default: barrier-free wave groups)
