@@ -12,7 +12,6 @@ struct BitPermPlan {
   BitPermArg a;
   bool vread = false;   // the vector-component bits stay: 16-byte LDS reads
   unsigned block = 256, nv = 4;
-  bool pref = false;
   int split = 0;        // 1..3: one moved bit more than the 128 KiB tile holds (bitperm_tile_kernel SPLIT mode)
   size_t lds = 0;
 };
@@ -165,29 +164,26 @@ static bool plan_bitperm(const unsigned* perm, unsigned m, bool inplace, BitPerm
   P.vread = true;
   for (unsigned b = 0; b < VB; ++b) P.vread = P.vread && perm[b] == b;
   const unsigned nvec = (1u << tb) >> VB;
-  // register prefetch of the next tile: measured slower on 64 KiB tiles (4.19 vs 4.89 TB/s) and on 128 KiB tiles (5.13 vs
-  // 5.32): off unless HQ_PERM_PREF=1
-  static const int use_pref = env_int("HQ_PERM_PREF", 0);
+  // (a register prefetch of the next tile, the recipe of apply_blocked_kernel, measured SLOWER here -- 4.19 vs 4.89 TB/s on
+  // 64 KiB tiles, 5.13 vs 5.32 on 128 KiB tiles, round 3 -- and left the library in round 5)
   if (nvec <= 8 * 256) {
     P.block = 256;
     P.nv = nvec / 256;
-    P.pref = false;
-  } else {  // 64 / 128 KiB tiles: two / one 1024-thread workgroups per CU, next tile prefetched into registers
+  } else {  // 64 / 128 KiB tiles: two / one 1024-thread workgroups per CU
     P.block = 1024;
     P.nv = nvec / 1024;
-    P.pref = use_pref != 0;
   }
   if (P.nv < 1 || P.nv > 8 || (P.nv & (P.nv - 1))) return false;
   P.lds = (size_t)sizeof(E) << tb;
   return true;
 }
 
-template <typename E, int BLOCK, int NV, bool VREAD, bool PREF, int SPLIT = 0>
+template <typename E, int BLOCK, int NV, bool VREAD, int SPLIT = 0>
 static int launch_bitperm_inst(Context& c, hipStream_t s, bool on_lib_stream, const E* s0, const E* s1, const BitPermPlan& P,
                                uint64_t ntiles) {
   static bool attr_done = false;  // per instantiation, under the context mutex
   if (!attr_done) {
-    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF, SPLIT>,
+    HQ_HIP_CHECK(hipFuncSetAttribute((const void*)bitperm_tile_kernel<E, BLOCK, NV, VREAD, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
     attr_done = true;
   }
@@ -198,9 +194,9 @@ static int launch_bitperm_inst(Context& c, hipStream_t s, bool on_lib_stream, co
   const unsigned grid = (unsigned)std::min<uint64_t>(total, 256 * per_cu * (BLOCK == 256 ? (uint64_t)grid_mult : 1));
   const BitPermArg a = P.a;
   if (on_lib_stream) {
-    HQ_LAUNCH(c, (bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF, SPLIT>), dim3(grid), dim3(BLOCK), P.lds, s0, s1, a, ntiles);
+    HQ_LAUNCH(c, (bitperm_tile_kernel<E, BLOCK, NV, VREAD, SPLIT>), dim3(grid), dim3(BLOCK), P.lds, s0, s1, a, ntiles);
   } else {
-    hipLaunchKernelGGL((bitperm_tile_kernel<E, BLOCK, NV, VREAD, PREF, SPLIT>), dim3(grid), dim3(BLOCK), P.lds, s, s0, s1, a, ntiles);
+    hipLaunchKernelGGL((bitperm_tile_kernel<E, BLOCK, NV, VREAD, SPLIT>), dim3(grid), dim3(BLOCK), P.lds, s, s0, s1, a, ntiles);
   }
   HQ_HIP_CHECK(hipGetLastError());
   return 0;
@@ -212,25 +208,22 @@ static int launch_bitperm(Context& c, hipStream_t s, bool on_lib_stream, const E
   const uint64_t ntiles = 1ull << (P.a.m - P.a.nb);
   if (P.split) {
     if (P.block != 1024 || P.nv != 8 || P.a.planes != 1) return fail("bitperm: bad split plan");
-#define HQ_BPS(V, S) return launch_bitperm_inst<E, 1024, 8, V, false, S>(c, s, on_lib_stream, s0, s1, P, ntiles)
+#define HQ_BPS(V, S) return launch_bitperm_inst<E, 1024, 8, V, S>(c, s, on_lib_stream, s0, s1, P, ntiles)
     if (P.vread) { switch (P.split) { case 1: HQ_BPS(true, 1); case 2: HQ_BPS(true, 2); case 3: HQ_BPS(true, 3); } }
     else { switch (P.split) { case 1: HQ_BPS(false, 1); case 2: HQ_BPS(false, 2); case 3: HQ_BPS(false, 3); } }
 #undef HQ_BPS
     return fail("bitperm: bad split plan");
   }
-#define HQ_BP(B, N, V, PF) return launch_bitperm_inst<E, B, N, V, PF>(c, s, on_lib_stream, s0, s1, P, ntiles)
+#define HQ_BP(B, N, V) return launch_bitperm_inst<E, B, N, V>(c, s, on_lib_stream, s0, s1, P, ntiles)
   if (P.block == 256) {
     if (P.vread) {
-      switch (P.nv) { case 1: HQ_BP(256, 1, true, false); case 2: HQ_BP(256, 2, true, false); case 4: HQ_BP(256, 4, true, false); case 8: HQ_BP(256, 8, true, false); }
+      switch (P.nv) { case 1: HQ_BP(256, 1, true); case 2: HQ_BP(256, 2, true); case 4: HQ_BP(256, 4, true); case 8: HQ_BP(256, 8, true); }
     } else {
-      switch (P.nv) { case 1: HQ_BP(256, 1, false, false); case 2: HQ_BP(256, 2, false, false); case 4: HQ_BP(256, 4, false, false); case 8: HQ_BP(256, 8, false, false); }
+      switch (P.nv) { case 1: HQ_BP(256, 1, false); case 2: HQ_BP(256, 2, false); case 4: HQ_BP(256, 4, false); case 8: HQ_BP(256, 8, false); }
     }
-  } else if (P.pref) {
-    if (P.vread) { switch (P.nv) { case 4: HQ_BP(1024, 4, true, true); case 8: HQ_BP(1024, 8, true, true); } }
-    else { switch (P.nv) { case 4: HQ_BP(1024, 4, false, true); case 8: HQ_BP(1024, 8, false, true); } }
   } else {
-    if (P.vread) { switch (P.nv) { case 4: HQ_BP(1024, 4, true, false); case 8: HQ_BP(1024, 8, true, false); } }
-    else { switch (P.nv) { case 4: HQ_BP(1024, 4, false, false); case 8: HQ_BP(1024, 8, false, false); } }
+    if (P.vread) { switch (P.nv) { case 4: HQ_BP(1024, 4, true); case 8: HQ_BP(1024, 8, true); } }
+    else { switch (P.nv) { case 4: HQ_BP(1024, 4, false); case 8: HQ_BP(1024, 8, false); } }
   }
 #undef HQ_BP
   return fail("bitperm: unsupported tile shape");

@@ -317,7 +317,7 @@ struct BitPermArg {
 // write D0 = Q(0,0) u Q(0,1);  LDS <- S1 = Q(0,1) (from the registers) u Q(1,1) (from memory, still untouched);
 // write D1 = Q(1,0) u Q(1,1): every element is read once before its address is overwritten, one HBM pass.  On the source
 // side b is iteration bit SPLIT-1 of a thread's eight vectors, so the register-held quarter is a static half of them.
-template <typename E, int BLOCK, int NV, bool VREAD, bool PREF, int SPLIT = 0>
+template <typename E, int BLOCK, int NV, bool VREAD, int SPLIT = 0>
 __global__ void __launch_bounds__(BLOCK)
 bitperm_tile_kernel(const E* __restrict__ src0, const E* __restrict__ src1, const BitPermArg a, const uint64_t ntiles) {
   constexpr int VEC = 16 / (int)sizeof(E);
@@ -416,7 +416,7 @@ bitperm_tile_kernel(const E* __restrict__ src0, const E* __restrict__ src1, cons
     }
   };
   if constexpr (SPLIT > 0) {
-    static_assert(NV == 8 && !PREF, "split mode: eight vectors per thread");
+    static_assert(NV == 8, "split mode: eight vectors per thread");
     constexpr int UB = SPLIT - 1;  // iteration bit that is address bit b on the source side
     auto store_half = [&](uint64_t xb) {
       constexpr int CH = VREAD ? 4 : 2;  // element gathers: two vectors at a time keep the kernel inside 128 registers
@@ -465,22 +465,6 @@ bitperm_tile_kernel(const E* __restrict__ src0, const E* __restrict__ src1, cons
       fill(v);
       __syncthreads();
       store_half(xb | a.half_x);
-    }
-  } else if constexpr (PREF) {
-    // one or two workgroups per CU: the next tile is requested into registers while this one is permuted and stored
-    // (unconditional prefetch on a clamped tile number, LDS fill after the stores: the recipe of apply_blocked_kernel)
-    if (blockIdx.x >= total) return;
-    const uint64_t stride = gridDim.x;
-    PackV pr[NV];
-    load_tile(blockIdx.x, pr);
-    fill(pr);
-    load_tile(blockIdx.x + stride < total ? blockIdx.x + stride : blockIdx.x, pr);
-    for (uint64_t ht = blockIdx.x; ht < total; ht += stride) {
-      __syncthreads();
-      permute_store(ht);
-      __syncthreads();
-      fill(pr);
-      load_tile(ht + 2 * stride < total ? ht + 2 * stride : ht, pr);
     }
   } else {
     for (uint64_t ht = blockIdx.x; ht < total; ht += gridDim.x) {

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SETTINGS = [
     {},
-    {'HQ_BLOCKED_PREF': '0', 'HQ_GEMM_PREF': '0', 'HQ_SWAP_PREF': '0', 'HQ_PERM_PREF': '1'},
+    {'HQ_BLOCKED_PREF': '0', 'HQ_GEMM_PREF': '0', 'HQ_SWAP_PREF': '0'},
     {'HQ_BLOCKED_ALDS': '0'},
     {'HQ_BIG_PHASED': '0', 'HQ_BLOCKED_PIPE': '0', 'HQ_GEMM_PIPE': '0'},  # round 5: the inner-gate / K loops of rounds 1-4a
     {'HQ_BIG_PHASED': '1', 'HQ_PERM_TB': '12', 'HQ_PERM_INPLACE_TB': '14'},
