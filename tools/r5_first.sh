@@ -12,6 +12,12 @@ ab() { echo "-- $*"; env "$@" timeout 300 python tools/ab_blocked.py 30 complex6
 rocm-smi --showproductname 2>/dev/null | head -8
 run python -m pytest -q -m gpu -x tests/test_gpu_parity.py tests/test_gpu_golden.py | tee "$out/oracle_first.txt"
 run python -m pytest -q -m gpu -s tests/test_gpu_round4.py tests/test_gpu_determinism.py | tee "$out/round4_determinism.txt"
+# the bench line (it carries the A/B of every variant in `blocked_variants` and the self-check status) and the rocprofv3 kernel
+# statistics of the same command, before anything longer: a lease that ends early still leaves the record
+run python bench.py | tee "$out/bench.txt"
+(cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/prof" -- python "$OLDPWD/bench.py" --no-variants > "$OLDPWD/$out/bench_under_rocprof.txt" 2>&1)
+db=$(find "$out/prof" -name "*.db" | head -1); [ -n "$db" ] && python profiles/extract_stats.py "$db" "$out/kernel_stats.csv" && head -30 "$out/kernel_stats.csv"
+run python __graft_entry__.py smoke | tee "$out/smoke.txt"
 for rep in 1 2; do
   echo "== rep $rep"
   { ab HQ_BLOCKED_PIPE=1 HQ_BLOCKED_GROUPS=1
@@ -26,5 +32,4 @@ done
 echo "== tile GEMM k = 7..10, operands ahead of the MFMAs (default) / the old K loop"
 timeout 600 python tools/sweep_gemm.py 2>&1 | tail -14 | tee "$out/gemm_pipe1.txt"
 HQ_GEMM_PIPE=0 timeout 600 python tools/sweep_gemm.py 2>&1 | tail -14 | tee "$out/gemm_pipe0.txt"
-run python __graft_entry__.py smoke | tee "$out/smoke.txt"
 run python -m pytest -q -m gpu -x tests/test_gpu_round2.py tests/test_gpu_round3.py tests/test_gpu_depth_parity.py | tee "$out/round23_depth.txt"

@@ -9,4 +9,4 @@ run() { echo "== $*"; timeout 2400 "$@" 2>&1 | tail -40; echo "rc=${PIPESTATUS[0
 run python -m pytest tests -q -x -m gpu | tee "$out/gpu_suite.txt"
 run python bench.py | tee "$out/bench.txt"
 (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/prof" -- python "$OLDPWD/bench.py" --no-variants > "$OLDPWD/$out/bench_under_rocprof.txt" 2>&1)
-python profiles/extract_stats.py "$out/prof" 2>/dev/null | head -40 | tee "$out/kernel_stats_head.txt"
+db=$(find "$out/prof" -name "*.db" | head -1); [ -n "$db" ] && python profiles/extract_stats.py "$db" "$out/kernel_stats.csv" && head -30 "$out/kernel_stats.csv"
