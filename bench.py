@@ -10,12 +10,22 @@ One "step" = one pass of that circuit over the resident state vector.  The state
 already in HBM when the timed region starts; matrices (<= 128 B each) cross the C ABI
 as host pointers exactly like in the reference (simulation.py:637-644).
 
-Prints ONE JSON line (rank 0):  value = amplitude updates per second of the whole job
-(= gate-applications/s x 2^n), plus gate_apps_per_s, a `roofline` object for the
+Prints the JSON line of the contract (rank 0):  value = amplitude updates per second of the
+whole job (= gate-applications/s x 2^n), plus gate_apps_per_s, a `roofline` object for the
 dominant kernel measured live with HIP events on the library's stream, and (N=1) a
 `cpu_baseline` object: the reference's own C++ core (oracle/_ref, "reference") or this
 repo's C restatement ("port") timed on the host cores on a bounded sample of the same
 circuit.
+
+Order of work (VERDICT r05 next #1a): timed region -> roofline -> the same kernels on a
+plain-placement state -> cpu_baseline -> THE LINE IS PRINTED AND FLUSHED.  Everything
+else (`extras`: fused / cache-blocked schedules, per-k rates, data-movement primitives,
+config-4 / config-5 legs, the full-depth parity block, the A/B of the opt-in kernel
+variants) runs afterwards inside a wall-clock budget (--extras-seconds, default 300),
+anything that launches kernel code hardware has not yet run does so in a subprocess with
+its own timeout, and the complete line (headline + extras) is printed once more as the
+LAST line.  Both lines carry identical contract fields; a run killed at any moment after
+the timed region has left a parseable line.
 """
 import argparse
 import json
@@ -75,6 +85,8 @@ def parse_args():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-events', action='store_true', help='skip per-gate HIP events in the timed region')
     ap.add_argument('--overlap', action='store_true', help='N > 1: exchanges in rounds with the independent local gates applied to the pieces as they land (hybridq_amd.dist.overlap_exchanges; default off until measured on xGMI)')
+    ap.add_argument('--extras-seconds', type=float, default=300.0, help='wall-clock budget of everything after the first printed line (0: headline only)')
+    ap.add_argument('--plain-gates', type=int, default=30, help='gate applications of the headline circuit timed on a plain-placement (torch allocator) state as well')
     ap.add_argument('--variants-min-qubits', type=int, default=26, help='the blocked_variants leg runs from this size on')
     ap.add_argument('--no-variants', action='store_true', help='skip the blocked_variants leg (the cache-blocked step under the opt-in kernel switches of round 4, one subprocess each)')
     ap.add_argument('--no-config-legs', action='store_true', help='skip the short BASELINE config 4 / config 5 legs after the timed region')
@@ -234,30 +246,40 @@ def parity_check(complex_type, depth, n=24):
     return out
 
 
-def blocked_variants(n, complex_type):
-    """tools/ab_blocked.py (plan + 1 warm-up + 3 timed cache-blocked steps of the depth-40 generator circuit at n qubits) once
-    per switch setting: the default (pipelined inner gates, barrier-free wave groups), one barrier per inner gate, the old
-    inner-gate loops, both (= the kernels of round 2), the tile movement folded into the first gate, 128 KiB tiles on one 1024-thread workgroup, both, and (a planner setting, not a kernel) one forced low
-    tile bit less.  Never raises."""
+def _ab_blocked(n, complex_type, bits, env, mode='json', timeout=240):
+    """One run of tools/ab_blocked.py (plan + 1 warm-up + 3 timed cache-blocked steps of the depth-40 generator circuit at n
+    qubits) in its OWN process under `env`: a wedged wave in kernel code that hardware has not run costs this leg, not the
+    line.  Never raises."""
     import subprocess
+    try:
+        cmd = [sys.executable, os.path.join(ROOT, 'tools', 'ab_blocked.py'), str(n), complex_type, str(bits), mode]
+        r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        return dict(json.loads(line[-1]), env=env) if line else {'error': (r.stderr or r.stdout)[-300:], 'rc': r.returncode}
+    except Exception as e:  # noqa: BLE001
+        return {'error': repr(e)}
+
+
+def blocked_variants(n, complex_type, time_left=lambda: 1e9):
+    """The cache-blocked step under every opt-in kernel switch, one subprocess each: pipelined inner gates, barrier-free wave
+    groups, both, the tile movement folded into the first gate (with / without groups), 128 KiB tiles on one 1024-thread
+    workgroup (staged / direct) and -- a planner setting, not a kernel -- one forced low tile bit less.  The library's default
+    (the kernels of round 2, the ones the driver's GPU tests have seen) is the `blocked` leg.  Never raises."""
     tb = 13 if complex_type == 'complex64' else 12
-    settings = [('default', {}, tb), ('groups_off', {'HQ_BLOCKED_GROUPS': '0'}, tb),
-                # the inner-gate loops of rounds 2-4a (LDS reads where the compiler puts them) / the kernels GPUTEST_r02 saw
-                ('pipe_off', {'HQ_BLOCKED_PIPE': '0'}, tb), ('round2_kernels', {'HQ_BLOCKED_PIPE': '0', 'HQ_BLOCKED_GROUPS': '0'}, tb),
-                ('direct', {'HQ_BLOCKED_DIRECT': '1'}, tb),
-                ('big_tiles', {'HQ_BLOCKED_BIG': '1'}, tb + 1), ('big_tiles_direct', {'HQ_BLOCKED_BIG': '1', 'HQ_BLOCKED_DIRECT': '1'}, tb + 1),
+    settings = [('pipe', {'HQ_BLOCKED_PIPE': '1'}, tb), ('groups', {'HQ_BLOCKED_GROUPS': '1'}, tb),
+                ('pipe_groups', {'HQ_BLOCKED_PIPE': '1', 'HQ_BLOCKED_GROUPS': '1'}, tb),
+                ('direct', {'HQ_BLOCKED_DIRECT': '1'}, tb), ('direct_groups', {'HQ_BLOCKED_DIRECT': '1', 'HQ_BLOCKED_GROUPS': '1'}, tb),
+                ('big_tiles', {'HQ_BLOCKED_BIG': '1', 'HQ_BLOCKED_GROUPS': '1'}, tb + 1),
+                ('big_tiles_direct', {'HQ_BLOCKED_BIG': '1', 'HQ_BLOCKED_DIRECT': '1', 'HQ_BLOCKED_GROUPS': '1'}, tb + 1),
                 # one forced low tile bit less = 64-byte runs per plane instead of whole 128-byte lines: 26 instead of 28 passes
                 ('low_bits_minus_1', {'HQ_AB_LOW_BITS': str(4 if complex_type == 'complex64' else 3)}, tb)]
     out = {}
     for name, env, bits in settings:
-        try:
-            cmd = [sys.executable, os.path.join(ROOT, 'tools', 'ab_blocked.py'), str(n), complex_type, str(bits), 'json']
-            r = subprocess.run(cmd,
-                               env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-            out[name] = dict(json.loads(line[-1]), env=env) if line else {'error': (r.stderr or r.stdout)[-300:]}
-        except Exception as e:  # noqa: BLE001
-            out[name] = {'error': repr(e)}
+        left = time_left()
+        if left < 20:
+            out[name] = {'skipped': 'extras budget spent'}
+            continue
+        out[name] = _ab_blocked(n, complex_type, bits, env, timeout=min(240, left))
     return out
 
 
@@ -495,7 +517,120 @@ def main():
                                              'VMM_MIN_BYTES); HQ_STATE_ALLOC=torch disables it')
     except Exception as e:  # noqa: BLE001
         result['state_placement_error'] = repr(e)
+    if rank == 0 and (events is not None or (sharded_path and op_timer is not None)):
+        per_class = {}
+        if events is not None:
+            for s in range(args.steps):
+                for kname, (e0, e1) in zip(kernel_of, events[s]):
+                    per_class.setdefault(kname, []).append(e0.elapsed_time(e1))
+        else:  # sharded: rank 0's local gate kernels (exchange / permutation passes reported on their own)
+            other = {}
+            for kname, e0, e1 in op_timer.rows:
+                (per_class if kname not in OP_NAMES.values() else other).setdefault(kname, []).append(e0.elapsed_time(e1))
+            result['in_loop_ms'] = {c: {'launches': len(v), 'avg_ms': float(np.mean(v)), 'total_ms_per_step': float(np.sum(v)) / args.steps}
+                                    for c, v in sorted(other.items())}
+        total = {c: float(np.sum(v)) for c, v in per_class.items()}
+        dom = max(total, key=total.get)
+        avg_ms = float(np.mean(per_class[dom]))
+        achieved = bytes_per_gate / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))  # PMC-measured HBM bytes per launch (profiles/r01_pmc_hbm_traffic.csv)
+                if tj.get('n_qubits') == n_local and tj.get('dtype') == args.dtype:
+                    traffic = tj.get(dom)
+            except Exception:
+                traffic = None
+        result['roofline'] = {
+            'bound': 'hbm',
+            'kernel': dom,
+            'achieved': achieved,
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS,
+            'traffic': traffic,
+            'traffic_source': (None if traffic is None else
+                               'stored PMC measurement (profiles/traffic.json <- profiles/r02_pmc_hbm_traffic.csv, r03_pmc_hbm_traffic.csv: '
+                               '2 x FETCH_SIZE + WRITE_SIZE of this kernel at this n, separate rocprofv3 --pmc passes), '
+                               'not a counter of this run'),
+            'algorithmic_bytes_per_launch': bytes_per_gate,
+            'avg_launch_ms': avg_ms,
+            'launches': len(per_class[dom]),
+            'per_kernel_avg_ms': {c: float(np.mean(v)) for c, v in sorted(per_class.items())},
+            'per_kernel_launches': {c: len(v) for c, v in sorted(per_class.items())},
+        }
+    # ---- the same kernels on a PLAIN-placement state (torch's allocator): the tuned placement is a draw-and-probe search
+    # (hq_alloc_state) whose winner differs from box to box; both figures in the driver's line show the spread
+    if rank == 0 and not sharded_path and events is not None and args.plain_gates > 0:
+        try:
+            free_b, _tot = torch.cuda.mem_get_info()
+            if free_b > 1.5 * state.planes.numel() * state.planes.element_size():
+                pstate = EvolutionState(list(range(n)), complex_type=args.dtype, initial_state='0' * n, placement='plain')
+                sample = plan[:args.plain_gates]
+                for U, qs, pos in sample:  # untimed pass
+                    core.apply_U(pstate.planes[0], pstate.planes[1], U, pos, n)
+                torch.cuda.synchronize()
+                pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in sample]
+                for (U, qs, pos), (e0, e1) in zip(sample, pev):
+                    e0.record()
+                    core.apply_U(pstate.planes[0], pstate.planes[1], U, pos, n)
+                    e1.record()
+                torch.cuda.synchronize()
+                per_p = {}
+                for kname, (e0, e1) in zip(kernel_of, pev):
+                    per_p.setdefault(kname, []).append(e0.elapsed_time(e1))
+                dom_p = result['roofline']['kernel'] if result.get('roofline', {}).get('kernel') in per_p else max(per_p, key=lambda c: float(np.sum(per_p[c])))
+                avg_p = float(np.mean(per_p[dom_p]))
+                result['roofline_plain_placement'] = {
+                    'bound': 'hbm', 'kernel': dom_p, 'achieved': bytes_per_gate / (avg_p * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': bytes_per_gate / (avg_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 'avg_launch_ms': avg_p, 'launches': len(per_p[dom_p]),
+                    'gate_applications': len(sample), 'all_kernels_frac': bytes_per_gate / (float(np.mean([t for v in per_p.values() for t in v])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'note': 'the first gate applications of the same circuit on a state from torch.empty (no placement search), HIP events per call'}
+                del pstate
+                torch.cuda.empty_cache()
+            else:
+                result['roofline_plain_placement'] = {'skipped': 'no room for a second state'}
+        except Exception as e:  # noqa: BLE001 -- a reported extra
+            result['roofline_plain_placement'] = {'error': repr(e)}
+    if rank == 0 and not sharded_path and not args.no_cpu_baseline:
+        try:
+            result['cpu_baseline'] = cpu_baseline(gates, n, args.cpu_seconds, args.dtype)
+        except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
+            result['cpu_baseline'] = {'value': None, 'unit': 'amplitudes/s', 'cores': 0, 'kind': 'port',
+                                      'sample': f'failed: {e!r}'}
     if sharded_path:
+        result['exchange_transport'] = {'transport': getattr(sharded.backend, 'transport', None), 'note': getattr(sharded.backend, 'transport_note', '')}
+        try:
+            result['exchange_transport'].update(core.shard_info())  # world / rank / transport as the LIBRARY holds them; rccl_ranks_seen = ncclCommCount of its communicator
+        except Exception as e:  # noqa: BLE001
+            result['exchange_transport']['info_error'] = repr(e)
+
+    # ---- THE LINE: everything the contract names is in `result` now.  Printed and flushed before any extra runs.
+    def emit(final=False):
+        if rank == 0:
+            result['line'] = 'complete' if final else 'headline (the complete line follows as the last line of this run)'
+            print(json.dumps(result), flush=True)
+
+    emit()
+    t_extras = time.perf_counter()
+    skipped = []
+
+    def time_left():
+        return args.extras_seconds - (time.perf_counter() - t_extras)
+
+    def budget(name, need):
+        """True when `need` seconds (a generous estimate of the leg) are left; under N > 1 rank 0 decides for everybody."""
+        ok = time_left() >= need
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device='cuda')
+            dist.broadcast(flag, src=0)
+            ok = bool(flag.item())
+        if not ok:
+            skipped.append(name)
+        return ok
+
+    if sharded_path and budget('exchange', 60):
         # everything in this block is a reported extra: a failure here must never cost the headline line
         try:
             # the exchange on its own (SURVEY 8d/8e): every rank sends (G-1)/G of both planes, one
@@ -600,50 +735,7 @@ def main():
                 'note': 'unmeasured on hardware: no multi-GPU node was available to this build'}
         except Exception as e:  # noqa: BLE001
             result['extras_error'] = repr(e)
-    if rank == 0 and (events is not None or (sharded_path and op_timer is not None)):
-        per_class = {}
-        if events is not None:
-            for s in range(args.steps):
-                for kname, (e0, e1) in zip(kernel_of, events[s]):
-                    per_class.setdefault(kname, []).append(e0.elapsed_time(e1))
-        else:  # sharded: rank 0's local gate kernels (exchange / permutation passes reported on their own)
-            other = {}
-            for kname, e0, e1 in op_timer.rows:
-                (per_class if kname not in OP_NAMES.values() else other).setdefault(kname, []).append(e0.elapsed_time(e1))
-            result['in_loop_ms'] = {c: {'launches': len(v), 'avg_ms': float(np.mean(v)), 'total_ms_per_step': float(np.sum(v)) / args.steps}
-                                    for c, v in sorted(other.items())}
-        total = {c: float(np.sum(v)) for c, v in per_class.items()}
-        dom = max(total, key=total.get)
-        avg_ms = float(np.mean(per_class[dom]))
-        achieved = bytes_per_gate / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))  # PMC-measured HBM bytes per launch (profiles/r01_pmc_hbm_traffic.csv)
-                if tj.get('n_qubits') == n_local and tj.get('dtype') == args.dtype:
-                    traffic = tj.get(dom)
-            except Exception:
-                traffic = None
-        result['roofline'] = {
-            'bound': 'hbm',
-            'kernel': dom,
-            'achieved': achieved,
-            'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS,
-            'traffic': traffic,
-            'traffic_source': (None if traffic is None else
-                               'stored PMC measurement (profiles/traffic.json <- profiles/r02_pmc_hbm_traffic.csv, r03_pmc_hbm_traffic.csv: '
-                               '2 x FETCH_SIZE + WRITE_SIZE of this kernel at this n, separate rocprofv3 --pmc passes), '
-                               'not a counter of this run'),
-            'algorithmic_bytes_per_launch': bytes_per_gate,
-            'avg_launch_ms': avg_ms,
-            'launches': len(per_class[dom]),
-            'per_kernel_avg_ms': {c: float(np.mean(v)) for c, v in sorted(per_class.items())},
-            'per_kernel_launches': {c: len(v) for c, v in sorted(per_class.items())},
-        }
-    if rank == 0 and not sharded_path and not args.no_fused:
+    if rank == 0 and not sharded_path and not args.no_fused and budget('fused', 30):
         try:  # a reported extra: a failure here must never cost the headline line
             # The reference's DEFAULT driver setting fuses the circuit into <= 4-qubit gates first
             # (compress=4, simulation.py:314,436-454; untimed there, :519).  Reported separately:
@@ -678,81 +770,28 @@ def main():
                 }
         except Exception as e:  # noqa: BLE001
             result['fused_error'] = repr(e)
-    if rank == 0 and not sharded_path and not args.no_fused:
-        try:  # a reported extra: a failure here must never cost the headline line
-            # Cache-blocked execution (hybridq_amd/blocking.py): many gates per HBM pass through
-            # LDS tiles.  Same circuit and state; scheduling is host work done before the clock,
-            # like fusion.  "logical" rates count the ORIGINAL gate applications.
-            from hybridq_amd.blocking import blocked_stats, plan_blocked
-            t_p = time.perf_counter()
-            tb = 13 if args.dtype == 'complex64' else 12  # 64 KiB of LDS per tile
-            bops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, complex_type=args.dtype)
-            t_plan = time.perf_counter() - t_p
-            packed = [('B', op[1], core.pack_blocked(op[2], args.dtype)) if op[0] == 'B' else op for op in bops]
-            # the blocked passes gather short runs from all over the state: they run ~7 % faster from torch's
-            # allocator than from the VMM placement tuned for the streaming kernels (simulate() picks the same)
-            bstate = state
-            free_b, _tot = torch.cuda.mem_get_info()
-            if free_b > 2.5 * state.planes.numel() * state.planes.element_size():
-                bstate = EvolutionState(list(range(n)), complex_type=args.dtype, initial_state='0' * n, placement='plain')
-
-            def run_blocked():
-                for op in packed:
-                    if op[0] == 'G':
-                        core.apply_U(bstate.planes[0], bstate.planes[1], op[1], op[2], n)
-                    else:
-                        core.apply_blocked(bstate.planes[0], bstate.planes[1], op[1], packed=op[2], n_qubits=n)
-
-            run_blocked()
-            barrier()
-            t0b = time.perf_counter()
-            for _ in range(args.steps):
-                run_blocked()
-            barrier()
-            elb = (time.perf_counter() - t0b) / args.steps
-            st = blocked_stats(bops)
-            result['blocked'] = dict(st, tile_bits=tb, ms_per_step=1e3 * elb,
-                                     logical_gate_apps_per_s=len(gates) / elb,
-                                     logical_amplitudes_per_s=len(gates) / elb * float(1 << n),
-                                     host_planning_seconds_untimed=t_plan,
-                                     state_placement='plain (torch allocator)' if bstate is not state else 'tuned (shared with the per-gate run)')
-            result['blocked']['inner_k_histogram'] = {str(k): v for k, v in st['inner_k_histogram'].items()}
-            # the library's own cross-check of the kernel variants of rounds 4-5 against the round-2 kernels on this device
-            # (bit for bit, the first passes of the process: hq_blocked_selfcheck) -- failures must be 0
-            result['blocked']['selfcheck'] = core.blocked_selfcheck()
-            # the same blocked schedule WITHOUT any algebraic fusion: each of the original gates is
-            # applied on its own inside the LDS tiles (what "no fusion" looks like when gates share passes)
-            uops = plan_blocked(gates, state.map, n, tile_bits=tb, low_bits=tb - 8, inner_max=0, complex_type=args.dtype)
-            upacked = [('B', op[1], core.pack_blocked(op[2], args.dtype)) if op[0] == 'B' else op for op in uops]
-
-            def run_unfused():
-                for op in upacked:
-                    if op[0] == 'G':
-                        core.apply_U(bstate.planes[0], bstate.planes[1], op[1], op[2], n)
-                    else:
-                        core.apply_blocked(bstate.planes[0], bstate.planes[1], op[1], packed=op[2], n_qubits=n)
-
-            run_unfused()
-            barrier()
-            t0u = time.perf_counter()
-            run_unfused()
-            barrier()
-            elu = time.perf_counter() - t0u
-            stu = blocked_stats(uops)
-            result['blocked_no_fusion'] = {'blocked_passes': stu['blocked_passes'], 'plain_gates': stu['plain_gates'],
-                                           'inner_gates': stu['inner_gates'], 'ms_per_step': 1e3 * elu,
-                                           'gate_apps_per_s': len(gates) / elu,
-                                           'amplitudes_per_s': len(gates) / elu * float(1 << n)}
-            if bstate is not state:
-                del bstate
-                torch.cuda.empty_cache()
-        except Exception as e:  # noqa: BLE001
-            result['blocked_error'] = repr(e)
-    if rank == 0 and not sharded_path and not args.no_fused and not args.no_variants and n >= args.variants_min_qubits:
-        # The cache-blocked step under the kernel switches built without a GPU in round 4 (the library reads them once, so
-        # each runs in its own process, after the timed region): whoever runs this line on hardware gets the A/B with it.
-        result['blocked_variants'] = blocked_variants(n, args.dtype)
-    if rank == 0 and not sharded_path and not args.no_fused:
+    if rank == 0 and not sharded_path and not args.no_fused and budget('blocked', 60):
+        # Cache-blocked execution (hybridq_amd/blocking.py): many gates per HBM pass through LDS tiles.  Same circuit; the
+        # scheduling is host work done before the clock, like fusion; "logical" rates count the ORIGINAL gate applications.
+        # Runs in its OWN process (tools/ab_blocked.py, on a plain-placement state of its own as simulate() picks for blocked
+        # schedules): since round 3 the inner loops of this kernel family have been reworked without hardware, and although
+        # the library's defaults are the loops hardware has run, nothing after the printed line shares a process with the
+        # line's own measurements unless it has to.
+        tb = 13 if args.dtype == 'complex64' else 12  # 64 KiB of LDS per tile
+        leg = _ab_blocked(n, args.dtype, tb, {}, mode='json_full', timeout=max(30, min(300, time_left())))
+        if 'error' in leg:
+            result['blocked_error'] = leg
+        else:
+            ms = float(np.mean(leg['ms_per_step']))
+            result['blocked'] = dict(leg.pop('stats', {}), tile_bits=tb, ms_per_step=ms, ms_per_step_runs=leg['ms_per_step'],
+                                     logical_gate_apps_per_s=len(gates) / (ms * 1e-3), logical_amplitudes_per_s=len(gates) / (ms * 1e-3) * float(1 << n),
+                                     host_planning_seconds_untimed=leg.get('plan_seconds'), state_placement='plain (torch allocator)',
+                                     kernel=leg.get('kernel'), selfcheck=leg.get('selfcheck'), process='subprocess (tools/ab_blocked.py)')
+            if 'no_fusion' in leg:
+                nf = leg['no_fusion']
+                result['blocked_no_fusion'] = dict(nf, gate_apps_per_s=len(gates) / (nf['ms_per_step'] * 1e-3),
+                                                   amplitudes_per_s=len(gates) / (nf['ms_per_step'] * 1e-3) * float(1 << n))
+    if rank == 0 and not sharded_path and not args.no_fused and budget('valu_direct_only', 15):
         try:  # a reported extra: a failure here must never cost the headline line
             # the same 900-gate step through the VALU register-butterfly kernels only (no matrix cores):
             # north_star asks for MFMA only where the tile update is a genuine GEMM (k >= 4); the role
@@ -774,7 +813,7 @@ def main():
                                           'last_kernel': kinds[0]}
         except Exception as e:  # noqa: BLE001
             result['valu_direct_only_error'] = repr(e)
-    if rank == 0 and not sharded_path and not args.no_fused:
+    if rank == 0 and not sharded_path and not args.no_fused and budget('role_kernel_only', 20):
         try:  # a reported extra: the same step through the matrix-core role kernel ONLY (the round-2 default; Auto now sends
             # k <= 3 gates with every target at bit >= 8 to the VALU kernel): same state, same process, back to back
             core.set_apply_mode('mfma')
@@ -797,7 +836,7 @@ def main():
                                           'auto_ms_per_step_back_to_back': 1e3 * ela, 'auto_gate_apps_per_s_back_to_back': len(gates) / ela}
         except Exception as e:  # noqa: BLE001
             result['role_kernel_only_error'] = repr(e)
-    if rank == 0 and not sharded_path and not args.no_fused:
+    if rank == 0 and not sharded_path and not args.no_fused and budget('per_k', 15):
         try:  # a reported extra: a failure here must never cost the headline line
             # one gate of every width on the same resident state (k >= 5 reach the matrix cores through
             # apply_mfma_big_kernel / apply_gemm_kernel): ms per gate, HBM rate and MFMA rate
@@ -822,7 +861,7 @@ def main():
             result['per_k'] = per_k
         except Exception as e:  # noqa: BLE001
             result['per_k_error'] = repr(e)
-    if rank == 0 and not sharded_path and not args.no_fused:
+    if rank == 0 and not sharded_path and not args.no_fused and budget('aux', 15):
         try:  # a reported extra
             # the data-movement primitives of the boundary on the same resident state (north_star names the
             # index-swap primitive): algorithmic bytes = one read + one write of what they touch
@@ -868,7 +907,7 @@ def main():
             result['aux'] = aux
         except Exception as e:  # noqa: BLE001
             result['aux_error'] = repr(e)
-    if rank == 0 and not sharded_path and not args.no_config_legs and args.workload == 'rqc_1q2q' and n % 2 == 0:
+    if rank == 0 and not sharded_path and not args.no_config_legs and args.workload == 'rqc_1q2q' and n % 2 == 0 and budget('config_legs', 40):
         # BASELINE configs 4 and 5 as short legs of the SAME run (after the timed config-2 region, on the same resident
         # state): gate-apps/s, the dominant kernel and its share of the HBM peak, and the generator's parity at a small n
         for key, make in (('cfg4_dense_k34', lambda nn: dense_kq(nn, n_gates=200, seed=34)),
@@ -883,20 +922,14 @@ def main():
                 result[key] = leg
             except Exception as e:  # noqa: BLE001 -- a reported extra
                 result[key + '_error'] = repr(e)
-    if rank == 0 and not sharded_path and not args.no_cpu_baseline:
-        try:
-            result['cpu_baseline'] = cpu_baseline(gates, n, args.cpu_seconds, args.dtype)
-        except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
-            result['cpu_baseline'] = {'value': None, 'unit': 'amplitudes/s', 'cores': 0, 'kind': 'port',
-                                      'sample': f'failed: {e!r}'}
-    if rank == 0 and not sharded_path and not args.no_cpu_baseline:
+    if rank == 0 and not sharded_path and not args.no_cpu_baseline and budget('parity_check', 45):
         # max relative difference of the final amplitudes, GPU vs the reference CPU path,
         # on the same generator at the largest n the CPU finishes in seconds.
         try:
             result['parity_check'] = parity_check(args.dtype, args.depth, n=args.parity_qubits)
         except Exception as e:
             result['parity_check'] = {'error': repr(e)}
-    if args.sweep:
+    if args.sweep and budget('sweep', 30):
         # north_star: gate-applications/s for n = 30..36 random circuits.  Same generator, short depth,
         # every size that fits this job's HBM (single GPU: one state; sharded: two shard buffers per rank).
         try:
@@ -954,8 +987,12 @@ def main():
             result['sweep'] = {'depth': args.sweep_depth, 'n_gpus': world, 'rows': rows}
         except Exception as e:  # noqa: BLE001 -- a reported extra
             result['sweep_error'] = repr(e)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    if rank == 0 and not sharded_path and not args.no_fused and not args.no_variants and n >= args.variants_min_qubits and budget('blocked_variants', 30):
+        # The cache-blocked step under the opt-in kernel switches built without a GPU in rounds 4-5 (the library reads them once,
+        # so each runs in its own process): whoever runs this line on hardware gets the A/B with it.  Last: the longest leg.
+        result['blocked_variants'] = blocked_variants(n, args.dtype, time_left)
+    result['extras'] = {'budget_seconds': args.extras_seconds, 'used_seconds': time.perf_counter() - t_extras, 'skipped_for_budget': skipped}
+    emit(final=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -214,7 +214,7 @@ EXPORTED = [
     'hq_exchange_float32', 'hq_exchange_float64', 'hq_exchange_rounds_float32', 'hq_exchange_rounds_float64', 'hq_exchange_round_wait', 'hq_alloc', 'hq_free', 'hq_alloc_mapped', 'hq_alloc_scattered',
     'hq_alloc_state', 'hq_free_state', 'hq_state_info', 'hq_state_pool_trim',
     'hq_plan_blocked', 'hq_plan_counts', 'hq_plan_read', 'hq_plan_free', 'hq_plan_simplify', 'hq_plan_fuse',
-    'hq_blocked_selfcheck',
+    'hq_blocked_selfcheck', 'hq_pointer_info', 'hq_vmm_remap', 'hq_shard_comm_count',
 ]
 
 
@@ -457,10 +457,14 @@ def shard_p2p_register(local_plane, peer_addresses):
     _check(_shard_p2p_register(_ptr(local_plane), arr), 'hq_shard_p2p_register')
 
 
+_shard_comm_count = _define_function(_lib, 'hq_shard_comm_count', ctypes.c_int, ctypes.POINTER(ctypes.c_int))
+
+
 def shard_info():
-    w, r, t = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_int(0)
+    w, r, t, cnt = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_int(0), ctypes.c_int(0)
     _shard_info(ctypes.byref(w), ctypes.byref(r), ctypes.byref(t))
-    return {'world': w.value, 'rank': r.value, 'transport': {0: None, 1: 'rccl', 2: 'p2p'}[t.value]}
+    _check(_shard_comm_count(ctypes.byref(cnt)), 'hq_shard_comm_count')
+    return {'world': w.value, 'rank': r.value, 'transport': {0: None, 1: 'rccl', 2: 'p2p'}[t.value], 'rccl_ranks_seen': cnt.value}
 
 
 def shard_rccl_selftest(src, dst):

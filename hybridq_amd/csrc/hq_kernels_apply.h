@@ -273,7 +273,11 @@ struct BigOffsets { int64_t off[32]; };
 //   wave did not either, 4.67 ms: vmcnt counts loads and stores in order, so a prefetch issued
 //   before the stores cannot be waited for without waiting for the stores' acknowledgement, and
 //   the register allocator copies the second set around the loop).
-template <typename T, int KBITS, int VMASK, bool NT, int BLOCK, bool PHASED>
+//
+// TWOB (only meaningful where the table exceeds 64 KiB = complex128 k = 6): true = the second LDS base address of round 5
+// (no scratch, operand pipeline), false = the instantiation rounds 2-3 ran on hardware (plain indexing, operands read where
+// they are used, ~52 B/lane of scratch).  The host picks (HQ_BIG_TWOBASE, default 0 until a hardware run has seen the new form).
+template <typename T, int KBITS, int VMASK, bool NT, int BLOCK, bool PHASED, bool TWOB = true>
 __global__ void __launch_bounds__(BLOCK)
 apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ A,
                       const MfmaRoles ro, const BigOffsets tab, const uint64_t niter) {
@@ -303,11 +307,15 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
   // every read at base + immediate (32-bit LDS addresses: a pointer through inline assembly loses its address space):
   // 223 registers with the operand pipeline, no scratch.
   constexpr int kHalf = 65536 / 16;  // vectors
-  constexpr bool kTwoBases = (size_t)NRB * NG * 64 > (size_t)kHalf;
+  constexpr bool kTableAbove64K = (size_t)NRB * NG * 64 > (size_t)kHalf;
+  constexpr bool kTwoBases = kTableAbove64K && TWOB;
+  constexpr bool kOperandPipe = !kTableAbove64K || TWOB;  // (the round-2 form of complex128 k = 6 has no registers for a second operand pair)
   typedef __attribute__((address_space(3))) const V LdsCV;
   const unsigned al_lo = (unsigned)reinterpret_cast<uintptr_t>(Al);  // LDS byte address of this lane's slot of row 0
   unsigned al_hi = al_lo + (kTwoBases ? 65536u : 0u);
+#ifndef HQ_ASAN  // (host builds: the address is used as it is)
   if constexpr (kTwoBases) asm volatile("" : "+v"(al_hi));
+#endif
   auto Aop = [&](const int idx) -> V {
     if constexpr (!kTwoBases) return Al[idx];
     else return *reinterpret_cast<LdsCV*>((uintptr_t)((idx >= kHalf ? al_hi : al_lo) + 16u * (unsigned)(idx & (kHalf - 1))));
@@ -366,9 +374,16 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
         const int sg = g / NP, rb = 2 * (g % NP);
         const int gn = (g + 1) % NGRP, sgn = gn / NP, rbn = 2 * (gn % NP);
         V n0 = a0, n1 = a1;
-        if (g + 1 < NGRP || cf + 1 < NCB) {
-          n0 = Aop((rbn * NG + sgn) * 64);
-          n1 = Aop(((rbn + 1) * NG + sgn) * 64);
+        if constexpr (kOperandPipe) {
+          if (g + 1 < NGRP || cf + 1 < NCB) {
+            n0 = Aop((rbn * NG + sgn) * 64);
+            n1 = Aop(((rbn + 1) * NG + sgn) * 64);
+          }
+        } else {
+          a0 = Al[(rb * NG + sg) * 64];
+          a1 = Al[((rb + 1) * NG + sg) * 64];
+          n0 = a0;
+          n1 = a1;
         }
         __builtin_amdgcn_sched_barrier(0);  // the reads of the NEXT pair-group stay in front of ...
 #pragma unroll

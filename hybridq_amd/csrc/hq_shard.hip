@@ -21,6 +21,7 @@ struct RcclApi {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;  // optional (diagnostics)
 };
 
 struct Shard {
@@ -75,6 +76,7 @@ static int load_rccl(Shard& sh) {
   HQ_SYM(Recv, "ncclRecv")
   HQ_SYM(GetErrorString, "ncclGetErrorString")
 #undef HQ_SYM
+  a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
   return 0;
 }
 
@@ -170,13 +172,9 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
   if (m > 62 || m < 2 * sh.g + 2) return fail("exchange: shard too small for the number of ranks");
   if (sub_bits > 6 || (sub_bits && m < 2 * sh.g + 2 + sub_bits)) return fail("exchange: too many rounds for this shard");
   const bool rounds = n_rounds != nullptr;
-  if (rounds) { *n_rounds = 1; sh.rounds_pending = 1; }
-  if (rounds && sh.round_ev.empty()) {  // round 0 of a one-round exchange: nothing to wait for, but the event must exist
-    hipEvent_t e0 = nullptr;
-    HQ_HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-    sh.round_ev.push_back(e0);
-  }
-  if (rounds) HQ_HIP_CHECK(hipEventRecord(sh.round_ev[0], c.stream));  // "everything issued so far": overwritten by the RCCL path
+  // No shard state changes before every argument has been validated, and a call that fails leaves NO round to wait for:
+  // rounds_pending is set when (and to what) the call has really recorded (hq_exchange_round_wait refuses the rest).
+  if (rounds) { *n_rounds = 1; sh.rounds_pending = 0; }
   if (!is_device_pointer(src_re) || !is_device_pointer(src_im) || !is_device_pointer(dst_re) || !is_device_pointer(dst_im))
     return fail("exchange: device pointers only");
   const unsigned G = sh.world, g = sh.g;
@@ -208,15 +206,27 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
   }
   unsigned char* S_[2] = {reinterpret_cast<unsigned char*>(src_re), reinterpret_cast<unsigned char*>(src_im)};
   unsigned char* D[2] = {reinterpret_cast<unsigned char*>(dst_re), reinterpret_cast<unsigned char*>(dst_im)};
+  // one-round transports (single rank, peer-to-peer): round 0 = "everything this call has issued on the library stream"
+  auto one_round_done = [&]() -> int {
+    if (!rounds) return 0;
+    if (sh.round_ev.empty()) {
+      hipEvent_t e0 = nullptr;
+      HQ_HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+      sh.round_ev.push_back(e0);
+    }
+    HQ_HIP_CHECK(hipEventRecord(sh.round_ev[0], c.stream));
+    sh.rounds_pending = 1;
+    return 0;
+  };
 
   if (G == 1) {  // one rank: the exchange is the permutation alone
-    if (!has_perm) { *result_in_src = 1; return 0; }
+    if (!has_perm) { *result_in_src = 1; return one_round_done(); }
     a.planes = 2;
     a.dst[0][0] = D[0];
     a.dst[0][1] = D[1];
     if (launch_pack<E>(c, c.stream, src_re, src_im, a, has_perm ? perm : nullptr)) return 1;
     *result_in_src = 0;
-    return 0;
+    return one_round_done();
   }
 
   if (sh.transport == 2) {
@@ -235,7 +245,7 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
     }
     if (launch_pack<E>(c, c.stream, src_re, src_im, a, has_perm ? perm : nullptr)) return 1;
     *result_in_src = 0;
-    return 0;
+    return one_round_done();
   }
 
   // RCCL transport: every rank sends chunk j to rank j and receives chunk j from it, all 2(G-1)
@@ -259,7 +269,7 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
       HQ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       sh.round_ev.push_back(e);
     }
-    *n_rounds = sh.rounds_pending = S;
+    *n_rounds = S;
     unsigned char** from = has_perm ? D : S_;
     unsigned char** to = has_perm ? S_ : D;
     if (has_perm) {
@@ -273,14 +283,26 @@ static int exchange_entry(E* src_re, E* src_im, E* dst_re, E* dst_im, unsigned m
     } else {
       HQ_HIP_CHECK(hipEventRecord(sh.ev[0], c.stream));  // src is final once the stream reaches here
     }
+    // One ncclGroup per round carrying BOTH planes = 4(G-1) transfers, so that every xGMI link has a send and a receive of
+    // each plane queued in every round (include/hq_hip.h).  The one exception is round 0 of an exchange with a folded
+    // permutation: the re plane's transfers go in a group of their own as soon as re is packed, while im is still being
+    // packed on the library stream (one group would make the re transfers wait for the im pack).
     for (unsigned s_ = 0; s_ < S; ++s_) {
-      for (int p = 0; p < 2; ++p) {
-        if (s_ == 0 && (p == 0 || has_perm)) HQ_HIP_CHECK(hipStreamWaitEvent(cs, sh.ev[p], 0));
+      if (s_ == 0 && has_perm) {
+        for (int p = 0; p < 2; ++p) {
+          HQ_HIP_CHECK(hipStreamWaitEvent(cs, sh.ev[p], 0));
+          HQ_NCCL_CHECK(sh, sh.api.GroupStart());
+          if (transfer_plane(from[p], to[p], 0)) { (void)sh.api.GroupEnd(); return 1; }
+          HQ_NCCL_CHECK(sh, sh.api.GroupEnd());
+        }
+      } else {
+        if (s_ == 0) HQ_HIP_CHECK(hipStreamWaitEvent(cs, sh.ev[0], 0));
         HQ_NCCL_CHECK(sh, sh.api.GroupStart());
-        if (transfer_plane(from[p], to[p], s_)) { (void)sh.api.GroupEnd(); return 1; }
+        if (transfer_plane(from[0], to[0], s_) || transfer_plane(from[1], to[1], s_)) { (void)sh.api.GroupEnd(); return 1; }
         HQ_NCCL_CHECK(sh, sh.api.GroupEnd());
       }
       HQ_HIP_CHECK(hipEventRecord(sh.round_ev[s_], cs));
+      sh.rounds_pending = s_ + 1;  // an error further down leaves exactly the recorded rounds waitable
     }
     for (int p = 0; p < 2; ++p)  // self chunk, all its pieces (with a permutation: after BOTH packs, src chunk `rank` is free)
       if (copy16(c, c.stream, to[p] + (size_t)sh.rank * chunk, from[p] + (size_t)sh.rank * chunk, chunk)) return 1;
@@ -446,6 +468,18 @@ int hq_shard_info(unsigned int* world, unsigned int* rank, int* transport) {
   return 0;
 }
 
+int hq_shard_comm_count(int* count) {
+  if (!count) return hq::fail("hq_shard_comm_count: null pointer");
+  hq::Context& c = hq::ctx();
+  std::lock_guard<std::mutex> lock(c.mu);
+  hq::Shard& sh = hq::shard();
+  *count = 0;
+  if (sh.transport != 1 || !sh.comm) return 0;
+  *count = (int)sh.world;
+  if (sh.api.CommCount) HQ_NCCL_CHECK(sh, sh.api.CommCount(sh.comm, count));
+  return 0;
+}
+
 int hq_shard_free(void) {
   hq::Context& c = hq::ctx();
   std::lock_guard<std::mutex> lock(c.mu);
@@ -461,6 +495,7 @@ int hq_shard_free(void) {
   sh.comm = nullptr;
   sh.own_comm = false;
   sh.registry.clear();
+  sh.rounds_pending = 0;  // (the round events themselves are kept for the next transport: they are re-recorded before use)
   ++sh.epoch;
   sh.transport = 0;
   sh.world = 1;

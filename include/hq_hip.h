@@ -45,6 +45,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libhq_hip.so is built with -fvisibility=hidden: the prototypes below are its ENTIRE dynamic symbol table (like the
+ * reference's hybridq.so / hybridq_swap.so, which export their C symbols and nothing else: python_U.cpp:127-154,
+ * python_swap.cpp:68-99); tests/test_abi.py compares `nm -D` with this header in both directions. */
+#pragma GCC visibility push(default)
 
 /* ------------------------------------------------------------------------- */
 /* Part 1 -- reference boundary                                               */
@@ -232,6 +236,9 @@ int hq_shard_free(void);
  * with this rank as its own peer, through the same stream / event ordering as the exchange.  Needs a
  * communicator (a one-rank hq_shard_init_rccl with a unique id is legal). */
 int hq_shard_rccl_selftest(const void *src, void *dst, uint64_t bytes);
+/* Ranks of the library's RCCL communicator as RCCL itself reports them (ncclCommCount); 0 when the transport is not RCCL.
+ * What a multi-GPU record cites to show that the exchange really ran between `count` processes over RCCL. */
+int hq_shard_comm_count(int *count);
 int hq_ipc_export(const void *dev_ptr, void *handle64, uint64_t *offset);
 int hq_ipc_open(const void *handle64, uint64_t offset, void **dev_ptr);
 int hq_ipc_close(void *dev_ptr, uint64_t offset);
@@ -240,15 +247,18 @@ int hq_exchange_float32(float *src_re, float *src_im, float *dst_re, float *dst_
 int hq_exchange_float64(double *src_re, double *src_im, double *dst_re, double *dst_im, unsigned int n_local,
                         const unsigned int *perm, int *result_in_src);
 /* The same exchange in 2^sub_bits ROUNDS (sub_bits <= 6, n_local >= 2g + 2 + sub_bits): round s moves piece s (of
- * 2^sub_bits) of every chunk, both planes -- all 2(G-1) transfers of a round in one ncclGroup, so every xGMI link is busy
- * in every round -- and the library stream does NOT wait for the transfers: hq_exchange_round_wait(s) makes it wait for
+ * 2^sub_bits) of every chunk, both planes -- all 4(G-1) transfers of a round (a send and a receive per peer and plane) in
+ * ONE ncclGroup, so every xGMI link is busy in every round; only round 0 of an exchange with a folded permutation uses one
+ * group per plane (the re plane leaves while im is still being packed) -- and the library stream does NOT wait for the transfers: hq_exchange_round_wait(s) makes it wait for
  * round s, after which pieces [chunk j][piece s] of the result planes (where *result_in_src says) are final and the
  * caller may work on them while the later rounds are still on the wire (hybridq_amd.dist: the local gates attached to
  * an exchange run on the pieces as they land).  The caller waits for EVERY round, the last one at the latest before it
  * touches either plane pair in any other way.  The pack pass stays folded in (a plane's rounds start when that plane has
  * been packed; the rounds of re overlap the pack of im).  *n_rounds: the number of rounds actually used -- 2^sub_bits on
  * the RCCL transport, 1 on the peer-to-peer transport (whose stores the caller brackets with barriers as for
- * hq_exchange_*) and on a single rank; hq_exchange_round_wait(0) is then a no-op in stream order. */
+ * hq_exchange_*) and on a single rank; hq_exchange_round_wait(0) is then a no-op in stream order.  A call that is
+ * rejected (bad arguments, no transport) changes no state and leaves NO round to wait for: hq_exchange_round_wait then
+ * fails for every round, as it does after hq_shard_free. */
 int hq_exchange_rounds_float32(float *src_re, float *src_im, float *dst_re, float *dst_im, unsigned int n_local,
                                const unsigned int *perm, unsigned int sub_bits, int *result_in_src, unsigned int *n_rounds);
 int hq_exchange_rounds_float64(double *src_re, double *src_im, double *dst_re, double *dst_im, unsigned int n_local,
@@ -355,6 +365,14 @@ int hq_plan_simplify(unsigned int n_qubits, unsigned int n_gates, const unsigned
                      const double *U, double atol, int use_matrix_commutation, unsigned int max_n_qubits_matrix,
                      int remove_id_gates, unsigned int *out_index, unsigned int *out_count);
 
+/* Diagnostics (no reference counterpart).  hq_pointer_info: the raw hipPointerGetAttributes answer for `p` (memory type,
+ * owning device, HIP error code); returns 0 when the runtime knows the pointer.  hq_vmm_remap (tools/placement_remap.py): the
+ * SAME physical granules of a buffer from hq_alloc_mapped / hq_alloc_scattered mapped in another order into a fresh virtual
+ * range (granule i -> slot va_slot[i]); the old range is retired, *new_ptr replaces dev_ptr (free it with hq_free). */
+int hq_pointer_info(const void *p, int *type, int *device, int *err);
+int hq_vmm_remap(void *dev_ptr, const uint32_t *va_slot, void **new_ptr);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

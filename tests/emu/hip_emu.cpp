@@ -433,6 +433,10 @@ hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
   s->capture = nullptr;
   return hipSuccess;
 }
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* st) {
+  *st = (s && s->capture) ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
+  return hipSuccess;
+}
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
   *e = new hq_emu_graph_exec{g->ops};
   return hipSuccess;

@@ -169,6 +169,12 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t c, int* count) {
+  if (!c || !count) return ncclInvalidArgument;
+  *count = c->world;
+  return ncclSuccess;
+}
+
 ncclResult_t ncclGroupStart() { ++g_depth; return ncclSuccess; }
 
 ncclResult_t ncclGroupEnd() {

@@ -66,6 +66,7 @@ enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTy
 struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive, hipStreamCaptureStatusInvalidated };
 enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
 enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
 enum hipMemAllocationGranularity_flags { hipMemAllocationGranularityMinimum = 0 };
@@ -103,6 +104,7 @@ hipError_t hipStreamQuery(hipStream_t);
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned);
 hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode);
 hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*);
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus*);
 hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t);
 hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t);
 hipError_t hipGraphDestroy(hipGraph_t);

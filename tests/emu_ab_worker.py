@@ -1,6 +1,7 @@
 """Worker of tests/test_emu_kernels.py::test_pipelined_loops_are_bit_identical: digests of cache-blocked passes (every shape of
 inner gate) and of k = 4..10 gates through the tile GEMM kernel on the emulated device; the caller runs it against the
-default switches and under HQ_BLOCKED_PIPE=0 HQ_GEMM_PIPE=0 (the loops of rounds 1-4a) and compares line by line."""
+default switches (the loops hardware has run) and under HQ_BLOCKED_PIPE=1 HQ_GEMM_PIPE=1 HQ_BIG_TWOBASE=1 (the operand-ahead
+loops of rounds 4-5) and compares line by line; k = 5, 6 through the role kernel as well (complex128 k = 6: two LDS bases)."""
 import hashlib
 import os
 import sys
@@ -49,4 +50,10 @@ for ft in (np.float32, np.float64):
         finally:
             core.set_apply_mode('auto')
         print(f'gemm_{ft.__name__}_{k}', core.last_kernel_desc().replace(' ', '_'), digest(re, im), flush=True)
+    for k in (5, 6):  # role kernel (apply_mfma_big_kernel); no target on index bit 0: the widest instantiation
+        pos = [int(p) for p in 1 + rng.permutation(n - 1)[:k]]
+        U = rand_u(k, ct)
+        re[:], im[:] = psi.real, psi.imag
+        core.apply_U(re, im, U, pos, n)
+        print(f'role_{ft.__name__}_{k}', core.last_kernel_desc().replace(' ', '_'), digest(re, im), flush=True)
     free()

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
     src = open(os.path.join(ROOT, 'include', 'hq_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'^\s*#.*$', '', src, flags=re.M)  # preprocessor lines (the visibility pragma)
     return sorted(set(re.findall(r'\b([A-Za-z_][A-Za-z0-9_]*)\s*\(', src)) - {'defined'})
 
 
@@ -23,6 +24,20 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(core._lib, s), s
     assert sorted(core.EXPORTED) == syms
+
+
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """`nm -D` of libhq_hip.so == the prototypes of include/hq_hip.h, in both directions: no mangled hq:: internals, no kernel
+    handles, no undeclared C entry points (the reference's .so files export their C symbols and nothing else,
+    python_U.cpp:127-154, python_swap.cpp:68-99).  -fvisibility=hidden + the header's visibility pragma + libhq_hip.map."""
+    import subprocess
+    from hybridq_amd import build
+    out = subprocess.run(['nm', '-D', '--defined-only', build.LIB], capture_output=True, text=True, check=True).stdout
+    rows = [ln.split() for ln in out.splitlines() if ln.strip()]
+    exported = sorted(r[-1] for r in rows)
+    assert all(r[-2] == 'T' for r in rows), [r for r in rows if r[-2] != 'T'][:5]
+    assert not [s for s in exported if s.startswith('_Z')], [s for s in exported if s.startswith('_Z')][:5]
+    assert exported == _header_symbols(), (set(exported) ^ set(_header_symbols()))
 
 
 def test_reference_boundary_names_present():

@@ -81,12 +81,18 @@ def test_host_pointer_path_stages_through_emulated_device_memory():
     assert np.array_equal(a, src)  # new[x] = old[(x & ~7) | sum_i x_i << pos[i]]
 
 
-def test_wave_order():
-    """Forward, reverse and random wave schedules give the same bits for every LDS-synchronised kernel family."""
+@pytest.mark.parametrize('variants', [False, True], ids=['defaults', 'opt_in_loops'])
+def test_wave_order(variants):
+    """Forward, reverse and random wave schedules give the same bits for every LDS-synchronised kernel family -- under the
+    library's defaults (the loops hardware has run) and with the opt-in loops of rounds 4-5 switched on (pipelined inner gates,
+    barrier-free wave groups, operand-ahead K loop, two LDS bases)."""
+    extra = dict(HQ_BLOCKED_PIPE='1', HQ_BLOCKED_GROUPS='1', HQ_GEMM_PIPE='1', HQ_BIG_TWOBASE='1') if variants else {}
     outs = {}
     for order in ('forward', 'reverse', 'random'):
         env = dict(os.environ, HQ_EMU_ORDER=order, PYTHONPATH=ROOT)
-        env.pop('HQ_HIP_LIBRARY', None)
+        for var in ('HQ_HIP_LIBRARY', 'HQ_BLOCKED_PIPE', 'HQ_BLOCKED_GROUPS', 'HQ_GEMM_PIPE', 'HQ_BIG_TWOBASE'):
+            env.pop(var, None)
+        env.update(extra)
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu_order_worker.py')], env=env, capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -99,9 +105,16 @@ def test_wave_order():
     for order in ('reverse', 'random'):
         diff = {k: (outs['forward'][k], outs[order].get(k)) for k in outs['forward'] if outs[order].get(k) != outs['forward'][k]}
         assert not diff, (order, diff)
-    # the cache-blocked pass ran WITH barrier-free groups (round 4): fewer workgroup barriers than gates
+    # opt-in: the cache-blocked pass ran WITH barrier-free groups (round 4), fewer workgroup barriers than gates; default: one per gate
     blk = [k for k in outs['forward'] if k.startswith('blocked_float32_barriers')]
-    assert blk and int(blk[0].rsplit('barriers', 1)[1]) < 7, blk
+    assert blk and (int(blk[0].rsplit('barriers', 1)[1]) < 7) == variants, blk
+    _WAVE_ORDER_DIGESTS[variants] = {k.split('barriers')[0]: v for k, v in outs['forward'].items()}
+    if len(_WAVE_ORDER_DIGESTS) == 2:  # and the two settings agree bit for bit (requests and barriers move, arithmetic does not)
+        a, b = _WAVE_ORDER_DIGESTS[False], _WAVE_ORDER_DIGESTS[True]
+        assert a == b, {k: (a[k], b.get(k)) for k in a if a[k] != b.get(k)}
+
+
+_WAVE_ORDER_DIGESTS = {}
 
 
 def test_blocked_direct_pass():
@@ -153,24 +166,30 @@ def test_blocked_direct_pass():
 
 
 def test_pipelined_loops_are_bit_identical():
-    """The operand-ahead loops of round 4 (cache-blocked inner gates: LDS requests one wave-iteration / one vector ahead of
-    the MFMAs; tile GEMM: B operands one K-step, A operands one step group ahead) change the ORDER OF REQUESTS only: every
-    shape of inner gate and k = 4..10 through the GEMM kernel give the same bits as the loops they replaced, which the
-    library still contains as a run-time alternative (HQ_BLOCKED_PIPE=0 HQ_GEMM_PIPE=0: template parameters of the same kernels)."""
+    """The operand-ahead loops of rounds 4-5 (cache-blocked inner gates: LDS requests one wave-iteration / one vector ahead of
+    the MFMAs; tile GEMM: B operands one K-step, A operands one step group ahead; complex128 k = 6 role kernel: second LDS
+    base address + operand pipeline) change the ORDER OF REQUESTS only: every shape of inner gate, k = 4..10 through the GEMM
+    kernel and k = 5, 6 through the role kernel give the same bits as the loops hardware has run, which are the library's
+    defaults (HQ_BLOCKED_PIPE=1 HQ_GEMM_PIPE=1 HQ_BIG_TWOBASE=1 select the new ones: template parameters of the same kernels)."""
     outs = {}
-    for name, extra in (('default', {}), ('old_loops', dict(HQ_BLOCKED_PIPE='0', HQ_GEMM_PIPE='0'))):
+    for name, extra in (('default', {}), ('new_loops', dict(HQ_BLOCKED_PIPE='1', HQ_GEMM_PIPE='1', HQ_BIG_TWOBASE='1'))):
         env = dict(os.environ, PYTHONPATH=ROOT, **extra)
-        env.pop('HQ_HIP_LIBRARY', None)
+        for var in ('HQ_HIP_LIBRARY', 'HQ_BLOCKED_PIPE', 'HQ_GEMM_PIPE', 'HQ_BIG_TWOBASE', 'HQ_BLOCKED_GROUPS', 'HQ_BLOCKED_DIRECT', 'HQ_BLOCKED_BIG'):
+            if var not in extra:
+                env.pop(var, None)
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu_ab_worker.py')], env=env, capture_output=True, text=True,
                            timeout=1800)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[name] = [ln.split() for ln in r.stdout.strip().splitlines()]
+    # the DEFAULT run launches the hardware-verified loops everywhere (VERDICT r05 next #2)
+    assert not any('pipe=1' in ln[1] or 'twobase=1' in ln[1] for ln in outs['default']), outs['default']
     # (three complex128 k = 4 gates: their operand tables do not fit behind the tile, that pass computes its addresses)
-    assert sum('pipe=1' in ln[1] for ln in outs['default'] if 'blocked' in ln[1]) == 5 and not any('pipe=1' in ln[1] for ln in outs['old_loops'])
-    for o in outs.values():  # the descriptions differ in the pipe= marker only
+    assert sum('pipe=1' in ln[1] for ln in outs['new_loops'] if 'blocked' in ln[1]) == 5
+    assert sum('twobase=1' in ln[1] for ln in outs['new_loops']) == 1 and sum('twobase=0' in ln[1] for ln in outs['default']) == 1
+    for o in outs.values():  # the descriptions differ in the pipe= / twobase= markers only
         for ln in o:
-            ln[1] = ln[1].replace('_pipe=1', '').replace('_pipe=0', '')
-    assert len(outs['default']) == 20 and outs['default'] == outs['old_loops'], [(a, b) for a, b in zip(outs['default'], outs['old_loops']) if a != b]
+            ln[1] = ln[1].replace('_pipe=1', '').replace('_pipe=0', '').replace('_twobase=1', '').replace('_twobase=0', '')
+    assert len(outs['default']) == 24 and outs['default'] == outs['new_loops'], [(a, b) for a, b in zip(outs['default'], outs['new_loops']) if a != b]
     assert sum('gemm' in ln[1] for ln in outs['default']) >= 8 and sum('blocked' in ln[1] for ln in outs['default']) == 6
 
 

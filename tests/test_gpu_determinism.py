@@ -17,10 +17,10 @@ SETTINGS = [
     {},
     {'HQ_BLOCKED_PREF': '0', 'HQ_GEMM_PREF': '0', 'HQ_SWAP_PREF': '0'},
     {'HQ_BLOCKED_ALDS': '0'},
-    {'HQ_BIG_PHASED': '0', 'HQ_BLOCKED_PIPE': '0', 'HQ_GEMM_PIPE': '0'},  # round 5: the inner-gate / K loops of rounds 1-4a
+    {'HQ_BIG_PHASED': '0', 'HQ_BLOCKED_PIPE': '1', 'HQ_GEMM_PIPE': '1', 'HQ_BIG_TWOBASE': '1'},  # rounds 4-5 (opt-in): operand-ahead inner-gate / K loops, two LDS bases
     {'HQ_BIG_PHASED': '1', 'HQ_PERM_TB': '12', 'HQ_PERM_INPLACE_TB': '14'},
     {'HQ_PERM_TILE': '0'},  # round-2 paths: table-driven swap, two tile passes, gather kernels
-    {'HQ_BLOCKED_GROUPS': '0'},  # round 4: a workgroup barrier after EVERY inner gate (default: barrier-free wave groups)
+    {'HQ_BLOCKED_GROUPS': '1', 'HQ_BLOCKED_PIPE': '1'},  # round 4 (opt-in): barrier-free wave groups (default: a workgroup barrier after EVERY inner gate)
     {'HQ_BLOCKED_DIRECT': '1', 'HQ_BLOCKED_GRID': '64'},  # round 4: tile movement folded into the first gate, 8 tiles per workgroup
 ]
 _seen = {}
@@ -42,5 +42,6 @@ def test_lds_kernels_are_deterministic(torch_cuda, idx, capsys):
         name, h = ln.rsplit(' ', 1)
         if 'swap' in name or 'permute_bits' in name or 'exchange pack' in name:  # pure data movement: one right answer
             assert _seen.setdefault(name, h) == h, (name, SETTINGS[idx])
-        if 'blocked' in name and SETTINGS[idx] in ({}, {'HQ_BLOCKED_GROUPS': '0'}):  # the groups change barriers, not arithmetic
+        if 'blocked' in name and SETTINGS[idx] in ({}, SETTINGS[3], SETTINGS[6]):  # pipelining and groups change requests and barriers, not arithmetic
+            name = name.replace(' pipe=1', ' pipe=0')
             assert _blocked.setdefault(name, h) == h, (name, SETTINGS[idx])

@@ -197,6 +197,115 @@ def test_exchange_rounds_equal_the_plain_exchange(torch_cuda, tmp_path, world):
             assert r['rounds'] == (1 << int(key[-1]) if WANT_TRANSPORT == 'rccl' else 1), (rank, key, r)
 
 
+def _per_gpu_worker(rank, world, port, n, n_dm, out_dir):
+    """One rank PER GPU on the `nccl` (= RCCL) process group: what `bench.py --gpus N` and `simulate(devices=N)` are on a
+    multi-GPU node.  Under the host emulation the ranks are processes on the emulated device, the process group is gloo
+    and HQ_SHARD_TRANSPORT=rccl selects the same library transport (tests/emu/rccl_emu.cpp between the processes)."""
+    import emu_boot
+    emu = emu_boot.maybe_install()
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = 0 if emu else rank
+    torch.cuda.set_device(dev)
+    if emu:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev))
+    try:
+        from bench import dm_workload
+        from hybridq_amd import core
+        from hybridq_amd.circuits import rqc_1q2q
+        from hybridq_amd.dist import ShardedEvolution
+        import hybridq_amd.dist as dist_mod
+        out = {}
+        cfg3 = rqc_1q2q(n, depth=8, seed=33)                  # BASELINE configs[2]: random circuit, high-qubit shard
+        cfg5 = dm_workload(n_dm // 2, 4)                      # BASELINE configs[4]: noisy circuit as a 2 nq-qubit state vector
+        sh = ShardedEvolution(n, complex_type='complex64', initial_state='0' * n)
+        info = core.shard_info()
+        sched = sh.plan(cfg3)
+        sh.run(sched)
+        out['cfg3'] = sh.state_numpy()
+        out['cfg3_exchanges'] = sum(1 for op in sched if op[0] in ('X', 'XP'))
+        out['cfg3_folded'] = sum(1 for op in sched if op[0] == 'XP')
+        del sh
+        if emu:
+            dist_mod.OVERLAP_MIN_SUB_QUBITS = 8  # (the toy shards of the emulated run)
+        sho = ShardedEvolution(n, complex_type='complex64', initial_state='0' * n, overlap=True)  # exchanges in rounds, gates on the pieces
+        scho = sho.plan(cfg3)
+        sho.run(scho)
+        out['cfg3_overlap'] = sho.state_numpy()
+        out['cfg3_rounds_exchanges'] = sum(1 for op in scho if op[0] == 'XO')
+        del sho
+        shd = ShardedEvolution(n_dm, complex_type='complex64', initial_state='0' * n_dm)
+        shd.run(shd.plan(cfg5))
+        out['cfg5'] = shd.state_numpy()
+        del shd
+        infos = [None] * world
+        dist.all_gather_object(infos, dict(info, device=torch.cuda.current_device(), backend=dist.get_backend()))
+        if rank == 0:
+            import json
+            np.savez(os.path.join(out_dir, 'per_gpu.npz'), **out)
+            with open(os.path.join(out_dir, 'per_gpu.json'), 'w') as f:
+                json.dump(infos, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_sharded_one_rank_per_gpu_over_rccl(torch_cuda, tmp_path, world, capsys):
+    """Lights up by itself on a box with >= `world` GPUs (skipped on a one-GPU box; runs against tests/emu/rccl_emu.cpp in the
+    CPU suite): one process per GPU on the nccl backend, so HipBackend takes the RCCL transport -- a communicator of `world`
+    ranks made by the LIBRARY (hq_shard_init_rccl), grouped ncclSend / ncclRecv over xGMI -- and runs the BASELINE config-3
+    generator at n = 24 + g (plain exchanges, exchanges with the folded eviction permutation, exchanges in rounds with the
+    local gates applied to the pieces as they land) and the config-5 noisy-dm generator, each against the reference core
+    driven by the reference protocol on ONE process.  No reference counterpart (simulation.py:379-380: no multi-process
+    path); oracle: /root/reference/include/U.h:28-202 via oracle.evolve_reference_protocol."""
+    torch = torch_cuda
+    if EMU:
+        if WANT_TRANSPORT != 'rccl':
+            pytest.skip('one rank per GPU needs the RCCL transport (emulated: HQ_SHARD_TRANSPORT=rccl)')
+    elif torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
+    import json
+    import torch.multiprocessing as mp
+    import oracle
+    from bench import dm_workload
+    from hybridq_amd.circuits import rqc_1q2q
+    from tolerances import circuit_tol
+    g = int(np.log2(world))
+    n = (14 if EMU else 24) + g
+    n_dm = 2 * ((n + 1) // 2)
+    mp.spawn(_per_gpu_worker, args=(world, _free_port(), n, n_dm, str(tmp_path)), nprocs=world, join=True)
+    out = np.load(os.path.join(str(tmp_path), 'per_gpu.npz'))
+    infos = json.load(open(os.path.join(str(tmp_path), 'per_gpu.json')))
+    # the exchange really ran over RCCL between `world` processes, one per device
+    assert len(infos) == world
+    for r, info in enumerate(infos):
+        assert info['transport'] == 'rccl' and info['world'] == world and info['rank'] == r and info['rccl_ranks_seen'] == world, info
+        assert EMU or (info['device'] == r and info['backend'] == 'nccl'), info
+    lib = oracle.load_ref() if oracle.have_ref() else oracle.load_port()
+    cfg3 = rqc_1q2q(n, depth=8, seed=33)
+    exp3, _ = oracle.evolve_reference_protocol(lib, cfg3, n, complex_type='complex64', qubits=list(range(n)))
+    tol3 = circuit_tol(cfg3, cfg3, complex_type='complex64')
+    scale = np.abs(exp3).max()
+    err = np.abs(out['cfg3'].reshape(-1) - exp3).max() / scale
+    err_o = np.abs(out['cfg3_overlap'].reshape(-1) - exp3).max() / scale
+    assert err <= tol3 and err_o <= tol3, (err, err_o, tol3)
+    assert int(out['cfg3_exchanges']) >= 1 and int(out['cfg3_folded']) >= 1 and int(out['cfg3_rounds_exchanges']) >= 1
+    cfg5 = dm_workload(n_dm // 2, 4)
+    exp5, _ = oracle.evolve_reference_protocol(lib, cfg5, n_dm, complex_type='complex64', qubits=list(range(n_dm)))
+    tol5 = circuit_tol(cfg5, cfg5, complex_type='complex64')
+    err5 = np.abs(out['cfg5'].reshape(-1) - exp5).max() / np.abs(exp5).max()
+    assert err5 <= tol5, (err5, tol5)
+    with capsys.disabled():
+        print(f'\n  {world} ranks, one per {"emulated process" if EMU else "GPU"}, RCCL transport (ncclCommCount = {infos[0]["rccl_ranks_seen"]}): config 3 n={n} '
+              f'err {err:.2e} (in rounds with overlapped gates {err_o:.2e}; allowed {tol3:.2e}; literal bar met: {bool(max(err, err_o) <= 1e-6)}), '
+              f'config 5 n={n_dm} err {err5:.2e} (allowed {tol5:.2e}); {int(out["cfg3_exchanges"])} exchanges, {int(out["cfg3_folded"])} with a folded permutation')
+
+
 def test_exchange_one_rank_is_the_permutation(torch_cuda):
     """hq_exchange_* with one rank: no permutation = nothing to do (result stays in src), with a
     permutation = exactly hq_permute_bits on both planes (the pack pass alone)."""
@@ -327,7 +436,7 @@ def test_bench_eight_ranks_sharing_the_gpu(torch_cuda, workload, qubits):
     workloads (BASELINE configs 3 and 5 at toy size), with the eight ranks sharing the one GPU of this box
     (HQ_BENCH_SHARE_GPU=1: gloo process group, peer-to-peer exchange through HIP IPC): the whole N > 1 code path of the
     bench -- planner, exchanges with folded permutations, per-op events, exchange timing block with its analytic
-    expectation -- runs and prints ONE well-formed JSON line.  The numbers mean nothing on a shared GPU."""
+    expectation -- runs and prints its two well-formed JSON lines (headline first, complete line last).  The numbers mean nothing on a shared GPU."""
     import json
     import subprocess
     env = dict(os.environ, HQ_BENCH_SHARE_GPU='1', OMP_NUM_THREADS='1')
@@ -340,8 +449,14 @@ def test_bench_eight_ranks_sharing_the_gpu(torch_cuda, workload, qubits):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines) == 2, out.stdout[-2000:]  # the headline right after the timed region, the complete line last (rank 0 only)
+    h, d = json.loads(lines[0]), json.loads(lines[1])
+    assert h['line'].startswith('headline') and d['line'] == 'complete' and 'exchange' not in h
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'dtype', 'config', 'roofline'):
+        assert h[key] == d[key], key
+    # which transport the exchange really took, and between how many processes (RCCL: as ncclCommCount reports it)
+    assert h['exchange_transport']['transport'] == WANT_TRANSPORT and h['exchange_transport']['world'] == 8
+    assert h['exchange_transport']['rccl_ranks_seen'] == (8 if WANT_TRANSPORT == 'rccl' else 0), h['exchange_transport']
     assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['steps'] == 2 and d['value'] > 0
     assert d['config']['n_qubits'] == qubits and d['config']['exchanges_per_step'] >= 1
     ex = d['exchange']

@@ -28,7 +28,7 @@ def _worker(**env):
     res = json.loads(r.stdout.strip().splitlines()[-1])
     chk = res.pop('selfcheck')
     assert 'disagree' not in r.stderr, r.stderr[-2000:]
-    if any(env.get(k, d) != '0' for k, d in (('HQ_BLOCKED_PIPE', '1'), ('HQ_BLOCKED_GROUPS', '1'), ('HQ_BLOCKED_DIRECT', '0'), ('HQ_BLOCKED_BIG', '0'))):
+    if any(env.get(k, d) != '0' for k, d in (('HQ_BLOCKED_PIPE', '0'), ('HQ_BLOCKED_GROUPS', '0'), ('HQ_BLOCKED_DIRECT', '0'), ('HQ_BLOCKED_BIG', '0'))):
         assert chk['runs'] >= 1 and chk['failures'] == 0, chk
     for ct, r_ in res.items():  # the parity statement: every setting against the oracle
         assert r_['err_vs_oracle'] <= r_['tol'], (ct, env, r_)
@@ -40,7 +40,7 @@ def _worker(**env):
                          ids=lambda e: 'pipe%s_groups%s' % (e['HQ_BLOCKED_PIPE'], e['HQ_BLOCKED_GROUPS']))
 def test_blocked_staged_variants_against_the_oracle(torch_cuda, capsys, env):
     """The staged cache-blocked kernel in its four settings -- the loops of round 2 (HQ_BLOCKED_PIPE=0 HQ_BLOCKED_GROUPS=0:
-    the ones GPUTEST_r02 saw), pipelined inner gates, barrier-free wave groups, both (the default) -- each against the
+    the ones GPUTEST_r02 saw = the default), pipelined inner gates, barrier-free wave groups, both -- each against the
     oracle on a depth-16 circuit, several tiles per workgroup; all four agree bit for bit (same arithmetic, same order)."""
     res = _worker(HQ_BLOCKED_GRID='256', **env)
     with capsys.disabled():
@@ -82,3 +82,29 @@ def test_blocked_128k_tiles_on_the_device(torch_cuda, capsys):
             assert res['complex64 inner_max=3']['passes_1024_threads'] >= 1, res
             if direct == '1':
                 assert res['complex64 inner_max=3']['direct_passes'] >= 1, res
+
+
+def test_wide_kernels_both_loop_forms_against_the_oracle(torch_cuda, capsys):
+    """k = 5..10 (role kernel with the operand table in LDS: apply_mfma_big_kernel; tile GEMM: apply_gemm_kernel), both
+    precisions, several position patterns, PER CALL against the oracle (north_star's literal bar; k >= 7 in float32: the
+    rounding model of one 2^(k+1)-term accumulation, as in test_gpu_parity.py: wide_tol) -- once with the library's
+    defaults (the K loop / operand reads hardware has run: HQ_GEMM_PIPE=0, HQ_BIG_TWOBASE=0) and once with the operand-ahead
+    forms of rounds 4-5 (HQ_GEMM_PIPE=1, HQ_BIG_TWOBASE=1: compiled, ISA-checked and emulated only until a GPU runs this
+    test).  The two forms move requests, not arithmetic: bit-identical results.  Reference: /root/reference/include/U.h:123-202."""
+    res = {}
+    for name, env in (('defaults', dict(HQ_GEMM_PIPE='0', HQ_BIG_TWOBASE='0')), ('operand_ahead', dict(HQ_GEMM_PIPE='1', HQ_BIG_TWOBASE='1'))):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'wide_gpu_worker.py')], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        for case, v in res[name].items():
+            assert v['err_vs_oracle'] <= v['tol'], (name, case, v)
+            assert v['literal_bar_met'] or ('complex64' in case and int(case.split('k=')[1].split()[0]) >= 7), (name, case, v)
+    assert res['defaults'].keys() == res['operand_ahead'].keys() and len(res['defaults']) >= 22
+    assert not any('twobase=1' in v['kernel'] for v in res['defaults'].values())
+    assert any('twobase=1' in v['kernel'] for v in res['operand_ahead'].values()) and any('twobase=0' in v['kernel'] for v in res['defaults'].values())
+    for case, v in res['defaults'].items():
+        assert v['sha'] == res['operand_ahead'][case]['sha'], case
+    with capsys.disabled():
+        worst = max(res['operand_ahead'].items(), key=lambda kv: kv[1]['err_vs_oracle'] / kv[1]['tol'])
+        print(f"\n  {len(res['defaults'])} cases x 2 loop forms against the {worst[1]['oracle']} oracle, bit-identical between the forms; worst: {worst[0]} {worst[1]['err_vs_oracle']:.2e}")

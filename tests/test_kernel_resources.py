@@ -10,11 +10,15 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-#: kernels allowed to spill, with the measured consequence.  Empty since round 5: the 52 B/lane of the complex128 k = 6
-#: role kernel (apply_mfma_big_kernel<double, 7, 0, ...>, whitelisted in rounds 2-4) were LDS ADDRESSES -- its 128 KiB operand
-#: table lies beyond the 16-bit offset of a ds_read, and the compiler kept one address register per read of the upper half
-#: alive across both column blocks; a second base address 64 KiB up removed them (hq_kernels_apply.h: Aop).
-ALLOWED_SCRATCH = {}
+#: kernels allowed to spill, with the measured consequence.  The one entry is the complex128 k = 6 role kernel in the form
+#: that HARDWARE has run (rounds 2-3; TWOB = false, the default until a GPU run has seen the other one): 32 loaded vectors +
+#: 8 f64 accumulator blocks + per-read LDS address registers for the upper half of its 128 KiB operand table, which the
+#: compiler keeps alive across both column blocks = 13 dwords of scratch (4.69 ms at n = 29 = 59 TFLOP/s = 75 % of the f64
+#: peak, round 3).  Its round-5 form (TWOB = true: a second base address 64 KiB up, hq_kernels_apply.h: Aop; HQ_BIG_TWOBASE=1)
+#: has no scratch and must stay so -- it is not on this list.
+ALLOWED_SCRATCH = {
+    r'apply_mfma_big_kernel<double, 7, 0, (true|false), 512, (true|false), false>': 64,
+}
 
 
 @pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')

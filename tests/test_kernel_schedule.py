@@ -64,9 +64,9 @@ def test_the_old_loops_are_still_what_pipe_off_selects(kernels):
     assert mfma >= 100 and _awaited_reads(body) / mfma >= 0.10
 
 
-@pytest.mark.parametrize('name,min_mfma', [('apply_mfma_big_kernel<double, 7, 0, true, 512, true>', 512),
-                                           ('apply_mfma_big_kernel<double, 7, 1, true, 512, true>', 256),
-                                           ('apply_mfma_big_kernel<float, 7, 0, true, 512, true>', 512)])
+@pytest.mark.parametrize('name,min_mfma', [('apply_mfma_big_kernel<double, 7, 0, true, 512, true, true>', 512),
+                                           ('apply_mfma_big_kernel<double, 7, 1, true, 512, true, true>', 256),
+                                           ('apply_mfma_big_kernel<float, 7, 0, true, 512, true, true>', 512)])
 def test_role_kernel_operand_reads_are_base_plus_immediate(kernels, name, min_mfma):
     """k = 6 role kernels: every operand read of the MFMA phase is `ds_read_b128 dst, base offset:imm` on one of at most two
     base registers (tables above 64 KiB: a second base 64 KiB up), one pair-group ahead of its MFMAs (lgkmcnt(2) / (3),

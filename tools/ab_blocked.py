@@ -20,9 +20,14 @@ tb = int(sys.argv[3]) if len(sys.argv) > 3 else (13 if ctype == 'complex64' else
 gates = rqc_1q2q(n, depth=40, seed=n)
 # blocked passes run from torch's allocator (as simulate() and bench.py's blocked leg do: ~7 % faster than the tuned VMM placement)
 state = EvolutionState(list(range(n)), complex_type=ctype, initial_state='0' * n, placement=os.environ.get('HQ_AB_PLACEMENT', 'plain'))
-as_json = len(sys.argv) > 4 and sys.argv[4] == 'json'  # bench.py's blocked_variants leg: the planner's own fusion only, one JSON line
-for kw in ((dict(),) if as_json else (dict(), dict(inner_max=0))):
-    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=int(os.environ.get('HQ_AB_LOW_BITS', 5 if ctype == 'complex64' else 4)), complex_type=ctype), **kw})
+mode = sys.argv[4] if len(sys.argv) > 4 else ''
+as_json = mode in ('json', 'json_full')  # bench.py: one JSON line ('json': the planner's own fusion only; 'json_full': the `blocked` leg -- planner statistics and the no-fusion schedule as well)
+low_bits = int(os.environ.get('HQ_AB_LOW_BITS', 5 if ctype == 'complex64' else 4))
+report = {}
+for kw in ((dict(),) if mode == 'json' else (dict(), dict(inner_max=0))):
+    t_p = time.perf_counter()
+    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=low_bits, complex_type=ctype), **kw})
+    t_plan = time.perf_counter() - t_p
     packed = [('B', op[1], core.pack_blocked(op[2], ctype)) if op[0] == 'B' else op for op in ops]
 
     def run():
@@ -34,23 +39,30 @@ for kw in ((dict(),) if as_json else (dict(), dict(inner_max=0))):
     run()
     torch.cuda.synchronize()
     ts = []
-    for _ in range(3):
+    for _ in range(3 if not kw or not as_json else 1):
         t0 = time.perf_counter()
         run()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     st = blocked_stats(ops)
+    if as_json and kw:  # the same blocked schedule WITHOUT algebraic fusion: every original gate on its own inside the LDS tiles
+        report['no_fusion'] = {'blocked_passes': st['blocked_passes'], 'plain_gates': st['plain_gates'], 'inner_gates': st['inner_gates'], 'ms_per_step': round(ts[0], 3)}
+        continue
     if as_json:
-        import json
         n_direct = 0
         for op in packed:  # how many passes took the direct first gate (the library reports the last launch)
             if op[0] == 'B':
                 core.apply_blocked(state.planes[0], state.planes[1], op[1], packed=op[2], n_qubits=n)
                 n_direct += core.last_kernel_desc().endswith('direct')
         torch.cuda.synchronize()
-        print(json.dumps({'tile_bits': tb, 'low_bits': int(os.environ.get('HQ_AB_LOW_BITS', 5 if ctype == 'complex64' else 4)), 'passes': st['blocked_passes'], 'plain_gates': st['plain_gates'], 'inner_gates': st['inner_gates'],
-                          'direct_passes': n_direct, 'kernel': core.last_kernel_desc().split(' tb=')[0], 'ms_per_step': [round(t, 3) for t in ts],
-                          'selfcheck': core.blocked_selfcheck()}), flush=True)
+        report.update({'tile_bits': tb, 'low_bits': low_bits, 'passes': st['blocked_passes'], 'plain_gates': st['plain_gates'], 'inner_gates': st['inner_gates'],
+                       'direct_passes': n_direct, 'kernel': core.last_kernel_desc().split(' tb=')[0], 'ms_per_step': [round(t, 3) for t in ts],
+                       'plan_seconds': round(t_plan, 3), 'selfcheck': core.blocked_selfcheck()})
+        if mode == 'json_full':
+            report['stats'] = dict(st, inner_k_histogram={str(k): v for k, v in st['inner_k_histogram'].items()})
         continue
     print(os.path.basename(os.environ.get('HQ_HIP_LIBRARY', 'in-tree')), f'tb={tb}', core.last_kernel_desc().split('>')[0].split('<')[-1], kw, f"passes {st['blocked_passes']} + {st['plain_gates']} plain, inner {st['inner_gates']}:",
           ' '.join('%.1f' % t for t in ts), 'ms', flush=True)
+if as_json:
+    import json
+    print(json.dumps(report), flush=True)
