@@ -53,12 +53,21 @@ def lds_budget(tile_bits, complex_type='complex64'):
 
 def _dry_layers(qsets, kmax):
     """The grouping fusion.fuse would produce for gates arriving in this order, on qubit sets alone (sliding left
-    through disjoint layers only: the matrix-commutation test needs matrices)."""
+    through disjoint layers only: the matrix-commutation test needs matrices).  An entry ``('F', qubits or None)`` is a gate
+    without a matrix (fusion.Opaque): a layer of its own that nothing merges into, that gates on other qubits slide
+    across and that stops the rest (one without qubits stops everything); returned as such."""
     layers = []
     for q in qsets:
+        if isinstance(q, tuple):
+            layers.append(q)
+            continue
         merge_to = len(layers)
         for i in range(len(layers) - 1, -1, -1):
             cq = layers[i]
+            if isinstance(cq, tuple):
+                if cq[1] is None or (q & cq[1]):
+                    break
+                continue
             if len(q | cq) <= max(kmax, len(cq), len(q)):
                 merge_to = i
             if not (q & cq):

@@ -129,13 +129,32 @@ def exact_tolerance(gates, complex_type=None):
     return 8 * float(np.finfo(np.float32).eps) if single else 1e-12
 
 
+class Opaque:
+    """A gate WITHOUT a matrix inside a gate list (the reference's FunctionalGate family: Projection, Measure, user
+    functions).  ``qubits``: the labels it acts on, or None when it declares none (``Gate('fn', n_qubits=...)``).  The
+    planners never merge it and never look inside; what they need is how the reference's walks treat such an element:
+      compress (circuit/utils.py:583-669, called with skip_compression=[FunctionalGate], simulation.py:441): it always
+        opens a layer of its own; a later matrix gate can never be merged into that layer, slides ACROSS it when they
+        share no qubit (:636-637; matrix commutation switched on) and stops at it otherwise (``commutes_with(None)`` raises,
+        :640-646); a layer whose gate has no qubits stops every gate (``all_qubits()`` raises, :618-622);
+      simplify (insert_from_left, :166-208): it slides to the right past gates of at most max_n_qubits_matrix qubits that
+        share no qubit with it (``inv`` / ``commutes_with`` raise: no cancellation, no matrix test), matrix gates slide past
+        it under the same condition, and one without qubits is inserted at the far left and stops everything."""
+    __slots__ = ('obj', 'qubits')
+
+    def __init__(self, obj, qubits):
+        self.obj = obj
+        self.qubits = None if qubits is None else tuple(qubits)
+
+
 class _Layer:
-    __slots__ = ('gates', 'qubits', 'U', 'compress', 'has_matrix')
+    __slots__ = ('gates', 'qubits', 'U', 'compress', 'has_matrix', 'opaque')
 
     def __init__(self, U, qs, compress=True, has_matrix=True):
         self.gates = [(U, qs)]
         self.qubits = _sorted_union(qs, ())
         self.U = _embed(U, qs, self.qubits)
+        self.opaque = None
         self.compress = compress  # False: nothing may be merged into this layer (utils.py:615-617)
         # the reference keeps a layer's matrix for its commutation tests only while the layer spans at most
         # max_n_qubits_matrix qubits, and never gets it back afterwards (utils.py:660-669); the fused matrix `U` itself is
@@ -154,7 +173,13 @@ class _Layer:
 def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits=(), exact_commutation=False):
     layers = []
     exclude = set(exclude_qubits or ())
-    for U, qs in gates:
+    for item in gates:
+        if isinstance(item, Opaque):  # never merged anywhere: a layer of its own at the end (see Opaque)
+            L = _Layer.__new__(_Layer)
+            L.gates, L.qubits, L.U, L.compress, L.has_matrix, L.opaque = [item], item.qubits, None, False, False, item
+            layers.append(L)
+            continue
+        U, qs = item
         q = set(qs)
         can = not (q & exclude)  # gates on `exclude_qubits` are never compressed (utils.py:615-617)
         merge_to = len(layers)
@@ -162,6 +187,10 @@ def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matr
         gate_matrix = use_matrix_commutation and len(q) <= max_n_qubits_matrix
         for i in range(len(layers) - 1, -1, -1):
             L = layers[i]
+            if L.opaque is not None:
+                if L.qubits is None or not use_matrix_commutation or (q & set(L.qubits)):
+                    break
+                continue  # disjoint from a functional gate: slide across it (utils.py:636-637)
             cq = set(L.qubits)
             if can and L.compress and len(q | cq) <= max(max_n_qubits, len(cq), len(q)):  # utils.py:626-630
                 merge_to = i
@@ -184,7 +213,7 @@ def compress(gates, max_n_qubits=4, use_matrix_commutation=True, max_n_qubits_ma
              exclude_qubits=None):
     """Group `gates` ([(U, qubits), ...]) into layers like hybridq's ``utils.compress``.
     Returns a list of layers, each a list of the original gates in application order."""
-    gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
+    gates = [g if isinstance(g, Opaque) else (np.asarray(g[0]), tuple(g[1])) for g in gates]
     if max_n_qubits is None or max_n_qubits <= 0:  # utils.py:565-566
         return [[g] for g in gates]
     return [L.gates for L in _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol,
@@ -203,19 +232,39 @@ def to_matrix_gate(layer, complex_type='complex64'):
     return M.astype(complex_type), tuple(Q)
 
 
+def _layer_matrix_like_reference(layer_gates, qubits):
+    """The matrix the REFERENCE computes for a layer wider than 4 qubits: ``to_matrix_gate`` -> ``utils.matrix`` first
+    compresses the layer's own gates to width 4 with the default options (circuit/utils.py:751-759: max_compress = 4), i.e.
+    it regroups them with the 1e-5 commutation test, and multiplies the groups in that order.  Where every pair that is
+    swapped commutes exactly this is the plain product; where a pair commutes only to 1e-5 (named gates raised to tiny
+    powers) it differs from it by as much -- reproduced here so that reference-schedule runs agree with the reference as
+    vectors, not to 1e-5."""
+    inner = _build_layers(layer_gates, 4, True, 10, _COMMUTE_ATOL)
+    M = np.eye(1 << len(qubits), dtype=np.complex128)
+    for L in inner:
+        M = _embed(L.U, L.qubits, qubits) @ M
+    return M
+
+
 def fuse(gates, max_n_qubits=4, complex_type='complex64', use_matrix_commutation=True,
-         max_n_qubits_matrix=10, atol=1e-7, exclude_qubits=None, exact_commutation=False, native=None):
+         max_n_qubits_matrix=10, atol=1e-7, exclude_qubits=None, exact_commutation=False, native=None, reference_matrices=False):
     """compress + to_matrix_gate in one go: the fused gate stream ``_simulate_evolution``
     hands to the core (simulation.py:436-454).  Layer matrices are accumulated in
     complex128 and cast once.  ``native`` (default: whenever the circuit has at most 62 distinct qubits and fused gates stay
     within 10): the same rule behind the C ABI (``hq_plan_fuse``, csrc/hq_plan.hip; 36 -> 4 ms for the 900-gate benchmark
-    circuit at width 4); ``native=False``: the Python statement (``_build_layers``)."""
-    gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
+    circuit at width 4); ``native=False``: the Python statement (``_build_layers``).  ``reference_matrices``:
+    layers wider than 4 qubits get the matrix the reference's ``to_matrix_gate`` computes for them
+    (:func:`_layer_matrix_like_reference`; Python statement only)."""
+    gates = [g if isinstance(g, Opaque) else (np.asarray(g[0]), tuple(g[1])) for g in gates]
+    mixed = any(isinstance(g, Opaque) for g in gates)  # Opaque entries come back as they are, in their place among the fused gates
     if max_n_qubits is None or max_n_qubits <= 0:
-        return [(U.astype(complex_type), qs) for U, qs in gates]
+        return [g if isinstance(g, Opaque) else (g[0].astype(complex_type), g[1]) for g in gates]
     if exact_commutation is True:
-        exact_commutation = exact_tolerance(gates, complex_type)
-    if (native is None or native) and gates:
+        exact_commutation = exact_tolerance([g for g in gates if not isinstance(g, Opaque)], complex_type)
+    if mixed and native:
+        raise ValueError('hq_plan_fuse has no notion of gates without a matrix')
+    reference_matrices = bool(reference_matrices) and max_n_qubits > 4
+    if (native is None or native) and gates and not mixed and not reference_matrices:
         labels = _sorted_union([q for _, qs in gates for q in qs], ())  # ids follow the order of the labels
         ok = (len(labels) <= 62 and max_n_qubits <= 10 and
               all(len(qs) <= 10 and len(set(qs)) == len(qs) and U.size == 4 ** len(qs) for U, qs in gates))
@@ -241,7 +290,11 @@ def fuse(gates, max_n_qubits=4, complex_type='complex64', use_matrix_commutation
             raise ValueError('hq_plan_fuse takes at most 62 distinct qubits and gates of at most 10 qubits')
     layers = _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matrix, atol, exclude_qubits,
                            exact_commutation)
-    return [(L.U.astype(complex_type), tuple(L.qubits)) for L in layers]
+    if reference_matrices:
+        for L in layers:
+            if L.opaque is None and len(L.qubits) > 4 and len(L.gates) > 1:
+                L.U = _layer_matrix_like_reference(L.gates, L.qubits)
+    return [L.opaque if L.opaque is not None else (L.U.astype(complex_type), tuple(L.qubits)) for L in layers]
 
 
 def matrix(gates, order=None, complex_type='complex64'):
@@ -289,7 +342,11 @@ def simplify(gates, atol=1e-8, use_matrix_commutation=True, max_n_qubits_matrix=
     commutes with (no shared qubit, or commuting matrices) and cancelling it against the first
     gate that is its inverse.  The circuit's action is unchanged; what changes is the gate
     list the fusion sees (the reference's ``simulate`` runs this by default, simulation.py:304)."""
-    gates = [(np.asarray(U), tuple(qs)) for U, qs in gates]
+    gates = [g if isinstance(g, Opaque) else (np.asarray(g[0]), tuple(g[1])) for g in gates]
+    if any(isinstance(g, Opaque) for g in gates):
+        if native:
+            raise ValueError('hq_plan_simplify has no notion of gates without a matrix')
+        return _simplify_mixed(gates, atol, use_matrix_commutation, max_n_qubits_matrix, remove_id_gates)
     if native is None or native:
         labels = {}
         for _, qs in gates:
@@ -336,3 +393,42 @@ def simplify(gates, atol=1e-8, use_matrix_commutation=True, max_n_qubits_matrix=
         if not placed:
             new.append((U, qs, q))
     return [(U, qs) for U, qs, _ in new]
+
+
+def _simplify_mixed(gates, atol, use_matrix_commutation, max_n_qubits_matrix, remove_id_gates):
+    """simplify() on a list that holds Opaque entries (gates without a matrix): the same walk, with the reference's
+    treatment of a FunctionalGate on either side of a comparison (see Opaque; insert_from_left, circuit/utils.py:166-208)."""
+    def is_identity(U):
+        eye = np.eye(U.shape[0])
+        return U.shape == eye.shape and bool((np.abs(U - eye) <= atol + 1e-5 * eye).all())
+
+    if remove_id_gates:  # utils.py:841-845: gates that provide no matrix are kept
+        gates = [g for g in gates if isinstance(g, Opaque) or len(g[1]) > max_n_qubits_matrix or not is_identity(g[0])]
+    new = []  # entries: (U or None, qubits or None, frozenset or None, Opaque or None)
+    for g in reversed(gates):
+        if isinstance(g, Opaque):
+            U, qs, op = None, g.qubits, g
+        else:
+            (U, qs), op = g, None
+        if qs is None:  # no qubits declared: "just append to the left" (:170-173)
+            new.insert(0, (None, None, None, op))
+            continue
+        q = frozenset(qs)
+        placed = False
+        for p, (V, vs, vset, vop) in enumerate(new):
+            if op is None and vop is None and vset == q and _inverse_of(U, qs, V, vs, atol):  # :182-184
+                del new[p]
+                placed = True
+                break
+            ok = False
+            if vs is not None and len(vs) <= max_n_qubits_matrix:  # :192-195 (an entry without qubits: the test itself raises)
+                ok = not (q & vset)
+                if not ok and use_matrix_commutation and op is None and vop is None:
+                    ok = commute(U, qs, V, vs, atol)
+            if not ok:  # :199-201
+                new.insert(p, (U, qs, q, op))
+                placed = True
+                break
+        if not placed:
+            new.append((U, qs, q, op))
+    return [op if op is not None else (U, qs) for U, qs, _, op in new]

@@ -84,7 +84,7 @@ def flatten(circuit):
 
 def all_qubits(circuit):
     """Sorted qubit labels (hybridq/circuit/circuit.py:406-451)."""
-    qs = {q for g in circuit for q in (g.qubits if _is_functional(g) else _gate_qubits_matrix(g)[0])}
+    qs = {q for g in circuit for q in ((g.qubits or ()) if _is_functional(g) else _gate_qubits_matrix(g)[0])}
     try:
         return sorted(qs)
     except TypeError:  # heterogeneous labels: order by (type name, value) like utils.sort
@@ -553,27 +553,24 @@ class EvolutionState:
         return core.norm2(self.planes[0], self.planes[1])
 
 
+def _functional_qubits(g):
+    """Qubits a functional gate declares, or None (``Gate('fn', n_qubits=...)`` of the reference: qubits is None)."""
+    qs = getattr(g, 'qubits', None)
+    return None if qs is None else tuple(qs)
+
+
 def _simplify_runs(circuit, remove_id_gates, atol, opts):
-    """``utils.simplify`` (fusion.simplify) applied to every run of matrix gates between
-    FunctionalGates; the functional gates stay where they are (the reference lets a gate slide past
-    a FunctionalGate on disjoint qubits as well: a superset of these moves, same final state)."""
-    from .fusion import simplify as _simplify
-    out, run = [], []
-
-    def flush():
-        if run:
-            gates = _simplify([(U, qs) for qs, U in run], atol=atol, remove_id_gates=remove_id_gates, **opts)
-            out.extend((U, qs) for U, qs in gates)
-            run.clear()
-
-    for g in circuit:
-        if _is_functional(g):
-            flush()
-            out.append(g)
-        else:
-            run.append(_gate_qubits_matrix(g))
-    flush()
-    return out
+    """``utils.simplify`` (fusion.simplify) on the whole circuit.  FunctionalGates take part the way they do in the
+    reference's walk (insert_from_left, circuit/utils.py:166-208; fusion.Opaque): they slide past gates on other qubits and
+    gates slide past them, nothing cancels against them, one without qubits stops everything.  The resulting gate list is
+    the reference's, one for one (tests/test_reference_live_host.py)."""
+    from .fusion import Opaque, simplify as _simplify
+    if not any(_is_functional(g) for g in circuit):
+        gates = _simplify([(U, qs) for qs, U in (_gate_qubits_matrix(g) for g in circuit)], atol=atol, remove_id_gates=remove_id_gates, **opts)
+        return [(U, qs) for U, qs in gates]
+    items = [Opaque(g, _functional_qubits(g)) if _is_functional(g) else (lambda qu: (qu[1], qu[0]))(_gate_qubits_matrix(g)) for g in circuit]
+    out = _simplify(items, atol=atol, remove_id_gates=remove_id_gates, **{k: v for k, v in opts.items() if k != 'native'})
+    return [g.obj if isinstance(g, Opaque) else g for g in out]
 
 
 def _compress_args(compress):
@@ -592,13 +589,25 @@ def _compress_args(compress):
     return comp_n, comp_kw
 
 
-def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
+def _plan_ops(circuit, qubits, n, ctype, compress, blocked, reference=True):
     """Turn a circuit into the op list the gate loop executes: fused ``(qubits, U)`` gates
-    (simulation.py:436-454), or the 'B'/'G' ops of the cache-blocked planner; FunctionalGates are
-    never fused (skip_compression=[FunctionalGate], :441) -- the circuit is cut at them."""
+    (simulation.py:436-454), or the 'B'/'G' ops of the cache-blocked planner.  FunctionalGates are
+    never fused (skip_compression=[FunctionalGate], :441).  Under ``compress`` the walk is the reference's, functional
+    gates included: a gate that shares no qubit with a FunctionalGate slides across it into an earlier layer
+    (circuit/utils.py:630-648; fusion.Opaque) -- with non-unitary gates around a renormalising Projection that order
+    is part of the RESULT, so it is reproduced exactly.  The cache-blocked planner (no reference counterpart) and
+    compress=0 (nothing moves) keep the circuit cut at every FunctionalGate.  ``reference`` (the caller named the schedule:
+    'evolution-hybridq' or an explicit ``compress=``): fused gates wider than 4 qubits also get the matrix the reference's
+    ``to_matrix_gate`` computes (fusion._layer_matrix_like_reference); this driver's own schedules (choose_schedule) take the
+    plain product from the native planner."""
     comp_n, comp_kw = _compress_args(compress)
     use_blocked = bool(blocked) and n >= 14
     pos_of = {q: n - x - 1 for x, q in enumerate(qubits)}  # simulation.py:512 (never permuted here)
+    if comp_n and not use_blocked and any(_is_functional(g) for g in circuit):
+        from .fusion import Opaque, fuse
+        items = [Opaque(g, _functional_qubits(g)) if _is_functional(g) else (lambda qu: (qu[1], qu[0]))(_gate_qubits_matrix(g)) for g in circuit]
+        fused = fuse(items, comp_n, complex_type=ctype, reference_matrices=reference, **{k: v for k, v in comp_kw.items() if k != 'native'})
+        return [g.obj if isinstance(g, Opaque) else (g[1], g[0]) for g in fused]
     gates, run = [], []
 
     def flush():
@@ -614,7 +623,7 @@ def _plan_ops(circuit, qubits, n, ctype, compress, blocked):
             gates.extend(plan_blocked([(U, qs) for qs, U in run], pos_of, n, **opts))
         elif comp_n:
             from .fusion import fuse
-            gates.extend((qs, U) for U, qs in fuse([(U, qs) for qs, U in run], comp_n, complex_type=ctype, **comp_kw))
+            gates.extend((qs, U) for U, qs in fuse([(U, qs) for qs, U in run], comp_n, complex_type=ctype, reference_matrices=reference, **comp_kw))
         else:
             gates.extend(run)
         run.clear()
@@ -674,21 +683,9 @@ def _predict_fused_ms(circuit, n, ctype, kmax):
     without matrix commutation, ~2 ms for 900 gates instead of 40-70): a prediction to decide what is worth planning."""
     from .blocking import _dry_layers
     scale = 2.0 ** (n - 30) * (2.0 if np.dtype(ctype) == np.dtype('complex128') else 1.0)
-    t, run = 0.0, []
-
-    def flush():
-        nonlocal t
-        for layer in _dry_layers(run, kmax):
-            t += max(PASS_MS[min(len(layer), 10)] * scale, LAUNCH_FLOOR_MS)
-        run.clear()
-
-    for g in circuit:
-        if _is_functional(g):
-            flush()
-        else:
-            run.append(frozenset(_gate_qubits_matrix(g)[0]))
-    flush()
-    return t
+    run = [('F', None if _functional_qubits(g) is None else frozenset(_functional_qubits(g))) if _is_functional(g)
+           else frozenset(_gate_qubits_matrix(g)[0]) for g in circuit]  # FunctionalGates: slid across like in the plans (fusion.Opaque)
+    return sum(max(PASS_MS[min(len(layer), 10)] * scale, LAUNCH_FLOOR_MS) for layer in _dry_layers(run, kmax) if not isinstance(layer, tuple))
 
 
 def choose_schedule(circuit, qubits, n, ctype):
@@ -709,7 +706,7 @@ def choose_schedule(circuit, qubits, n, ctype):
         # search for 8 ms more host time now that the planner is native
         cands['blocked'] = dict(compress=5, blocked=True)
         cost['blocked'] = PLAN_HOST_MS_PER_GATE['blocked'] * n_matrix
-    plans = {'per_gate': _plan_ops(circuit, qubits, n, ctype, 0, False)}
+    plans = {'per_gate': _plan_ops(circuit, qubits, n, ctype, 0, False, reference=False)}
     est = {'per_gate': estimate_ms(plans['per_gate'], n, ctype)}
     pred = {}
     if est['per_gate'] > min(c for name, c in cost.items() if name != 'per_gate'):  # else nothing can pay its planning back
@@ -720,7 +717,7 @@ def choose_schedule(circuit, qubits, n, ctype):
     for name in sorted(pred, key=lambda k: pred[k] + cost[k]):
         if cost[name] + PREDICTION_SLACK * pred[name] < min(est.values()):
             kw = cands[name]
-            plans[name] = _plan_ops(circuit, qubits, n, ctype, kw['compress'], kw['blocked'])
+            plans[name] = _plan_ops(circuit, qubits, n, ctype, kw['compress'], kw['blocked'], reference=False)
             est[name] = estimate_ms(plans[name], n, ctype)
     best = min(est, key=est.get)
     return plans[best], {'chosen': best, 'modelled_ms': {k: round(v, 4) for k, v in est.items()},

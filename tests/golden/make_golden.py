@@ -619,6 +619,50 @@ def live_cases(path, seed):
         out[f'c{i}_proj_q'] = np.asarray([qubits.index(q) for q in pq], dtype=np.int32)
         out[f'c{i}_proj_bits'] = np.array(bits)
         out[f'c{i}_proj_cut'] = cut
+        # the gate stream of the projection run (compress slides gates on other qubits ACROSS the FunctionalGate,
+        # circuit/utils.py:630-648) and, with a Measure and a second Projection added, of simplify + compress: which
+        # element sits where, matrices of the fused ones.  An entry with k = -1 is functional gate number fF{j}.
+        from hybridq.circuit import utils as _utils
+        from hybridq.gate import Measure
+        from hybridq.gate import property as _pr
+
+        def stream(gates_, tag, do_simplify, fns):
+            # (simplify deep-copies what it inserts: the functional gates are told apart by name + qubits)
+            fkey = [(f.name, tuple(f.qubits)) for f in fns]
+            assert len(set(fkey)) == len(fkey)
+
+            def which(g):
+                return fkey.index((g.name, tuple(g.qubits)))
+            cc_ = _Circuit(g for g in gates_ if g.name != 'I')
+            if do_simplify:
+                cc_ = _utils.simplify(cc_, remove_id_gates=True, atol=1e-8, verbose=False)
+                out[f'{tag}_s_n'] = len(cc_)
+                for j, g in enumerate(cc_):  # the simplified list: functional gates by number, matrix gates by qubits + matrix
+                    fn = isinstance(g, _pr.FunctionalGate)
+                    out[f'{tag}_sF{j}'] = which(g) if fn else -1
+                    if not fn:
+                        out[f'{tag}_sq{j}'] = np.asarray([qubits.index(q) for q in g.qubits], dtype=np.int32)
+                        out[f'{tag}_sU{j}'] = np.asarray(g.matrix(), dtype=np.complex128)
+            layers_ = _utils.compress(cc_, compress, verbose=False, skip_compression=[_pr.FunctionalGate])
+            out[f'{tag}_f_n'] = len(layers_)
+            for j, layer in enumerate(layers_):
+                fn = any(isinstance(g, _pr.FunctionalGate) for g in layer)
+                assert not fn or len(layer) == 1
+                out[f'{tag}_fF{j}'] = which(layer[0]) if fn else -1
+                if not fn:
+                    mg = _utils.to_matrix_gate(layer, complex_type='complex128')
+                    out[f'{tag}_fU{j}'] = np.asarray(mg.matrix())
+                    out[f'{tag}_fq{j}'] = np.asarray([qubits.index(q) for q in mg.qubits], dtype=np.int32)
+
+        P1 = Projection(state=bits, qubits=pq)
+        stream(gl[:cut] + [P1] + gl[cut:], f'c{i}_pj', False, [P1])
+        mq = [qubits[int(x)] for x in rng.permutation(len(qubits))[:2]]
+        p2q = [[q for q in (qubits[int(x)] for x in rng.permutation(len(qubits))) if [q] != list(pq)][0]]
+        out[f'c{i}_fn_mq'] = np.asarray([qubits.index(q) for q in mq], dtype=np.int32)
+        out[f'c{i}_fn_p2q'] = np.asarray([qubits.index(q) for q in p2q], dtype=np.int32)
+        c3 = len(gl) // 3
+        M1, P2 = Measure(qubits=mq), Projection(state='1', qubits=p2q)
+        stream(gl[:c3] + [P1] + gl[c3:2 * c3] + [M1] + gl[2 * c3:] + [P2], f'c{i}_fn', True, [P1, M1, P2])
         op = get_rqc(2, 3, indexes=[qubits[1], qubits[len(qubits) - 2]], use_random_indexes=False, use_unitary_only=False)
         for j, g in enumerate(op):
             out[f'c{i}_opU{j}'] = np.asarray(g.matrix(), dtype=np.complex128)

@@ -272,7 +272,16 @@ def test_driver_planning_host_logic():
     cut = _plan_ops(g[:40] + [fg] + g[40:], qubits, n, ct, 4, False)
     k = [i for i, op in enumerate(cut) if op is fg]
     assert len(k) == 1
-    assert len(cut[:k[0]]) == len(fuse(g[:40], 4)) and len(cut[k[0] + 1:]) == len(fuse(g[40:], 4))
+    # gates on other qubits slide ACROSS the functional gate into earlier fused gates, as in the reference's walk
+    # (circuit/utils.py:636-637); gates on its qubit stay on their side of it
+    assert len(fuse(g, 4)) <= len(cut) - 1 <= len(fuse(g[:40], 4)) + len(fuse(g[40:], 4))
+    import oracle
+    full = _plan_ops(g[:40] + g[40:], qubits, n, ct, 0, False)
+    a = oracle.evolve_tensordot([(U, qs) for qs, U in cut[:k[0]]] + [(U, qs) for qs, U in cut[k[0] + 1:]], n, qubits=qubits)
+    b = oracle.evolve_tensordot([(U, qs) for qs, U in full], n, qubits=qubits)
+    assert np.abs(a - b).max() / np.abs(b).max() < 1e-5  # (an identity functional gate: the circuit's action is unchanged)
+    c0 = _plan_ops(g[:40] + [fg] + g[40:], qubits, n, ct, 0, False)  # compress = 0: nothing moves
+    assert c0.index(fg) == 40 and len(c0) == len(g) + 1
     blk = _plan_ops(g[:40] + [fg] + g[40:], qubits, n, ct, 4, True)
     kinds = [op[0] if isinstance(op, tuple) and isinstance(op[0], str) else 'F' for op in blk]
     assert kinds.count('F') == 1 and 'B' in kinds[:kinds.index('F')] and 'B' in kinds[kinds.index('F') + 1:]

@@ -141,22 +141,26 @@ def test_simulation_2__tuple(torch_cuda, seed):
 @pytest.mark.parametrize('seed', range(2))
 def test_simulation_2__message(torch_cuda, seed):
     """tests.py:1980-2034: a MessageGate (FunctionalGate on no qubits) after every gate neither changes the state nor
-    joins a fused gate, and every message is printed, in circuit order."""
+    joins a fused gate, and every message is printed exactly once."""
     from hybridq_amd.circuits import random_dense
     from hybridq_amd.simulation import _is_functional, _plan_ops, simulate
     n_qubits, depth = 12, 200
     file = io.StringIO()
     circuit = random_dense(n_qubits, depth, kmax=2, seed=200 + seed)
     circuit_msg = [x for i, g in enumerate(circuit) for x in (g, MessageGate(f'{i}', file))]
-    # compression: the MessageGates stay isolated, and what lies between two of them is the gate itself
+    # compression: the MessageGates stay isolated (never part of a fused gate), and -- acting on no qubit -- let every gate
+    # slide across them exactly as the reference's walk does (circuit/utils.py:636-637): the matrix gates fuse as if the
+    # messages were not there
+    from hybridq_amd.fusion import fuse
     ops = _plan_ops(circuit_msg, list(range(n_qubits)), n_qubits, np.dtype('complex64'), 4, False)
-    assert sum(1 for o in ops if _is_functional(o)) == depth and len(ops) == 2 * depth
+    assert sum(1 for o in ops if _is_functional(o)) == depth and len(ops) == depth + len(fuse(circuit, 4))
     psi = simulate(circuit, initial_state='0', qubits=list(range(n_qubits)), compress=0, simplify=False)
     psi_msg = simulate(circuit_msg, initial_state='0', qubits=list(range(n_qubits)))
-    assert_allclose(psi, psi_msg)
-    assert np.array_equal(psi, psi_msg)
+    assert_allclose(psi, psi_msg)  # (the gates now fuse across the messages: equal to rounding, as upstream asserts)
     file.seek(0)
-    assert [int(x.strip()) for x in file.readlines()] == list(range(depth))
+    # every message exactly once; like the reference's, the simplify pass leaves the zero-qubit gates in another order
+    # (they commute with everything) -- tests.py:2030-2034 sorts before comparing, and so does this
+    assert sorted(int(x.strip()) for x in file.readlines()) == list(range(depth))
 
 
 def test_simulation_2__stochastic(torch_cuda):
@@ -271,10 +275,10 @@ def test_container_gates_against_the_reference_itself(torch_cuda):
     psi = simulate(msg, initial_state=init, complex_type='complex128', qubits=q).reshape(-1)
     assert np.abs(psi - z['msg_psi']).max() / np.abs(z['msg_psi']).max() < 1e-12
     file.seek(0)
-    # every message exactly once; the reference prints them in the order its simplify / compress passes left the zero-qubit
-    # gates in (they commute with everything: 79, 78, ... here), this driver in circuit order -- tests.py:2030-2034 sorts too
+    # every message exactly once, in the order the REFERENCE printed them: its simplify pass slides the zero-qubit gates past
+    # everything (they commute with everything: 79, 78, ... here), and this driver's walk is the same (fusion.Opaque)
     ours = [int(x.strip()) for x in file.readlines()]
-    assert ours == list(range(len(gs))) and sorted(int(x) for x in z['msg_lines']) == ours
+    assert ours == [int(x) for x in z['msg_lines']] and sorted(ours) == list(range(len(gs)))
 
 
 def test_prepare_state_api(torch_cuda):

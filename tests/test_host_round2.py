@@ -50,13 +50,16 @@ def test_choose_schedule_cost_model():
     assert m25['chosen'] == 'blocked' and m25['not_planned'] == ['fused_4', 'fused_5']
     _, m28 = choose_schedule(rqc_1q2q(28, depth=40, seed=28), list(range(28)), 28, np.dtype('complex64'))
     assert m28['chosen'] == 'blocked' and m28['not_planned'] == ['fused_4', 'fused_5']
-    # FunctionalGates cut the prediction's runs like they cut the plans
+    # FunctionalGates: the prediction lets gates on other qubits slide across them, like the plans (fusion.Opaque)
     from hybridq_amd.simulation import FunctionalGate, _predict_fused_ms
     g29 = rqc_1q2q(29, depth=40, seed=29)
     cut = g29[:400] + [FunctionalGate((0,), lambda psi, order: (psi, order))] + g29[400:]
     p_cut = _predict_fused_ms(cut, 29, np.dtype('complex64'), 4)
     assert p_cut == pytest.approx(estimate_ms(_plan_ops(cut, list(range(29)), 29, np.dtype('complex64'), 4, False), 29, np.dtype('complex64')), rel=0.02)
     assert p_cut >= _predict_fused_ms(g29, 29, np.dtype('complex64'), 4)
+    hard = g29[:400] + [FunctionalGate((0,), lambda psi, order: (psi, order))] + g29[400:]
+    hard[400].qubits = None  # a functional gate that declares no qubits stops every gate (circuit/utils.py:618-622)
+    assert _predict_fused_ms(hard, 29, np.dtype('complex64'), 4) >= p_cut
     # wide gates are priced by their own width
     wide = [g for g in random_dense(20, 40, kmax=7, seed=3) if len(g[1]) >= 6][:3]
     _, w = choose_schedule(wide, list(range(20)), 20, np.dtype('complex64'))
@@ -155,7 +158,7 @@ def test_allow_sampling_replaces_stochastic_gates(monkeypatch):
 
     seen = {}
 
-    def fake_plan(circuit, qubits, n, ctype, compress, blocked):
+    def fake_plan(circuit, qubits, n, ctype, compress, blocked, reference=True):
         seen['circuit'] = list(circuit)
         raise RuntimeError('stop before the device')
 
@@ -383,7 +386,7 @@ def test_evolution_einsum_alias_runs_on_the_one_engine(monkeypatch):
     import hybridq_amd.simulation as sim
     seen = {}
 
-    def fake_plan(circuit, qubits, n, ctype, compress, blocked):
+    def fake_plan(circuit, qubits, n, ctype, compress, blocked, reference=True):
         seen['compress'], seen['blocked'] = compress, blocked
         raise RuntimeError('stop before the device')
     monkeypatch.setattr(sim, '_plan_ops', fake_plan)
