@@ -577,6 +577,10 @@ class HipBackend:
         if self.transport in ('rccl', 'none'):
             self.core.exchange_round_wait(r)
 
+    def exchange_in_real_rounds(self):
+        """True where exchange_rounds really moves the shard in several rounds the gate stream can work behind (RCCL)."""
+        return self.transport == 'rccl'
+
     def fill_zero(self, planes):
         planes.zero_()
 
@@ -628,11 +632,15 @@ class ShardedEvolution:
                  group=None, overlap=None):
         """``overlap``: overlap every qubit exchange with the local gates that do not touch the moving bits
         (:func:`overlap_exchanges`; default: the environment variable HQ_SHARD_OVERLAP, off -- the round-trip on xGMI has
-        not been measured yet).  Overlapped exchanges travel as torch.distributed send / recv
-        rounds (RCCL on the device) instead of through hq_exchange_*."""
+        not been measured yet).  Overlapped exchanges run behind the C ABI (hq_exchange_rounds_*) on
+        HipBackend, as torch.distributed send / recv rounds on minimal backends.  ``True`` takes effect only where the
+        exchange really proceeds in rounds (HipBackend on the RCCL transport, minimal backends): on a transport that
+        completes in one blocking round (peer-to-peer stores, the torch fallback) attaching gates to an exchange would only
+        split them into per-piece launches, so the plan keeps plain exchanges there; ``'force'`` attaches them regardless
+        (tests of the one-round executor path)."""
         import os
         import torch.distributed as dist
-        self.overlap = (os.environ.get('HQ_SHARD_OVERLAP', '0') == '1') if overlap is None else bool(overlap)
+        self.overlap = (os.environ.get('HQ_SHARD_OVERLAP', '0') == '1') if overlap is None else (overlap if overlap == 'force' else bool(overlap))
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -710,7 +718,7 @@ class ShardedEvolution:
                 sched.append(op)
         self._planned_final_pos = final_pos
         sched = fuse_evictions(sched)
-        if self.overlap:
+        if self.overlap == 'force' or (self.overlap and getattr(self.backend, 'exchange_in_real_rounds', lambda: True)()):
             sched = overlap_exchanges(sched, self.m, self.g, itemsize=self.float_type.itemsize)
         if blocked and self.m >= 14:
             from .blocking import plan_blocked

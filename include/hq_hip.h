@@ -20,21 +20,24 @@
  * reports), HQ_APPLY_MODE / HQ_NONTEMPORAL (initial hq_set_apply_mode values),
  * HQ_PROGRAM_MB (table buffer of a recorded program, default 64),
  * HQ_PROGRAM_GRAPH (0: replay programs as a launch loop instead of a hipGraph);
- * measurement switches: HQ_GEMM_TB (tile bits of the k >= 7 kernel),
- * HQ_BLOCKED_ALDS (0: operand and address tables of
- * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_PIPE /
- * HQ_GEMM_PIPE (0: the inner-gate / K loops of rounds 1-4a: operands requested where
- * the compiler puts them instead of ahead of the matrix cores), HQ_BLOCKED_GROUPS
- * (0: a workgroup barrier after every inner gate), HQ_BLOCKED_SELFCHECK (how many of
- * the first blocked passes of a process are cross-checked against the round-2
- * kernels, default 3; hq_blocked_selfcheck), HQ_BLOCKED_DIRECT (1: tile
- * movement of a blocked pass folded into its first gate), HQ_BLOCKED_BIG (1: 128 KiB
- * tiles run on one 1024-thread workgroup per CU), HQ_BLOCKED_GRID (cap,
- * a power of two, on the resident workgroups of a blocked pass), HQ_BLOCKED_PREF,
- * HQ_GEMM_PREF, HQ_SWAP_PREF (0: no register prefetch of the next tile in the
- * cache-blocked / k >= 7 / low-bit-swap kernels), HQ_BIG_PHASED, HQ_BIG_GRID (k = 5, 6
- * kernel), HQ_SWAP_TWO_PASS (0: one 128 KiB-tile pass or gather + copy for s > 13),
- * HQ_VMM_FREE_VA (1: hq_free also releases the virtual range).
+ * measurement switches: HQ_GEMM_TB (tile bits of the k >= 7 kernel), HQ_BLOCKED_ALDS (0: operand and address tables of
+ * blocked passes stay in global memory / are computed per gate), HQ_BLOCKED_GRID (cap, a power of two, on the resident
+ * workgroups of a blocked pass), HQ_BLOCKED_PREF, HQ_GEMM_PREF, HQ_SWAP_PREF (0: no register prefetch of the next tile in
+ * the cache-blocked / k >= 7 / low-bit-swap kernels), HQ_BIG_PHASED, HQ_BIG_GRID (k = 5, 6 kernel), HQ_SWAP_TWO_PASS (0: one
+ * 128 KiB-tile pass or gather + copy for s > 13), HQ_VMM_FREE_VA (1: hq_free also releases the virtual range).
+ *
+ * OPT-IN kernel variants (all default 0 = the code the driver's GPU tests have run; each is a template parameter of the
+ * same build, exercised against the oracle in every setting by tests/test_gpu_round4.py and timed by bench.py's
+ * `blocked_variants` leg, so that one hardware run decides them):
+ *   HQ_BLOCKED_PIPE=1    cache-blocked inner gates: LDS operands requested one wave-iteration ahead of the matrix cores
+ *   HQ_BLOCKED_GROUPS=1  cache-blocked passes: barrier-free wave groups instead of a workgroup barrier after every inner gate
+ *   HQ_BLOCKED_DIRECT=1  tile movement of a blocked pass folded into its first gate (implies HQ_BLOCKED_PIPE=1)
+ *   HQ_BLOCKED_BIG=1     128 KiB tiles on one 1024-thread workgroup per CU (implies HQ_BLOCKED_PIPE=1)
+ *   HQ_GEMM_PIPE=1       k >= 7 tile GEMM: operands requested ahead of the matrix cores in the K loop
+ *   HQ_BIG_TWOBASE=1     complex128 k = 6 role kernel: second LDS base address (no scratch) + operand pipeline
+ * HQ_BLOCKED_SELFCHECK (default 3): how many of the first blocked passes of a process THAT RUN ONE OF THE OPT-IN
+ * VARIANTS are cross-checked against the default kernels on a scratch state (hq_blocked_selfcheck); a default run never
+ * checks anything, and a check that cannot run (no memory, stream under capture) is skipped, never an error.
  */
 #ifndef HQ_HIP_H
 #define HQ_HIP_H
@@ -307,11 +310,13 @@ int hq_apply_blocked_float64(double *psi_re, double *psi_im, unsigned int n_qubi
                              const unsigned int *tile_pos, unsigned int tile_bits, unsigned int n_gates,
                              const double *U_all, const unsigned int *pos_all, const unsigned int *k_all);
 
-/* The cache-blocked kernel variants written in rounds 3-4 (pipelined inner gates, barrier-free wave groups, direct first
- * gate, 1024-thread tiles) are cross-checked on the device against the per-gate-barrier kernels of round 2 for the first
- * HQ_BLOCKED_SELFCHECK (default 3) passes of a process; a variant whose result differs by one bit is switched off for the
- * process with a warning on stderr.  *runs / *failures: checks done / failed so far; *switches: bit 0 pipelined gates,
- * bit 1 barrier-free groups, bit 2 direct first gate, bit 3 1024-thread tiles currently ON.  Any pointer may be NULL. */
+/* The OPT-IN cache-blocked kernel variants (pipelined inner gates, barrier-free wave groups, direct first gate, 1024-thread
+ * tiles; environment section above) are cross-checked on the device against the default kernels for the first
+ * HQ_BLOCKED_SELFCHECK (default 3) passes of a process whose launch really selects one of them; a variant whose result
+ * differs by more than a few units in the last place is switched off for the process with a warning on stderr.  A parity
+ * check, not a race detector; a check that cannot run is skipped (one note on stderr), it never fails the caller's apply.
+ * *runs / *failures: checks done / failed so far; *switches: bit 0 pipelined gates, bit 1 barrier-free groups, bit 2
+ * direct first gate, bit 3 1024-thread tiles currently ON (all 0 on a default run).  Any pointer may be NULL. */
 int hq_blocked_selfcheck(int *runs, int *failures, int *switches);
 
 /* Compiled circuits.  Between hq_program_begin() and hq_program_end() every DEVICE-pointer call

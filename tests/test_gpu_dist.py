@@ -88,7 +88,7 @@ def _worker(rank, world, port, n, ct, out_dir):
         # GPU: one round)
         import hybridq_amd.dist as dist_mod
         dist_mod.OVERLAP_MIN_SUB_QUBITS = 8
-        sho = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, overlap=True)
+        sho = ShardedEvolution(n, complex_type=ct, initial_state='0' * n, overlap='force')  # (one-round transports: the executor path all the same)
         scho = sho.plan(gates)
         n_xo = sum(1 for op in scho if op[0] == 'XO')
         sho.run(scho)
@@ -119,10 +119,10 @@ def test_sharded_hip_backend_two_ranks_one_gpu(torch_cuda, tmp_path, world, n, c
     expb = oracle.evolve_tensordot(rqc_1q2q(n + 2, depth=8, seed=13), n + 2)
     assert np.abs(out['psib'] - expb).max() / np.abs(expb).max() < 5 * tol
     assert int(out['nb']) >= 1  # blocked passes were really used
-    if True:  # overlapped exchanges (the pieces may dispatch to other kernels than the whole shard: equal to rounding)
-        assert int(out['n_xo']) >= 1
-        assert np.abs(out['psi_o'] - exp).max() / np.abs(exp).max() < tol, np.abs(out['psi_o'] - exp).max() / np.abs(exp).max()
-        assert np.abs(out['psi_o'] - out['psi']).max() / np.abs(exp).max() < tol
+    # overlapped exchanges (the pieces may dispatch to other kernels than the whole shard: equal to rounding)
+    assert int(out['n_xo']) >= 1
+    assert np.abs(out['psi_o'] - exp).max() / np.abs(exp).max() < tol, np.abs(out['psi_o'] - exp).max() / np.abs(exp).max()
+    assert np.abs(out['psi_o'] - out['psi']).max() / np.abs(exp).max() < tol
 
 
 def _rounds_worker(rank, world, port, out_dir):
