@@ -3,7 +3,7 @@ cache-blocked kernel with / without pipelined inner gates and barrier-free wave 
 apply_blocked_direct_kernel (HQ_BLOCKED_DIRECT=1, the tile movement folded into the first gate of a pass -- k <= 4 first
 gates) and the 1024-thread kernels for 128 KiB tiles (HQ_BLOCKED_BIG=1).  Every worker also reports the library's own
 bit-for-bit cross-check of these variants against the round-2 kernels (hq_blocked_selfcheck): it must have run and found
-nothing.  Timings: tools/r5_first.sh, bench.py's blocked_variants."""
+nothing.  Timings: tools/r6_second.sh, bench.py's blocked_variants."""
 import json
 import os
 import subprocess
