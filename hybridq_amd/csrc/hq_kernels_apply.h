@@ -309,7 +309,9 @@ apply_mfma_big_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restric
   constexpr int kHalf = 65536 / 16;  // vectors
   constexpr bool kTableAbove64K = (size_t)NRB * NG * 64 > (size_t)kHalf;
   constexpr bool kTwoBases = kTableAbove64K && TWOB;
-  constexpr bool kOperandPipe = !kTableAbove64K || TWOB;  // (the round-2 form of complex128 k = 6 has no registers for a second operand pair)
+  // (TWOB = false is the code of rounds 2-4 to the letter: there only complex128 k = 6 WITHOUT a component target -- 32 loaded
+  // vectors -- had no registers for a second operand pair; with one (VMASK = 1, 16 vectors) it pipelined its operands already)
+  constexpr bool kOperandPipe = TWOB || !(sizeof(T) == 8 && NL == 32);
   typedef __attribute__((address_space(3))) const V LdsCV;
   const unsigned al_lo = (unsigned)reinterpret_cast<uintptr_t>(Al);  // LDS byte address of this lane's slot of row 0
   unsigned al_hi = al_lo + (kTwoBases ? 65536u : 0u);
