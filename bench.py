@@ -587,6 +587,9 @@ def main():
                     'frac': bytes_per_gate / (avg_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 'avg_launch_ms': avg_p, 'launches': len(per_p[dom_p]),
                     'gate_applications': len(sample), 'all_kernels_frac': bytes_per_gate / (float(np.mean([t for v in per_p.values() for t in v])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     'note': 'the first gate applications of the same circuit on a state from torch.empty (no placement search), HIP events per call'}
+                if 'roofline' in result:  # the two placements side by side in the one object every reader of the line keeps
+                    result['roofline']['plain_placement_frac'] = result['roofline_plain_placement']['frac']
+                    result['roofline']['plain_placement_achieved'] = result['roofline_plain_placement']['achieved']
                 del pstate
                 torch.cuda.empty_cache()
             else:
@@ -992,6 +995,35 @@ def main():
         # so each runs in its own process): whoever runs this line on hardware gets the A/B with it.  Last: the longest leg.
         result['blocked_variants'] = blocked_variants(n, args.dtype, time_left)
     result['extras'] = {'budget_seconds': args.extras_seconds, 'used_seconds': time.perf_counter() - t_extras, 'skipped_for_budget': skipped}
+    if rank == 0:
+        # the figures a reader of the LAST two kilobytes of the output should find (records keep the tail of stdout)
+        try:
+            summ = {'gate_apps_per_s': result['gate_apps_per_s'], 'roofline_frac': result.get('roofline', {}).get('frac'),
+                    'roofline_frac_plain_placement': result.get('roofline_plain_placement', {}).get('frac'),
+                    'cpu_baseline_gate_apps_per_s': (result.get('cpu_baseline') or {}).get('gate_apps_per_s'),
+                    'cpu_baseline_cores': (result.get('cpu_baseline') or {}).get('cores')}
+            for key in ('fused', 'fused_k5', 'blocked'):
+                if key in result:
+                    summ[key + '_ms_per_step'] = result[key].get('ms_per_step')
+            if 'blocked' in result:
+                summ['blocked_kernel'] = result['blocked'].get('kernel')
+            if 'blocked_variants' in result:
+                summ['blocked_variants_ms_per_step'] = {k: (float(np.median(v['ms_per_step'])) if 'ms_per_step' in v else v.get('error', v.get('skipped')))
+                                                        for k, v in result['blocked_variants'].items()}
+                summ['blocked_variants_selfcheck_failures'] = sum(v.get('selfcheck', {}).get('failures', 0) for v in result['blocked_variants'].values() if isinstance(v, dict))
+            pc = result.get('parity_check')
+            if isinstance(pc, dict) and 'pass' in pc:
+                summ['parity_check'] = {k: pc.get(k) for k in ('n_qubits', 'gate_applications', 'cpu_kind', 'pass', 'literal_bar_met', 'literal_bar_depth', 'literal_bar_depth_of',
+                                                                'max_rel_diff_per_gate', 'max_rel_diff_fused_k4', 'max_rel_diff_blocked', 'reference_cpu_f32_vs_f64',
+                                                                'gpu_f32_per_gate_vs_f64', 'tolerance_two_evolutions', 'bar')}
+            for key in ('cfg4_dense_k34', 'cfg5_noisy_dm'):
+                if key in result:
+                    summ[key] = {'gate_apps_per_s': result[key].get('gate_apps_per_s'), 'roofline_frac': result[key].get('roofline', {}).get('frac'),
+                                 'kernel': result[key].get('roofline', {}).get('kernel'), 'parity_small_n_pass': (result[key].get('parity_small_n') or {}).get('pass')}
+            summ['errors'] = sorted(k for k in result if k.endswith('_error'))
+            result['summary'] = summ
+        except Exception as e:  # noqa: BLE001
+            result['summary'] = {'error': repr(e)}
     emit(final=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -89,6 +89,10 @@ def test_bench_line_end_to_end_against_the_emulated_library():
     assert set(bv) == {'pipe', 'groups', 'pipe_groups', 'direct', 'direct_groups', 'big_tiles', 'big_tiles_direct', 'low_bits_minus_1'} and not [k for k, v in bv.items() if 'error' in v], bv
     assert all(len(v['ms_per_step']) == 3 and v['passes'] >= 1 and v['selfcheck']['failures'] == 0 for v in bv.values()), bv
     assert bv['pipe']['selfcheck']['runs'] >= 1 and bv['pipe']['kernel'].endswith('pipe=1') and bv['direct']['selfcheck']['pipe'] is True  # (direct implies the pipelined gates)
+    # the LAST key of the complete line is a compact summary (records keep the tail of stdout): headline, both placements, the
+    # cache-blocked step and every variant, the parity verdict
+    assert list(line)[-2:] == ['summary', 'line'] and line['summary']['errors'] == [] and line['summary']['parity_check']['pass'] is True
+    assert set(line['summary']['blocked_variants_ms_per_step']) == set(bv) and line['summary']['roofline_frac_plain_placement'] == line['roofline']['plain_placement_frac']
     pc = line['parity_check']
     assert pc['pass'] is True and pc['literal_bar_depth'] == pc['literal_bar_depth_of'] and len(pc['prefixes']) >= 8
     assert 'l2_rel_diff_per_gate' in pc and 'reference_vs_f64_leaves_bar_after' in pc
