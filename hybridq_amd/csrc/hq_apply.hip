@@ -502,14 +502,15 @@ static int launch_gemm_rc(Context& c, T* re, T* im, const T* dA, const unsigned*
   // K loop of rounds 1-3, the one hardware has run (defaults = what hardware has verified)
   static const int use_pipe = env_int("HQ_GEMM_PIPE", 0);
   constexpr bool kCanPipe = gemm_can_pipe<T, RBW, CBW>();
-  static bool attr_done = false;  // under the context mutex
-  if (!attr_done) {
-    const void* fns[] = {(const void*)apply_gemm_kernel<T, RBW, CBW, 0, false>, (const void*)apply_gemm_kernel<T, RBW, CBW, 0, kCanPipe>,
-                         (const void*)apply_gemm_kernel<T, RBW, CBW, NPVx, false>, (const void*)apply_gemm_kernel<T, RBW, CBW, NPVx, kCanPipe>};
-    for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  const bool pipe = use_pipe && kCanPipe;
+  static bool attr_done = false;  // under the context mutex (one flag per instantiation of this function; `pipe` is fixed per process)
+  if (!attr_done) {  // only the instantiations this process can launch: a default run does not touch the opt-in ones
+    const void* f0 = pipe ? (const void*)apply_gemm_kernel<T, RBW, CBW, 0, kCanPipe> : (const void*)apply_gemm_kernel<T, RBW, CBW, 0, false>;
+    const void* f1 = pipe ? (const void*)apply_gemm_kernel<T, RBW, CBW, NPVx, kCanPipe> : (const void*)apply_gemm_kernel<T, RBW, CBW, NPVx, false>;
+    HQ_HIP_CHECK(hipFuncSetAttribute(f0, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HQ_HIP_CHECK(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_done = true;
   }
-  const bool pipe = use_pipe && kCanPipe;
   if constexpr (NPVx > 0) {
     if (use_pref && ((1u << (a.tb - CBv)) == (unsigned)NPVx * kGemmBlock)) {
       if (pipe) HQ_LAUNCH(c, (apply_gemm_kernel<T, RBW, CBW, NPVx, kCanPipe>), dim3(grid), dim3(kGemmBlock), lds, re, im, dA, dOff, a, ntiles);
@@ -850,19 +851,25 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
   const uint64_t ntiles = 1ull << (n - tb);
   const size_t tile_bytes = ((size_t)2 << tb) * sizeof(T);
   const size_t per_cu = std::min<size_t>(std::max<size_t>(1, (160 * 1024) / tile_bytes), 4);
-  static bool attr_done = false;
+  // LDS limits: the default family (the instantiations a default run can launch) once per process; the opt-in
+  // instantiations only in a process that opted in -- a default run does not depend on anything about them
+  static bool attr_done = false, variant_attr_done = false;  // under the context mutex
   if (!attr_done) {
     const void* fns[] = {(const void*)apply_blocked_kernel<float, 512, false, false, false>, (const void*)apply_blocked_kernel<double, 512, false, false, false>,
-                         (const void*)apply_blocked_kernel<float, 512, true, false, true>, (const void*)apply_blocked_kernel<double, 512, true, false, true>,
                          (const void*)apply_blocked_kernel<float, 512, true, false, false>, (const void*)apply_blocked_kernel<double, 512, true, false, false>,
-                         (const void*)apply_blocked_kernel<float, 512, true, true, true>, (const void*)apply_blocked_kernel<double, 512, true, true, true>,
                          (const void*)apply_blocked_kernel<float, 512, true, true, false>, (const void*)apply_blocked_kernel<double, 512, true, true, false>,
-                         (const void*)apply_blocked_kernel<float, 512, false, true, false>,
+                         (const void*)apply_blocked_kernel<float, 512, false, true, false>};
+    for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  if (!variant_attr_done && (sw.pipe || sw.direct || sw.big)) {
+    const void* fns[] = {(const void*)apply_blocked_kernel<float, 512, true, false, true>, (const void*)apply_blocked_kernel<double, 512, true, false, true>,
+                         (const void*)apply_blocked_kernel<float, 512, true, true, true>, (const void*)apply_blocked_kernel<double, 512, true, true, true>,
                          (const void*)apply_blocked_direct_kernel<float, 512>, (const void*)apply_blocked_direct_kernel<double, 512>,
                          (const void*)apply_blocked_kernel<float, 1024, true, true, true>, (const void*)apply_blocked_kernel<double, 1024, true, true, true>,
                          (const void*)apply_blocked_direct_kernel<float, 1024>, (const void*)apply_blocked_direct_kernel<double, 1024>};
     for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    variant_attr_done = true;
   }
   unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * per_cu);
   if (sw.grid_cap > 0 && (sw.grid_cap & (sw.grid_cap - 1)) == 0) grid = std::min<unsigned>(grid, (unsigned)sw.grid_cap);
