@@ -32,6 +32,8 @@ What is recorded
   e2e_containers.npz  TupleGate / StochasticGate (allow_sampling, sampling_seed) / zero-qubit MessageGate circuits through
                       the reference's simulate() (python make_golden.py containers).
   e2e_matrix.npz      utils.matrix / compress / to_matrix_gate on small circuits (python make_golden.py matrix).
+  e2e_fn_streams.npz  circuits with Projection / Measure gates through the reference's simplify / compress / simulate: order of the
+                      resulting gate lists, matrices as probe products, projection-run states (python make_golden.py fn_streams).
 The import of the reference Python needs stand-ins for three absent third-party modules
 (opt_einsum, more_itertools, numba); none of them is on the evolution-hybridq path except
 numba.vectorize for '+-' initial states.
@@ -687,6 +689,54 @@ def live_cases(path, seed):
     np.savez_compressed(path, **out)
 
 
+def fn_stream_fixture():
+    """python make_golden.py fn_streams: tests/golden/e2e_fn_streams.npz -- circuits with FunctionalGates (a Projection in the
+    middle; a Projection, a Measure and a closing Projection) through the REFERENCE's simulate / simplify / compress, recorded
+    by live_cases() and reduced to what travels: the input gates, the functional gates' qubits, the order of the resulting gate
+    lists, and every resulting matrix as its product with a fixed probe vector (tests/fn_stream_checks.py: probe) -- 2^k numbers
+    instead of 4^k -- plus the final state of the projection run for the smaller cases.  Cases: seed 4 (a width-6 layer whose
+    gates commute only to 1e-5: to_matrix_gate's inner regrouping shows) and seed 5 (non-unitary gates around the projection)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from fn_stream_checks import probe
+    out = {}
+    n_out = 0
+    for seed in (4, 5):
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, 'live.npz')
+            live_cases(path, seed)
+            z = np.load(path, allow_pickle=False)
+            # per seed: the (up to three) compress = 6 cases -- fused gates wider than 4 are where to_matrix_gate regroups -- and
+            # one case at width 2 or 4
+            cand = [i for i in range(int(z['n_cases'])) if f'c{i}_pj_f_n' in z.files and f'c{i}_proj_psi' in z.files]
+            wide = [i for i in cand if int(z[f'c{i}_compress']) == 6][:3]
+            narrow = [i for i in cand if int(z[f'c{i}_compress']) in (2, 4)][:1]
+            picked = 0
+            for i in sorted(wide + narrow):
+                pre, dst = f'c{i}_', f'c{n_out}_'
+                for key in ('n', 'n_gates', 'names', 'unitary', 'init', 'compress', 'proj_q', 'proj_bits', 'proj_cut', 'fn_mq', 'fn_p2q'):
+                    out[dst + key] = z[pre + key]
+                for j in range(int(z[pre + 'n_gates'])):
+                    out[f'{dst}U{j}'], out[f'{dst}q{j}'] = z[f'{pre}U{j}'], z[f'{pre}q{j}']
+                if int(z[pre + 'n']) <= 12:
+                    out[dst + 'proj_psi'] = z[pre + 'proj_psi']
+                for stag, kind in (('pj', 'f'), ('fn', 's'), ('fn', 'f')):
+                    cnt = int(z[f'{pre}{stag}_{kind}_n'])
+                    out[f'{dst}{stag}_{kind}_n'] = cnt
+                    for j in range(cnt):
+                        out[f'{dst}{stag}_{kind}F{j}'] = z[f'{pre}{stag}_{kind}F{j}']
+                        if int(z[f'{pre}{stag}_{kind}F{j}']) < 0:
+                            U = z[f'{pre}{stag}_{kind}U{j}']
+                            out[f'{dst}{stag}_{kind}q{j}'] = z[f'{pre}{stag}_{kind}q{j}']
+                            out[f'{dst}{stag}_{kind}Uv{j}'] = U @ probe(U.shape[0])
+                out[dst + 'seed'] = seed
+                n_out += 1
+                picked += 1
+    out['n_cases'] = n_out
+    np.savez_compressed(os.path.join(HERE, 'e2e_fn_streams.npz'), **out)
+    print('functional-gate stream fixture written:', n_out, 'cases')
+
+
 def live_dm_cases(path, seed):
     """python make_golden.py live_dm OUT.npz SEED: random noisy circuits (depolarizing / dephasing / amplitude-damping noise
     from hybridq.noise.utils) through the reference's dm simulate(), as data like dm_circuit() records them."""
@@ -919,6 +969,9 @@ if __name__ == '__main__':
         raise SystemExit(0)
     if len(sys.argv) > 3 and sys.argv[1] == 'live':
         live_cases(sys.argv[2], int(sys.argv[3]))
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'fn_streams':
+        fn_stream_fixture()
         raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'containers':
         container_vectors()

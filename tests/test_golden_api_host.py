@@ -14,6 +14,6 @@ import test_gpu_golden as golden  # noqa: E402
 
 
 @pytest.mark.parametrize('name', ['test_dm_front_end', 'test_api_simulate_mixed_initial_state', 'test_api_projection_and_measure',
-                                  'test_api_expectation_value'])
+                                  'test_api_expectation_value', 'test_functional_gate_streams_against_the_reference_record'])
 def test_reference_recorded_outputs_on_the_double(numpy_device, name):
     getattr(golden, name)(None)

@@ -253,3 +253,22 @@ def test_c_abi_demo_without_python(torch_cuda, tmp_path):
     out = subprocess.run([exe, core._LIB_PATH], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.stdout, out.stderr)
     assert 'wrong_amplitudes=0' in out.stdout
+
+
+def test_functional_gate_streams_against_the_reference_record(torch_cuda):
+    """Circuits with FunctionalGates in reference-schedule mode against what the REFERENCE did with them
+    (tests/golden/e2e_fn_streams.npz, recorded by `make_golden.py fn_streams` from its simplify / compress / simulate,
+    circuit/utils.py:166-208, 583-669, 751-759; simulation.py:436-454): the order of the simplified and of the fused gate lists
+    with a Projection, a Measure and a closing Projection in them (which element sits where, qubits, matrices via probe
+    products), and the final state of the run with a Projection in the middle AS A VECTOR -- non-unitary gates around the
+    renormalising projection included, where the order in which gates slide across it is part of the result."""
+    from fn_stream_checks import check_functional_case
+    from hybridq_amd.simulation import simulate
+    z = gu.load('e2e_fn_streams.npz')
+    assert int(z['n_cases']) >= 6
+    seen = []
+    for i in range(int(z['n_cases'])):
+        seen += check_functional_case(z, i, simulate, tag='fixture')
+    assert seen.count('streams') == int(z['n_cases']) and seen.count('state') >= 4
+    assert any(int(z[f'c{i}_compress']) == 6 and not bool(z[f'c{i}_unitary']) for i in range(int(z['n_cases'])))
+

@@ -55,64 +55,10 @@ def test_random_circuits_and_options_against_the_reference(numpy_device, tmp_pat
             assert np.abs(np.asarray(U) - fU).max() <= (1e-12 if ctype == 'complex128' else 1e-6) * max(1.0, np.abs(fU).max()), (seed, i, j)
         ref = z[f'c{i}_psi']
         assert psi.dtype == ref.dtype and psi.shape == (2,) * n
-        # a Projection (device-side functional gate here, host numpy code there) in the middle of the circuit
-        if f'c{i}_proj_psi' in z.files:
-            from hybridq_amd.functional import Projection
-            cut = int(z[f'c{i}_proj_cut'])
-            P = Projection(str(z[f'c{i}_proj_bits']), [int(q) for q in z[f'c{i}_proj_q']])
-            # (Gate('I') is stripped by NAME before anything else in the reference, simulation.py:289-291; (U, qubits) pairs carry
-            # no names, so the caller drops them here -- left in, they would take part in the compression walk)
-            keep_ = [j for j, name in enumerate(z[f'c{i}_names']) if str(name) != 'I']
-            before = [gates[j] for j in keep_ if j < cut]
-            after = [gates[j] for j in keep_ if j >= cut]
-            pp = simulate(before + [P] + after, initial_state=str(z[f'c{i}_init']), optimize='evolution-hybridq',
-                          complex_type='complex128', compress=int(z[f'c{i}_compress']), simplify=False, qubits=list(range(n)))
-            pref, pp = z[f'c{i}_proj_psi'], pp.reshape(-1)
-            if not pref.any():  # nothing survived the projection (projection.py:58-66): all zeros on both sides
-                assert not pp.any(), (seed, i, 'projection onto nothing')
-                continue_projection = False
-            else:
-                continue_projection = True
-            # compared as VECTORS, non-unitary circuits included: the reference's compression slides gates on other qubits
-            # across the (renormalising) projection, which changes the norm at the moment of renormalisation; this driver
-            # reproduces that walk (fusion.Opaque; circuit/utils.py:630-648), so the states agree, not merely the rays
-            if continue_projection:
-                assert np.abs(pp - pref).max() / np.abs(pref).max() < 1e-10, (seed, i, 'projection', bool(z[f'c{i}_unitary']))
-        # the gate streams with FunctionalGates in them, one for one: compress with a Projection in the middle, and
-        # simplify + compress with a Projection, a Measure and a closing Projection (element order, qubits, matrices)
-        if f'c{i}_pj_f_n' in z.files:
-            from hybridq_amd.functional import Measure, Projection
-            cut = int(z[f'c{i}_proj_cut'])
-            P1 = Projection(str(z[f'c{i}_proj_bits']), [int(q) for q in z[f'c{i}_proj_q']])
-            c3 = len(gates) // 3
-            fns = [P1, Measure([int(q) for q in z[f'c{i}_fn_mq']]), Projection('1', [int(q) for q in z[f'c{i}_fn_p2q']])]
-            comp = int(z[f'c{i}_compress'])
-
-            def check_stream(ops, tag, kind):
-                assert len(ops) == int(z[f'{tag}_{kind}_n']), (seed, i, tag, kind, len(ops), int(z[f'{tag}_{kind}_n']))
-                for j, op in enumerate(ops):
-                    want = int(z[f'{tag}_{kind}F{j}'])
-                    if want >= 0:
-                        assert op is fns[want], (seed, i, tag, kind, j)
-                        continue
-                    qs, U = op if kind == 'f' else (op[1], op[0])
-                    fq, fU = tuple(int(q) for q in z[f'{tag}_{kind}q{j}']), z[f'{tag}_{kind}U{j}']
-                    if tuple(qs) != fq:  # unfused gates keep the order they were given in; the reference sorts (to_matrix_gate)
-                        assert kind == 's' or comp == 0, (seed, i, tag, kind, j)
-                        assert sorted(qs) == sorted(fq), (seed, i, tag, kind, j)
-                        U = _embed(U, qs, list(fq))
-                    assert np.abs(np.asarray(U) - fU).max() <= 1e-12 * max(1.0, np.abs(fU).max()), (seed, i, tag, kind, j)
-
-            g128 = [(np.asarray(U, dtype=np.complex128), qs) for U, qs in gates]
-            named128 = [g for g, name in zip(g128, z[f'c{i}_names']) if str(name) != 'I']
-            keep = [j for j, name in enumerate(z[f'c{i}_names']) if str(name) != 'I']
-            n_before = lambda c: sum(1 for j in keep if j < c)  # noqa: E731 -- position of a cut in the list without the named identities
-            with_p = named128[:n_before(cut)] + [fns[0]] + named128[n_before(cut):]
-            check_stream(_plan_ops(with_p, list(range(n)), n, np.dtype('complex128'), comp, False), f'c{i}_pj', 'f')
-            with_all = (named128[:n_before(c3)] + [fns[0]] + named128[n_before(c3):n_before(2 * c3)] + [fns[1]] + named128[n_before(2 * c3):] + [fns[2]])
-            simp = _simplify_runs(with_all, True, 1e-8, {})
-            check_stream(simp, f'c{i}_fn', 's')
-            check_stream(_plan_ops(simp, list(range(n)), n, np.dtype('complex128'), comp, False), f'c{i}_fn', 'f')
+        # a Projection (device-side functional gate here, host numpy code there) in the middle of the circuit, as a vector; the gate
+        # streams with FunctionalGates in them one for one (tests/fn_stream_checks.py, shared with the golden-fixture test)
+        from fn_stream_checks import check_functional_case
+        assert 'streams' in check_functional_case(z, i, simulate, tag=f'live seed {seed}')
         # <psi| op |psi> of the reference's final state
         from hybridq_amd.simulation import expectation_value
         op = [(z[f'c{i}_opU{j}'], tuple(int(q) for q in z[f'c{i}_opq{j}'])) for j in range(int(z[f'c{i}_op_n']))]
