@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libhq_hip.so')
 UNITS = ['hq_core', 'hq_apply', 'hq_swap', 'hq_shard', 'hq_state', 'hq_plan']
 SOURCES = [os.path.join(CSRC, u + '.hip') for u in UNITS]
-HEADERS = [os.path.join(CSRC, 'libhq_hip.map')] + [os.path.join(CSRC, h) for h in ('hq_common.h', 'hq_kernels_common.h', 'hq_kernels_apply.h', 'hq_kernels_blocked.h', 'hq_kernels_gemm.h', 'hq_kernels_swap.h',
+HEADERS = [os.path.join(CSRC, 'libhq_hip.map')] + [os.path.join(CSRC, h) for h in ('hq_common.h', 'hq_kernels_common.h', 'hq_kernels_apply.h', 'hq_kernels_blocked.h', 'hq_kernels_blocked_r3.h', 'hq_kernels_gemm.h', 'hq_kernels_swap.h',
                                            'hq_kernels_aux.h', 'hq_bitperm.h')] + [os.path.join(HERE, '..', 'include', 'hq_hip.h')]
 ARCH = '--offload-arch=gfx950'
 # -fvisibility=hidden: the dynamic symbol table is what include/hq_hip.h declares (its visibility pragma) and nothing else

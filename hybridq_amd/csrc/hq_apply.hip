@@ -5,6 +5,7 @@
 #include "hq_common.h"
 #include "hq_kernels_apply.h"
 #include "hq_kernels_blocked.h"
+#include "hq_kernels_blocked_r3.h"
 #include "hq_kernels_gemm.h"
 
 namespace hq {
@@ -814,6 +815,9 @@ struct BlockedSwitches {
   int groups;     // barrier-free wave groups
   int pipe;       // LDS requests one wave-iteration ahead of the matrix cores, table words one gate ahead
   int selfcheck;  // how many of the first passes of the process are cross-checked (0: none)
+  int r3;         // 1 (default): a pass that uses none of the opt-in variants is launched on the kernels of hq_kernels_blocked_r3.h
+                  // -- the binaries of the last commit that ran on hardware; 0: on the PIPE = false instantiations of
+                  // hq_kernels_blocked.h (the code the variants are built on; what the self-check compares against)
 };
 static BlockedSwitches& blocked_switches() {
   // (the direct first gate and the 1024-thread tiles exist with the pipelined inner gates only: asking for one of them
@@ -822,7 +826,7 @@ static BlockedSwitches& blocked_switches() {
                               env_int("HQ_BLOCKED_ALDS", 1),   env_int("HQ_BLOCKED_PREF", 1), env_int("HQ_BLOCKED_BIG", 0),
                               env_int("HQ_BLOCKED_DIRECT", 0), env_int("HQ_BLOCKED_GROUPS", 0),
                               env_int("HQ_BLOCKED_PIPE", (env_int("HQ_BLOCKED_DIRECT", 0) || env_int("HQ_BLOCKED_BIG", 0)) ? 1 : 0),
-                              env_int("HQ_BLOCKED_SELFCHECK", 3)};
+                              env_int("HQ_BLOCKED_SELFCHECK", 3), env_int("HQ_BLOCKED_R3", 1)};
   return s;
 }
 static int g_selfcheck_runs = 0, g_selfcheck_failures = 0;  // under the context mutex
@@ -968,6 +972,44 @@ static int blocked_launch(Context& c, T* re, T* im, const unsigned n, BlockedPas
   const BlockedGate* const pG = (const BlockedGate*)dG;
   const T* const pA = (const T*)dA;
   const unsigned a_elems = (unsigned)Atab.size();
+  // A pass that uses none of the opt-in variants: the kernels of the last commit that ran on hardware (hq_kernels_blocked_r3.h),
+  // launched as that commit launched them -- same grid, same LDS bytes, same arguments (BlockedGate / BlockedArg have the same
+  // layout in both namespaces; wave_bits = 0 is that commit's padding word).
+  const bool use_r3 = sw.r3 && !sw.pipe && !direct && !big && n_barriers == n_gates;
+  if (use_r3) {
+    static_assert(sizeof(r3::BlockedGate) == sizeof(BlockedGate) && sizeof(r3::BlockedArg) == sizeof(BlockedArg), "layout");
+    static_assert(r3::kBlockedTabWords == BlockedTab<512>::kWords, "address-table layout");
+    static bool r3_attr_done = false;  // under the context mutex
+    if (!r3_attr_done) {
+      const void* fns[] = {(const void*)r3::apply_blocked_kernel<float, 512, false, false>, (const void*)r3::apply_blocked_kernel<double, 512, false, false>,
+                           (const void*)r3::apply_blocked_kernel<float, 512, true, false>, (const void*)r3::apply_blocked_kernel<double, 512, true, false>,
+                           (const void*)r3::apply_blocked_kernel<float, 512, true, true>, (const void*)r3::apply_blocked_kernel<float, 512, false, true>,
+                           (const void*)r3::apply_blocked_kernel<double, 512, true, true>};
+      for (const void* f : fns) HQ_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      r3_attr_done = true;
+    }
+    const r3::BlockedGate* const rG = reinterpret_cast<const r3::BlockedGate*>(dG);
+    r3::BlockedArg rba;
+    memcpy(&rba, &ba, sizeof(rba));
+#define HQ_R3_LAUNCH(kern, lds_, ae_) HQ_LAUNCH(c, kern, dim3(grid), dim3(512), lds_, re, im, rG, n_gates, pA, ae_, rba, ntiles)
+    if (fits) {
+      const size_t lds = tile_bytes + Atab.size() * sizeof(T) + tab_bytes;
+      if (pref) HQ_R3_LAUNCH((r3::apply_blocked_kernel<T, 512, true, true>), lds, a_elems);
+      else HQ_R3_LAUNCH((r3::apply_blocked_kernel<T, 512, true, false>), lds, a_elems);
+    } else if (pref && sizeof(T) == 4) {
+      if constexpr (sizeof(T) == 4) HQ_R3_LAUNCH((r3::apply_blocked_kernel<T, 512, false, true>), tile_bytes, 0u);
+    } else {
+      HQ_R3_LAUNCH((r3::apply_blocked_kernel<T, 512, false, false>), tile_bytes, 0u);
+    }
+#undef HQ_R3_LAUNCH
+    HQ_HIP_CHECK(hipGetLastError());
+    if (describe) {
+      c.last_kernel = "blocked";
+      c.last_desc = std::string("r3::apply_blocked_kernel<") + (sizeof(T) == 4 ? "float" : "double") + ", 512> pipe=0 tb=" + std::to_string(tb) +
+                    " gates=" + std::to_string(n_gates) + " barriers=" + std::to_string(n_barriers);
+    }
+    return 0;
+  }
 #define HQ_BLOCKED_LAUNCH(kern, threads_, lds_, ae_) \
   HQ_LAUNCH(c, kern, dim3(grid), dim3(threads_), lds_, re, im, pG, n_gates, pA, ae_, ba, ntiles)
   if (fits) {
@@ -1051,7 +1093,7 @@ static void blocked_selfcheck(Context& c, const BlockedPass<T>& P, const unsigne
     return e != hipSuccess;
   };
   BlockedSwitches base = sw;
-  base.pipe = base.groups = base.direct = base.big = 0;
+  base.pipe = base.groups = base.direct = base.big = 0;  // (with base.r3 at its default: the hardware-run kernels are the reference)
   base.grid_cap = 16;
   // a handful of units in the last place of the largest amplitude a pass of <= 64 gates on |x| < 1 produces
   const double ulps = 16.0 * (sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16);

@@ -35,6 +35,9 @@
  *   HQ_BLOCKED_BIG=1     128 KiB tiles on one 1024-thread workgroup per CU (implies HQ_BLOCKED_PIPE=1)
  *   HQ_GEMM_PIPE=1       k >= 7 tile GEMM: operands requested ahead of the matrix cores in the K loop
  *   HQ_BIG_TWOBASE=1     complex128 k = 6 role kernel: second LDS base address (no scratch) + operand pipeline
+ * HQ_BLOCKED_R3 (default 1): a cache-blocked pass that uses none of the variants above is launched on the kernel family of
+ * the last commit that ran on hardware (csrc/hq_kernels_blocked_r3.h: instruction for instruction that commit's binaries,
+ * tools/isa_vs_round.py); 0: on the PIPE = false instantiations of the current family (the code the variants are built on).
  * HQ_BLOCKED_SELFCHECK (default 3): how many of the first blocked passes of a process THAT RUN ONE OF THE OPT-IN
  * VARIANTS are cross-checked against the default kernels on a scratch state (hq_blocked_selfcheck); a default run never
  * checks anything, and a check that cannot run (no memory, stream under capture) is skipped, never an error.

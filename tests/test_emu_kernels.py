@@ -172,24 +172,28 @@ def test_pipelined_loops_are_bit_identical():
     kernel and k = 5, 6 through the role kernel give the same bits as the loops hardware has run, which are the library's
     defaults (HQ_BLOCKED_PIPE=1 HQ_GEMM_PIPE=1 HQ_BIG_TWOBASE=1 select the new ones: template parameters of the same kernels)."""
     outs = {}
-    for name, extra in (('default', {}), ('new_loops', dict(HQ_BLOCKED_PIPE='1', HQ_GEMM_PIPE='1', HQ_BIG_TWOBASE='1'))):
+    for name, extra in (('default', {}), ('new_loops', dict(HQ_BLOCKED_PIPE='1', HQ_GEMM_PIPE='1', HQ_BIG_TWOBASE='1')), ('r3_off', dict(HQ_BLOCKED_R3='0'))):
         env = dict(os.environ, PYTHONPATH=ROOT, **extra)
-        for var in ('HQ_HIP_LIBRARY', 'HQ_BLOCKED_PIPE', 'HQ_GEMM_PIPE', 'HQ_BIG_TWOBASE', 'HQ_BLOCKED_GROUPS', 'HQ_BLOCKED_DIRECT', 'HQ_BLOCKED_BIG'):
+        for var in ('HQ_HIP_LIBRARY', 'HQ_BLOCKED_PIPE', 'HQ_GEMM_PIPE', 'HQ_BIG_TWOBASE', 'HQ_BLOCKED_GROUPS', 'HQ_BLOCKED_DIRECT', 'HQ_BLOCKED_BIG', 'HQ_BLOCKED_R3'):
             if var not in extra:
                 env.pop(var, None)
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'emu_ab_worker.py')], env=env, capture_output=True, text=True,
                            timeout=1800)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[name] = [ln.split() for ln in r.stdout.strip().splitlines()]
-    # the DEFAULT run launches the hardware-verified loops everywhere (VERDICT r05 next #2)
+    # the DEFAULT run launches the hardware-verified loops everywhere (VERDICT r05 next #2), the cache-blocked passes on the very
+    # kernels of the last commit that ran on hardware (hq_kernels_blocked_r3.h); HQ_BLOCKED_R3=0: the PIPE = false instantiations of
+    # hq_kernels_blocked.h the variants are built on -- all three bit-identical
     assert not any('pipe=1' in ln[1] or 'twobase=1' in ln[1] for ln in outs['default']), outs['default']
+    assert all(ln[1].startswith('r3::') for ln in outs['default'] if 'blocked' in ln[0]) and not any('r3::' in ln[1] for ln in outs['r3_off'] + outs['new_loops'])
     # (three complex128 k = 4 gates: their operand tables do not fit behind the tile, that pass computes its addresses)
     assert sum('pipe=1' in ln[1] for ln in outs['new_loops'] if 'blocked' in ln[1]) == 5
     assert sum('twobase=1' in ln[1] for ln in outs['new_loops']) == 1 and sum('twobase=0' in ln[1] for ln in outs['default']) == 1
     for o in outs.values():  # the descriptions differ in the pipe= / twobase= markers only
         for ln in o:
-            ln[1] = ln[1].replace('_pipe=1', '').replace('_pipe=0', '').replace('_twobase=1', '').replace('_twobase=0', '')
+            ln[1] = ln[1].replace('_pipe=1', '').replace('_pipe=0', '').replace('_twobase=1', '').replace('_twobase=0', '').replace('r3::', '')
     assert len(outs['default']) == 24 and outs['default'] == outs['new_loops'], [(a, b) for a, b in zip(outs['default'], outs['new_loops']) if a != b]
+    assert outs['default'] == outs['r3_off'], [(a, b) for a, b in zip(outs['default'], outs['r3_off']) if a != b]
     assert sum('gemm' in ln[1] for ln in outs['default']) >= 8 and sum('blocked' in ln[1] for ln in outs['default']) == 6
 
 

@@ -51,6 +51,9 @@ with tempfile.TemporaryDirectory() as td:
 def old_names(n):
     if re.match(r'apply_blocked_kernel<.*, true>$', n):  # (the fifth parameter was another switch then)
         return []
+    m = re.match(r'r3::apply_blocked_kernel<(.*)>$', n)   # hq_kernels_blocked_r3.h: that commit's family under its own namespace
+    if m:
+        return ['apply_blocked_kernel<%s, false>' % m.group(1), 'apply_blocked_kernel<%s>' % m.group(1)]
     cand = [n]
     m = re.match(r'apply_gemm_kernel<(\w+), (\d+), (\d+), (\d+), false>', n)
     if m:
