@@ -154,7 +154,8 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
       for (int c = 0; c < CBW; ++c) { accr[rb][c] = Acc{0, 0, 0, 0}; acci[rb][c] = Acc{0, 0, 0, 0}; }
     // the loop of rounds 1-4a: still what complex128 with 128 accumulator registers runs (no registers for a second
     // operand set), and what PIPE = false runs everywhere
-    auto plain_loop = [&]() {
+    constexpr bool kPipe = PIPE && gemm_can_pipe<T, RBW, CBW>();
+    if constexpr (!kPipe) {
     for (unsigned sg = 0; sg < a.nsg; ++sg) {
         V ur[RBW], ui[RBW];
 #pragma unroll
@@ -181,10 +182,6 @@ apply_gemm_kernel(T* __restrict__ re, T* __restrict__ im, const T* __restrict__ 
           }
         }
       }
-    };
-    constexpr bool kPipe = PIPE && gemm_can_pipe<T, RBW, CBW>();
-    if constexpr (!kPipe) {
-      plain_loop();
     } else {
     // Operands ahead of the matrix cores (round 4, from the assembly of the loop above: the B operands of a K-step were
     // requested from LDS right in front of the step's 4 RBW CBW MFMAs and the A operands of a step group from L2 at its
