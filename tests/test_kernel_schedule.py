@@ -97,3 +97,53 @@ def test_direct_first_gate_never_drains_its_stores(kernels, name):
     nxt = min(j for j in loads if j > gate_stores[-1])
     between = ins[gate_stores[-1]:nxt]
     assert not [ln for ln in between if ln.startswith('s_waitcnt') and 'vmcnt' in ln], [ln for ln in between if 'vmcnt' in ln]
+
+
+def test_default_kernels_are_the_binaries_hardware_has_run(kernels):
+    """Every kernel of hq_apply.hip that a DEFAULT run can launch -- per-gate kernels of every width (VALU, matrix-core role
+    kernels incl. complex128 k = 6 in its TWOB = false form, tile GEMM with PIPE = false, generic / naive / tile) and the
+    cache-blocked family of hq_kernels_blocked_r3.h -- compiles, instruction for instruction, to what the last commit whose
+    device code ran on a GPU compiled to (tests/golden/isa_digests_round3.json, written by `tools/isa_vs_round.py af36621
+    --digests`; the whole library: profiles/r06_isa_vs_round3.txt).  A change to shared device code that alters one of these
+    binaries fails here: it has to go behind a switch (like PIPE / TWOB / HQ_BLOCKED_R3) until hardware has run it."""
+    import hashlib
+    import json
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'isa_digests_round3.json')))['kernels']
+
+    def digest(body):
+        ins = []
+        for ln in body.splitlines():
+            if re.match(r'^\s+[a-z]', ln) and not ln.strip().startswith('.'):
+                ins.append(re.sub(r'\.LBB\d+_\d+', '.L', re.sub(r';.*$', '', ln).strip()))
+        return hashlib.sha256('\n'.join(ins).encode()).hexdigest()[:32]
+
+    def old_name(n):  # template parameters added since, at the value a default run uses
+        if n.startswith('r3::'):
+            return n[4:]
+        m = re.match(r'apply_gemm_kernel<(.*), false>$', n)
+        if m:
+            return 'apply_gemm_kernel<%s>' % m.group(1)
+        m = re.match(r'apply_mfma_big_kernel<(.*), (true|false)>$', n)
+        if m and (m.group(2) == 'false' or not m.group(1).startswith('double, 7')):
+            return 'apply_mfma_big_kernel<%s>' % m.group(1)
+        return n
+
+    checked, bad = {}, []
+    for name, body in kernels.items():
+        fam = name.split('<')[0]
+        if fam not in ('apply_direct_kernel', 'apply_mfma_kernel', 'apply_mfma_big_kernel', 'apply_gemm_kernel', 'apply_generic_kernel',
+                       'apply_naive_kernel', 'apply_mfma_tile_kernel', 'r3::apply_blocked_kernel'):
+            continue
+        if fam == 'apply_gemm_kernel' and not name.endswith(', false>'):
+            continue  # (PIPE = true: opt-in)
+        if fam == 'apply_mfma_big_kernel' and name.startswith('apply_mfma_big_kernel<double, 7') and name.endswith(', true>'):
+            continue  # (TWOB = true: opt-in)
+        old = old_name(name)
+        assert old in ref, (name, old)
+        checked[fam] = checked.get(fam, 0) + 1
+        if digest(body) != ref[old]:
+            bad.append(name)
+    assert not bad, bad
+    assert checked == {'apply_direct_kernel': 34, 'apply_mfma_kernel': 24, 'apply_mfma_big_kernel': 48, 'apply_gemm_kernel': 21, 'apply_generic_kernel': 2,
+                       'apply_naive_kernel': 2, 'apply_mfma_tile_kernel': 4, 'r3::apply_blocked_kernel': 7}, checked
+

@@ -78,6 +78,14 @@ for n, ins in sorted(new.items()):
     rows[key].append('%-62s %5d -> %5d instructions, %3d -> %3d MFMA, %d -> %d barriers, similarity %.2f' % (
         n, len(o), len(ins), sum(x.startswith('v_mfma') for x in o), sum(x.startswith('v_mfma') for x in ins),
         sum(x.startswith('s_barrier') for x in o), sum(x.startswith('s_barrier') for x in ins), ratio))
+if len(sys.argv) > 3 and sys.argv[2] == '--digests':  # sha256 of every kernel's instruction stream at `commit`, for tests/test_kernel_schedule.py
+    import hashlib
+    import json
+    json.dump({'commit': commit, 'what': 'sha256 of the normalised gfx950 instruction stream (labels -> .L, comments and directives dropped) of every kernel '
+               'of csrc/ at this commit: the device code of the last round-3 hardware leases', 'kernels': {n: hashlib.sha256('\n'.join(i).encode()).hexdigest()[:32] for n, i in sorted(old.items())}},
+              open(sys.argv[3], 'w'), indent=0)
+    print(len(old), 'digests ->', sys.argv[3])
+    raise SystemExit(0)
 print(__doc__)
 print(f'commit {commit} vs working tree: {sum(len(v) for v in rows.values())} kernels present in both')
 for key, v in rows.items():
