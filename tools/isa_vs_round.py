@@ -55,6 +55,9 @@ def old_names(n):
     if m:
         return ['apply_blocked_kernel<%s, false>' % m.group(1), 'apply_blocked_kernel<%s>' % m.group(1)]
     cand = [n]
+    m = re.match(r'bitperm_tile_kernel<(.*), (\d+)>$', n)  # (the register-prefetch parameter, always false in use, left in round 5)
+    if m:
+        cand.append('bitperm_tile_kernel<%s, false, %s>' % m.groups())
     m = re.match(r'apply_gemm_kernel<(\w+), (\d+), (\d+), (\d+), false>', n)
     if m:
         cand.append('apply_gemm_kernel<%s, %s, %s, %s>' % m.groups())
