@@ -102,7 +102,8 @@ def test_direct_first_gate_never_drains_its_stores(kernels, name):
 def test_default_kernels_are_the_binaries_hardware_has_run(kernels):
     """Every kernel of hq_apply.hip that a DEFAULT run can launch -- per-gate kernels of every width (VALU, matrix-core role
     kernels incl. complex128 k = 6 in its TWOB = false form, tile GEMM with PIPE = false, generic / naive / tile) and the
-    cache-blocked family of hq_kernels_blocked_r3.h -- compiles, instruction for instruction, to what the last commit whose
+    cache-blocked family of hq_kernels_blocked_r3.h, and every kernel of hq_swap.hip (swaps, one-pass bit permutations,
+    to_complex) -- compiles, instruction for instruction, to what the last commit whose
     device code ran on a GPU compiled to (tests/golden/isa_digests_round3.json, written by `tools/isa_vs_round.py af36621
     --digests`; the whole library: profiles/r06_isa_vs_round3.txt).  A change to shared device code that alters one of these
     binaries fails here: it has to go behind a switch (like PIPE / TWOB / HQ_BLOCKED_R3) until hardware has run it."""
@@ -128,7 +129,30 @@ def test_default_kernels_are_the_binaries_hardware_has_run(kernels):
             return 'apply_mfma_big_kernel<%s>' % m.group(1)
         return n
 
+    # the swap / permutation / to_complex kernels as well (rows a7, a11-a13 of SURVEY section 8 and the pack pass of the exchange)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, 'hq_swap.s')
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
+                               os.path.join(ROOT, 'hybridq_amd', 'csrc', 'hq_swap.hip'), '-o', asm], stderr=subprocess.DEVNULL)
+        funcs = re.split(r'\n(?=\s*\.globl\s)', open(asm).read())
+    named = [(m.group(1), f) for f in funcs for m in [re.search(r'\.globl\s+(\S+)', f)] if m]
+    dem = subprocess.run(['c++filt'], input='\n'.join(n for n, _ in named), capture_output=True, text=True).stdout.splitlines()
+    swap_kernels = {re.sub(r'\(.*$', '', d).replace('void hq::', ''): f for (_, f), d in zip(named, dem)}
     checked, bad = {}, []
+    for name, body in swap_kernels.items():
+        fam = name.split('<')[0]
+        if fam.startswith('__hip') or fam == 'hq::upload_kernel':
+            continue
+        m = re.match(r'bitperm_tile_kernel<(.*), (\d+)>$', name)  # (the register-prefetch parameter, always false in use, left in round 5)
+        old = 'bitperm_tile_kernel<%s, false, %s>' % m.groups() if m else name
+        assert old in ref, (name, old)
+        checked[fam] = checked.get(fam, 0) + 1
+        if digest(body) != ref[old]:
+            bad.append(name)
+    assert not bad, bad
+    assert checked.get('bitperm_tile_kernel') == 36 and checked.get('swap_lds_kernel') == 8 and checked.get('interleave4_kernel') == 2 and len(checked) >= 6, checked
+    checked = {}
     for name, body in kernels.items():
         fam = name.split('<')[0]
         if fam not in ('apply_direct_kernel', 'apply_mfma_kernel', 'apply_mfma_big_kernel', 'apply_gemm_kernel', 'apply_generic_kernel',
