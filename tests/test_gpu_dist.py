@@ -259,7 +259,7 @@ def test_sharded_one_rank_per_gpu_over_rccl(torch_cuda, tmp_path, world, capsys)
     """Lights up by itself on a box with >= `world` GPUs (skipped on a one-GPU box; runs against tests/emu/rccl_emu.cpp in the
     CPU suite): one process per GPU on the nccl backend, so HipBackend takes the RCCL transport -- a communicator of `world`
     ranks made by the LIBRARY (hq_shard_init_rccl), grouped ncclSend / ncclRecv over xGMI -- and runs the BASELINE config-3
-    generator at n = 24 + g (plain exchanges, exchanges with the folded eviction permutation, exchanges in rounds with the
+    generator at n = 22 + g (plain exchanges, exchanges with the folded eviction permutation, exchanges in rounds with the
     local gates applied to the pieces as they land) and the config-5 noisy-dm generator, each against the reference core
     driven by the reference protocol on ONE process.  No reference counterpart (simulation.py:379-380: no multi-process
     path); oracle: /root/reference/include/U.h:28-202 via oracle.evolve_reference_protocol."""
@@ -276,7 +276,7 @@ def test_sharded_one_rank_per_gpu_over_rccl(torch_cuda, tmp_path, world, capsys)
     from hybridq_amd.circuits import rqc_1q2q
     from tolerances import circuit_tol
     g = int(np.log2(world))
-    n = (14 if EMU else 24) + g
+    n = (14 if EMU else 22) + g  # (every rank gathers the full state for the comparison: 2^25 amplitudes at world 8)
     n_dm = 2 * ((n + 1) // 2)
     mp.spawn(_per_gpu_worker, args=(world, _free_port(), n, n_dm, str(tmp_path)), nprocs=world, join=True)
     out = np.load(os.path.join(str(tmp_path), 'per_gpu.npz'))
