@@ -559,6 +559,19 @@ def _functional_qubits(g):
     return None if qs is None else tuple(qs)
 
 
+def _fusion_items(circuit):
+    """The circuit as fusion.simplify / fusion.fuse take it: ``(U, qubits)`` pairs, FunctionalGates wrapped as fusion.Opaque."""
+    from .fusion import Opaque
+    items = []
+    for g in circuit:
+        if _is_functional(g):
+            items.append(Opaque(g, _functional_qubits(g)))
+        else:
+            qs, U = _gate_qubits_matrix(g)
+            items.append((U, qs))
+    return items
+
+
 def _simplify_runs(circuit, remove_id_gates, atol, opts):
     """``utils.simplify`` (fusion.simplify) on the whole circuit.  FunctionalGates take part the way they do in the
     reference's walk (insert_from_left, circuit/utils.py:166-208; fusion.Opaque): they slide past gates on other qubits and
@@ -568,8 +581,7 @@ def _simplify_runs(circuit, remove_id_gates, atol, opts):
     if not any(_is_functional(g) for g in circuit):
         gates = _simplify([(U, qs) for qs, U in (_gate_qubits_matrix(g) for g in circuit)], atol=atol, remove_id_gates=remove_id_gates, **opts)
         return [(U, qs) for U, qs in gates]
-    items = [Opaque(g, _functional_qubits(g)) if _is_functional(g) else (lambda qu: (qu[1], qu[0]))(_gate_qubits_matrix(g)) for g in circuit]
-    out = _simplify(items, atol=atol, remove_id_gates=remove_id_gates, **{k: v for k, v in opts.items() if k != 'native'})
+    out = _simplify(_fusion_items(circuit), atol=atol, remove_id_gates=remove_id_gates, **{k: v for k, v in opts.items() if k != 'native'})
     return [g.obj if isinstance(g, Opaque) else g for g in out]
 
 
@@ -605,8 +617,7 @@ def _plan_ops(circuit, qubits, n, ctype, compress, blocked, reference=True):
     pos_of = {q: n - x - 1 for x, q in enumerate(qubits)}  # simulation.py:512 (never permuted here)
     if comp_n and not use_blocked and any(_is_functional(g) for g in circuit):
         from .fusion import Opaque, fuse
-        items = [Opaque(g, _functional_qubits(g)) if _is_functional(g) else (lambda qu: (qu[1], qu[0]))(_gate_qubits_matrix(g)) for g in circuit]
-        fused = fuse(items, comp_n, complex_type=ctype, reference_matrices=reference, **{k: v for k, v in comp_kw.items() if k != 'native'})
+        fused = fuse(_fusion_items(circuit), comp_n, complex_type=ctype, reference_matrices=reference, **{k: v for k, v in comp_kw.items() if k != 'native'})
         return [g.obj if isinstance(g, Opaque) else (g[1], g[0]) for g in fused]
     gates, run = [], []
 
