@@ -15,15 +15,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope='module')
-def kernels(tmp_path_factory):
-    asm = str(tmp_path_factory.mktemp('isa') / 'hq_apply.s')
+def _kernels_of(unit, workdir):
+    """{demangled kernel name: assembly text} of one translation unit of csrc/, compiled for gfx950 (no GPU needed)."""
+    asm = os.path.join(str(workdir), unit + '.s')
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
-                           os.path.join(ROOT, 'hybridq_amd', 'csrc', 'hq_apply.hip'), '-o', asm], stderr=subprocess.DEVNULL)
+                           os.path.join(ROOT, 'hybridq_amd', 'csrc', unit + '.hip'), '-o', asm], stderr=subprocess.DEVNULL)
     funcs = re.split(r'\n(?=\s*\.globl\s)', open(asm).read())
     named = [(m.group(1), f) for f in funcs for m in [re.search(r'\.globl\s+(\S+)', f)] if m]
     dem = subprocess.run(['c++filt'], input='\n'.join(n for n, _ in named), capture_output=True, text=True).stdout.splitlines()
     return {re.sub(r'\(.*$', '', d).replace('void hq::', ''): f for (_, f), d in zip(named, dem)}
+
+
+@pytest.fixture(scope='module')
+def kernels(tmp_path_factory):
+    return _kernels_of('hq_apply', tmp_path_factory.mktemp('isa'))
 
 
 def _instructions(body):
@@ -99,7 +104,7 @@ def test_direct_first_gate_never_drains_its_stores(kernels, name):
     assert not [ln for ln in between if ln.startswith('s_waitcnt') and 'vmcnt' in ln], [ln for ln in between if 'vmcnt' in ln]
 
 
-def test_default_kernels_are_the_binaries_hardware_has_run(kernels):
+def test_default_kernels_are_the_binaries_hardware_has_run(kernels, tmp_path):
     """Every kernel of hq_apply.hip that a DEFAULT run can launch -- per-gate kernels of every width (VALU, matrix-core role
     kernels incl. complex128 k = 6 in its TWOB = false form, tile GEMM with PIPE = false, generic / naive / tile) and the
     cache-blocked family of hq_kernels_blocked_r3.h, and every kernel of hq_swap.hip (swaps, one-pass bit permutations,
@@ -130,15 +135,7 @@ def test_default_kernels_are_the_binaries_hardware_has_run(kernels):
         return n
 
     # the swap / permutation / to_complex kernels as well (rows a7, a11-a13 of SURVEY section 8 and the pack pass of the exchange)
-    import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, 'hq_swap.s')
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
-                               os.path.join(ROOT, 'hybridq_amd', 'csrc', 'hq_swap.hip'), '-o', asm], stderr=subprocess.DEVNULL)
-        funcs = re.split(r'\n(?=\s*\.globl\s)', open(asm).read())
-    named = [(m.group(1), f) for f in funcs for m in [re.search(r'\.globl\s+(\S+)', f)] if m]
-    dem = subprocess.run(['c++filt'], input='\n'.join(n for n, _ in named), capture_output=True, text=True).stdout.splitlines()
-    swap_kernels = {re.sub(r'\(.*$', '', d).replace('void hq::', ''): f for (_, f), d in zip(named, dem)}
+    swap_kernels = _kernels_of('hq_swap', tmp_path)
     checked, bad = {}, []
     for name, body in swap_kernels.items():
         fam = name.split('<')[0]
