@@ -397,3 +397,77 @@ def test_evolution_einsum_alias_runs_on_the_one_engine(monkeypatch):
         assert seen == {'compress': 4, 'blocked': False}  # not the automatic schedule: the reference's default
     with pytest.raises(ValueError, match="only implements optimize='evolution'"):
         sim.simulate([(np.eye(2), (0,))], initial_state='0', optimize='tn')
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_opaque_walks_preserve_the_circuits_action(seed):
+    """fusion.simplify / compress / fuse on circuits with gates WITHOUT a matrix (fusion.Opaque: the reference's FunctionalGate
+    family) -- independent of the reference: every opaque element here is secretly a random (non-unitary) matrix on its
+    qubits, so the transformed circuit with the secrets put back must act exactly like the original one.  Checks that the
+    walks only ever move an element past elements on other qubits (or past matrix gates that commute), that an element
+    without qubits is a wall for everything, and that nothing is merged into an opaque element."""
+    import oracle
+    from hybridq_amd.fusion import Opaque, compress, fuse, simplify
+    rng = np.random.default_rng(100 + seed)
+    n = 7
+
+    def rand_gate(k):
+        qs = tuple(int(q) for q in rng.permutation(n)[:k])
+        U = rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k))
+        if rng.random() < 0.6:
+            U = np.linalg.qr(U)[0]
+        else:
+            U /= np.linalg.norm(U, 2)
+        return U, qs
+
+    circuit, secret = [], {}
+    for i in range(60):
+        r = rng.random()
+        if r < 0.2:
+            k = int(rng.integers(0, 3))
+            U, qs = rand_gate(k) if k else (np.array([[rng.standard_normal() + 0.5j]]), ())
+            op = Opaque(('fn', i), qs)
+            secret[id(op)] = (U, qs)
+            circuit.append(op)
+        elif r < 0.3:  # pairs that commute exactly (diagonal gates) and inverse pairs: what simplify slides and cancels
+            qs = tuple(int(q) for q in rng.permutation(n)[:2])
+            circuit.append((np.diag(np.exp(1j * rng.standard_normal(4))), qs))
+            circuit.append((np.diag(np.exp(1j * rng.standard_normal(2))), qs[:1]))
+        elif r < 0.36:
+            U, qs = rand_gate(2)
+            U = np.linalg.qr(U)[0]
+            circuit += [(U, qs), (U.conj().T, qs)]
+        else:
+            circuit.append(rand_gate(int(rng.integers(1, 4))))
+    wall = Opaque(('wall',), None)  # declares no qubits: in truth it acts on all of them
+    Uw = np.linalg.qr(rng.standard_normal((1 << n, 1 << n)) + 1j * rng.standard_normal((1 << n, 1 << n)))[0]
+    secret[id(wall)] = (Uw, tuple(range(n)))
+    circuit.insert(30, wall)
+
+    def reveal(items):
+        return [secret[id(g)] if isinstance(g, Opaque) else g for g in items]
+
+    init = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    exp = oracle.evolve_tensordot(reveal(circuit), n, initial_state=init, qubits=list(range(n)))
+    scale = np.abs(exp).max()
+    for use_comm in (True, False):
+        simp = simplify(circuit, use_matrix_commutation=use_comm, remove_id_gates=True)
+        assert sum(isinstance(g, Opaque) for g in simp) == len(secret) and len(simp) <= len(circuit)
+        got = oracle.evolve_tensordot(reveal(simp), n, initial_state=init, qubits=list(range(n)))
+        assert np.abs(got - exp).max() / scale < 1e-9, ('simplify', use_comm)
+        for width in (2, 4, 6):
+            layers = compress(simp, width, use_matrix_commutation=use_comm)
+            assert all(len(L) == 1 for L in layers if any(isinstance(g, Opaque) for g in L))  # nothing merges into an opaque element
+            flat = [g for L in layers for g in L]
+            got = oracle.evolve_tensordot(reveal(flat), n, initial_state=init, qubits=list(range(n)))
+            assert np.abs(got - exp).max() / scale < 1e-9, ('compress', use_comm, width)
+            for ref_mats in (False, True):
+                fused = fuse(simp, width, complex_type='complex128', use_matrix_commutation=use_comm, reference_matrices=ref_mats)
+                assert len(fused) == len(layers) and all(isinstance(f, Opaque) or len(f[1]) <= max(width, 3) for f in fused)
+                got = oracle.evolve_tensordot(reveal(fused), n, initial_state=init, qubits=list(range(n)))
+                assert np.abs(got - exp).max() / scale < 1e-9, ('fuse', use_comm, width, ref_mats)
+    # the wall: no element crosses it, in either walk
+    for out in (simplify(circuit), [g for L in compress(circuit, 4) for g in L]):
+        w = next(i for i, g in enumerate(out) if g is wall)
+        before = {id(g) for g in circuit[:30] if isinstance(g, Opaque)}
+        assert {id(g) for g in out[:w] if isinstance(g, Opaque)} == before
