@@ -14,6 +14,8 @@ import re
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -22,6 +24,7 @@ def _workers():
     return max(2, min(_usable_cpus(), 16))
 
 
+@pytest.mark.timeout(4200)  # (HQ_EMU_FULL=1: a quarter of an hour; the inner run has its own per-test timeout)
 def test_gpu_tests_pass_against_the_emulated_library():
     full = os.environ.get('HQ_EMU_FULL') == '1'
     env = dict(os.environ, HQ_EMU_GPU_SUITE='1', HQ_EMU_QUICK='0' if full else '1', PYTHONPATH=ROOT)
@@ -127,9 +130,8 @@ def test_bench_line_survives_a_kill_after_the_timed_region():
     assert set(lines[1]['extras']['skipped_for_budget']) >= {'fused', 'blocked', 'per_k', 'aux', 'parity_check'} and 'blocked' not in lines[1]
 
 
-import pytest  # noqa: E402
 
-
+@pytest.mark.timeout(4200)
 @pytest.mark.parametrize('transport', ['p2p', 'rccl'])
 def test_multi_rank_gpu_tests_against_the_emulated_library(transport):
     """The multi-rank `-m gpu` tests -- 2 and 4 ranks on the real HipBackend, the sharded simulate() / dm.simulate() API,
