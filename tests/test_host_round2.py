@@ -60,6 +60,12 @@ def test_choose_schedule_cost_model():
     hard = g29[:400] + [FunctionalGate((0,), lambda psi, order: (psi, order))] + g29[400:]
     hard[400].qubits = None  # a functional gate that declares no qubits stops every gate (circuit/utils.py:618-622)
     assert _predict_fused_ms(hard, 29, np.dtype('complex64'), 4) >= p_cut
+    # the cache-blocked planner with several seeds keeps the best plan by modelled time (never worse than the first seed)
+    from hybridq_amd.blocking import plan_blocked
+    ident29 = {q: 28 - q for q in range(29)}
+    one = estimate_ms(plan_blocked(g29, ident29, 29), 29, np.dtype('complex64'))
+    four = estimate_ms(plan_blocked(g29, ident29, 29, seeds=4), 29, np.dtype('complex64'))
+    assert four <= one and four >= 0.9 * one
     # wide gates are priced by their own width
     wide = [g for g in random_dense(20, 40, kmax=7, seed=3) if len(g[1]) >= 6][:3]
     _, w = choose_schedule(wide, list(range(20)), 20, np.dtype('complex64'))

@@ -26,7 +26,7 @@ low_bits = int(os.environ.get('HQ_AB_LOW_BITS', 5 if ctype == 'complex64' else 4
 report = {}
 for kw in ((dict(),) if mode == 'json' else (dict(), dict(inner_max=0))):
     t_p = time.perf_counter()
-    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=low_bits, complex_type=ctype), **kw})
+    ops = plan_blocked(gates, state.map, n, **{**dict(tile_bits=tb, low_bits=low_bits, complex_type=ctype, seeds=int(os.environ.get('HQ_AB_SEEDS', '4'))), **kw})  # (best of 4 seeds by modelled time: host work before the clock, reported as plan_seconds)
     t_plan = time.perf_counter() - t_p
     packed = [('B', op[1], core.pack_blocked(op[2], ctype)) if op[0] == 'B' else op for op in ops]
 
