@@ -161,6 +161,13 @@ class _Layer:
         # always kept here -- it is the output
         self.has_matrix = has_matrix
 
+    @classmethod
+    def of_opaque(cls, item):
+        """The layer an Opaque element opens: never merged into, no matrix."""
+        L = cls.__new__(cls)
+        L.gates, L.qubits, L.U, L.compress, L.has_matrix, L.opaque = [item], item.qubits, None, False, False, item
+        return L
+
     def merge(self, U, qs, has_matrix=True):
         self.gates.append((U, qs))
         self.has_matrix = self.has_matrix and has_matrix
@@ -175,9 +182,7 @@ def _build_layers(gates, max_n_qubits, use_matrix_commutation, max_n_qubits_matr
     exclude = set(exclude_qubits or ())
     for item in gates:
         if isinstance(item, Opaque):  # never merged anywhere: a layer of its own at the end (see Opaque)
-            L = _Layer.__new__(_Layer)
-            L.gates, L.qubits, L.U, L.compress, L.has_matrix, L.opaque = [item], item.qubits, None, False, False, item
-            layers.append(L)
+            layers.append(_Layer.of_opaque(item))
             continue
         U, qs = item
         q = set(qs)
